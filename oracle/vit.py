@@ -1,0 +1,149 @@
+"""Oracle: ViT backbone forward (TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py).
+
+Restates the arithmetic of timm==0.9.2 `VisionTransformer.forward` for the
+`vit_*_patch{8,16}_224.dino` family, which the reference obtains through
+`timm.create_model(name, pretrained=True)` (CARL_MVF/models/transformer.py:59)
+and taps with forward hooks on `blocks.{i}` (transformer.py:306-333).  timm is an
+un-vendored dependency and is absent offline, so this file follows its
+published algorithm:
+
+    x = Conv2d(3, D, k=P, s=P)(img).flatten(2).transpose(1, 2)       # patch_embed
+    x = cat([cls_token, x], 1) + pos_embed                            # _pos_embed
+    for blk:  x = x + ls1(attn(LN(x)));  x = x + ls2(mlp(LN(x)))      # pre-LN, eps 1e-6
+    attn: qkv = Linear(D, 3D); reshape(B, N, 3, H, hd); softmax(q k^T hd^-.5) v; Linear
+    mlp : Linear(D, 4D) -> exact (erf) GELU -> Linear(4D, D)
+    out = LN(x)[:, 0]                                                  # global_pool='token'
+
+Weights are a flat dict keyed with timm's state-dict names.  PARITY UNPINNED by
+the reference for this file (no reference test / vector exists); cross-checked
+against HuggingFace `transformers.ViTModel` in tests/test_oracle_vit.py.
+"""
+import math
+import torch
+import torch.nn.functional as F
+
+
+def vit_dims(name):
+    """(embed_dim, depth, heads, patch, has_layerscale) for the model names the
+    reference accepts (CARL_MVF/models/transformer.py:43-54)."""
+    table = {
+        'vit_small_patch16_224.dino': (384, 12, 6, 16, False),
+        'vit_small_patch8_224.dino': (384, 12, 6, 8, False),
+        'vit_base_patch16_224.dino': (768, 12, 12, 16, False),
+        'vit_base_patch8_224.dino': (768, 12, 12, 8, False),
+        'vit_small_patch14_dinov2.lvd142m': (384, 12, 6, 14, True),
+        'vit_base_patch14_dinov2.lvd142m': (768, 12, 12, 14, True),
+        'vit_large_patch14_dinov2.lvd142m': (1024, 24, 16, 14, True),
+        'vit_giant_patch14_dinov2.lvd142m': (1536, 40, 24, 14, True),
+    }
+    return table[name]
+
+
+def init_vit_weights(dim, depth, patch, img=224, seed=0, dtype=torch.float32, layerscale=False):
+    """Seeded random ViT weights (trunc-normal 0.02 like timm's init; LN weights
+    jittered so that a swapped gamma/beta would be caught)."""
+    g = torch.Generator().manual_seed(seed)
+    n = (img // patch) ** 2 + 1
+
+    def tn(*shape, std=0.02):
+        return (torch.randn(*shape, generator=g, dtype=torch.float64) * std).clamp_(-2 * std, 2 * std).to(dtype)
+
+    w = {
+        'cls_token': tn(1, 1, dim),
+        'pos_embed': tn(1, n, dim),
+        'patch_embed.proj.weight': tn(dim, 3, patch, patch),
+        'patch_embed.proj.bias': tn(dim),
+        'norm.weight': 1.0 + tn(dim, std=0.1),
+        'norm.bias': tn(dim, std=0.1),
+    }
+    for i in range(depth):
+        p = 'blocks.%d.' % i
+        w[p + 'norm1.weight'] = 1.0 + tn(dim, std=0.1)
+        w[p + 'norm1.bias'] = tn(dim, std=0.1)
+        w[p + 'attn.qkv.weight'] = tn(3 * dim, dim)
+        w[p + 'attn.qkv.bias'] = tn(3 * dim)
+        w[p + 'attn.proj.weight'] = tn(dim, dim)
+        w[p + 'attn.proj.bias'] = tn(dim)
+        w[p + 'norm2.weight'] = 1.0 + tn(dim, std=0.1)
+        w[p + 'norm2.bias'] = tn(dim, std=0.1)
+        w[p + 'mlp.fc1.weight'] = tn(4 * dim, dim)
+        w[p + 'mlp.fc1.bias'] = tn(4 * dim)
+        w[p + 'mlp.fc2.weight'] = tn(dim, 4 * dim)
+        w[p + 'mlp.fc2.bias'] = tn(dim)
+        if layerscale:
+            w[p + 'ls1.gamma'] = 1.0 + tn(dim, std=0.1)
+            w[p + 'ls2.gamma'] = 1.0 + tn(dim, std=0.1)
+    return w
+
+
+def patchify(img, patch):
+    """[F,3,H,W] -> [F, (H/P)*(W/P), 3*P*P] with k = c*P*P + ky*P + kx, the
+    flattening order of a Conv2d weight [D,3,P,P]."""
+    f, c, h, w = img.shape
+    gh, gw = h // patch, w // patch
+    x = img.reshape(f, c, gh, patch, gw, patch)
+    x = x.permute(0, 2, 4, 1, 3, 5)  # f, gh, gw, c, ky, kx
+    return x.reshape(f, gh * gw, c * patch * patch)
+
+
+def layer_norm(x, w, b, eps):
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def gelu_erf(x):
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def vit_block(x, w, p, heads, eps=1e-6):
+    f, n, d = x.shape
+    hd = d // heads
+    h = layer_norm(x, w[p + 'norm1.weight'], w[p + 'norm1.bias'], eps)
+    qkv = h @ w[p + 'attn.qkv.weight'].t() + w[p + 'attn.qkv.bias']
+    qkv = qkv.reshape(f, n, 3, heads, hd).permute(2, 0, 3, 1, 4)  # 3, f, H, n, hd
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    s = (q * hd ** -0.5) @ k.transpose(-1, -2)
+    a = torch.softmax(s, dim=-1) @ v  # f, H, n, hd
+    a = a.transpose(1, 2).reshape(f, n, d)
+    a = a @ w[p + 'attn.proj.weight'].t() + w[p + 'attn.proj.bias']
+    if p + 'ls1.gamma' in w:
+        a = a * w[p + 'ls1.gamma']
+    x = x + a
+    h = layer_norm(x, w[p + 'norm2.weight'], w[p + 'norm2.bias'], eps)
+    h = gelu_erf(h @ w[p + 'mlp.fc1.weight'].t() + w[p + 'mlp.fc1.bias'])
+    h = h @ w[p + 'mlp.fc2.weight'].t() + w[p + 'mlp.fc2.bias']
+    if p + 'ls2.gamma' in w:
+        h = h * w[p + 'ls2.gamma']
+    return x + h
+
+
+def vit_embed(img, w, patch):
+    """patch_embed + cls + pos: [F,3,H,W] -> [F, 1+N, D]."""
+    dim = w['patch_embed.proj.weight'].shape[0]
+    x = patchify(img, patch) @ w['patch_embed.proj.weight'].reshape(dim, -1).t() + w['patch_embed.proj.bias']
+    cls = w['cls_token'].expand(x.shape[0], -1, -1)
+    return torch.cat([cls, x], 1) + w['pos_embed']
+
+
+def vit_forward(img, w, heads, patch, taps=(3, 7, 11), eps=1e-6, first_block=0, last_block=None, x_in=None):
+    """Returns (features, cls_out):
+      features [F, 1+N, D*len(taps)]: outputs of blocks `taps`, channel-concatenated
+          (FeatureExtractor, CARL_MVF/models/transformer.py:322-333; CLS row kept,
+          dropped later at transformer.py:204)
+      cls_out  [F, D]: final LN, token 0 (timm forward_head with global_pool='token',
+          num_classes=0)
+    first_block/last_block/x_in restate the ViTFrontEnd/ViTBackEnd split
+    (transformer.py:342-392).
+    """
+    depth = 1 + max(int(k.split('.')[1]) for k in w if k.startswith('blocks.'))
+    last_block = depth if last_block is None else last_block
+    x = vit_embed(img, w, patch) if x_in is None else x_in
+    feats = {}
+    for i in range(first_block, last_block):
+        x = vit_block(x, w, 'blocks.%d.' % i, heads, eps)
+        if i in taps:
+            feats[i] = x
+    out = layer_norm(x, w['norm.weight'], w['norm.bias'], eps)[:, 0] if last_block == depth else x
+    features = torch.cat([feats[i] for i in taps], dim=2) if taps else None
+    return features, out

@@ -1,0 +1,161 @@
+/* mvf_hip.h -- C ABI of libmvf_hip.so: the MI355X (gfx950) kernels of the MV-Former SCL training step.
+ *
+ * The reference (facebookresearch/video_rep_learning, CARL_MVF/) is pure Python on PyTorch and has no
+ * FFI of its own; its hot path reaches native code only through ATen.  This header is the boundary a
+ * maintainer binds instead (ctypes stub: INTEGRATION.md).  Every entry point lists the reference code
+ * whose arithmetic it replaces (paths relative to /root/reference/CARL_MVF).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes, no framework types; all pointers are DEVICE pointers unless named *_host
+ *   - the caller owns every buffer (incl. workspaces); nothing is allocated, freed or synchronised inside
+ *   - work is enqueued on `stream`; returns 0 (MVF_OK) or MVF_ERR_* (bad argument, checked on the host
+ *     BEFORE any launch) or a hipError_t value; never throws
+ *   - fp32 tensors are `float`; bf16 tensors are raw 16-bit words (`void*` with a dtype code)
+ *   - row-major, innermost dimension contiguous unless a stride argument says otherwise
+ */
+#ifndef MVF_HIP_H_
+#define MVF_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVF_F32 0
+#define MVF_BF16 1
+
+/* gemm_tc epilogues */
+#define MVF_EPI_STORE 0 /* C = A W^T + b                                  */
+#define MVF_EPI_GELU 1  /* C = gelu_erf(A W^T + b)                        */
+#define MVF_EPI_RESID 2 /* resid += ls * (A W^T + b) ; optional tap copy   */
+#define MVF_EPI_PATCH 3 /* resid[f, 1+p] = A W^T + b + pos[1+p]            */
+
+/* ------------------------------------------------------------------------------------------------
+ * Frozen ViT backbone (forward only)
+ *   replaces: timm VisionTransformer.forward as called by models/transformer.py:59,188,322-331 and the
+ *   FeatureExtractor hook/concat + CLS-drop/movedim/reshape copies of transformer.py:199-214,306-333
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct MvfVitWeights {
+  int depth, dim, heads, patch, img, n_taps;
+  int taps[8];                 /* block indices whose OUTPUT is tapped (SMART_FEATS), ascending */
+  float ln_eps;                /* 1e-6 for timm ViT */
+  const float* cls_token;      /* [dim]            */
+  const float* pos_embed;      /* [1+P, dim]       */
+  const void* patch_w;         /* [dim, 3*p*p] dtype T (k = c*p*p + ky*p + kx) */
+  const float* patch_b;        /* [dim]            */
+  const float* norm_w;         /* final norm [dim] */
+  const float* norm_b;
+  /* per-block arrays of HOST-resident pointer tables (each table has `depth` device pointers) */
+  const float* const* ln1_w; const float* const* ln1_b;
+  const void* const* qkv_w;  const float* const* qkv_b;   /* [3*dim, dim] T, [3*dim] */
+  const void* const* proj_w; const float* const* proj_b;  /* [dim, dim]   T, [dim]   */
+  const float* const* ln2_w; const float* const* ln2_b;
+  const void* const* fc1_w;  const float* const* fc1_b;   /* [4*dim, dim] T */
+  const void* const* fc2_w;  const float* const* fc2_b;   /* [dim, 4*dim] T */
+  const float* const* ls1;   const float* const* ls2;     /* LayerScale gamma tables or NULL */
+} MvfVitWeights;
+
+size_t mvf_vit_workspace_bytes(int dtype, int frames_per_chunk, int tokens, int dim, int patch);
+
+/* frames [F,3,img,img] fp32 (normalised) -> taps_out[j] [F*(tokens-1), dim] dtype T (block taps[j] output,
+ * CLS row dropped), cls_out [F, dim] fp32 (final LN, token 0; may be NULL).  frames_per_chunk <= 0: all. */
+int mvf_vit_fwd(const MvfVitWeights* w, int dtype, const float* frames, int F, void* const* taps_out, float* cls_out,
+                void* workspace, size_t ws_bytes, int frames_per_chunk, int attn_variant, hipStream_t stream);
+
+/* pieces of the same path, exported for unit parity tests */
+int mvf_gemm_tc(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
+                float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tokens_per_frame, int M,
+                int N, int K, hipStream_t stream);
+int mvf_patchify(int dtype, const float* frames, void* out, int F, int H, int W, int P, hipStream_t stream);
+int mvf_layernorm_fwd(int out_dtype, const float* x, size_t in_stride, const float* g, const float* b, void* y,
+                      size_t out_stride, int rows, int D, float eps, hipStream_t stream);
+int mvf_vit_attn_fwd(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t stream);
+int mvf_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Trainable head, fp32, forward + backward
+ * ---------------------------------------------------------------------------------------------- */
+/* C[m,n] (+)= act(alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] + bias[n] + table[((m/div)%mod)*tab_si + n*tab_sn])
+ *   replaces every nn.Linear fwd / input-grad / weight-grad on the path (models/mvformer.py:77,86,97;
+ *   models/utils.py:65-68,182-183; models/resnet_c2d.py:117-120) and the PE add of utils.py:136-145 (table) */
+int mvf_hgemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
+              const float* bias, const float* table, long tab_si, long tab_sn, int tab_div, int tab_mod, int M, int N,
+              int K, float alpha, int relu, int accumulate, hipStream_t stream);
+int mvf_colsum(const float* x, long ld, int rows, int cols, float* out, int accumulate, hipStream_t stream);
+
+/* dx = dy * [y > 0]  (ReLU backward of the FFN, models/utils.py:190) */
+int mvf_relu_bwd(const float* dy, const float* y, float* dx, size_t n, hipStream_t stream);
+
+/* y = resid + dropout_p(x) with a counter-based mask (nn.Dropout + residual add, models/utils.py:153-159;
+ * mvformer.py:76; resid may be NULL); backward = same call on dy with resid = NULL */
+int mvf_dropout_add(const float* x, const float* resid, float* y, size_t n, float p, uint64_t seed, uint64_t offset,
+                    hipStream_t stream);
+
+/* LayerNorm  (models/utils.py:147-159, eps 1e-5) */
+int mvf_ln_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int rows, int D,
+               float eps, hipStream_t stream);
+int mvf_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, float* dx, float* dg,
+               float* db, int rows, int D, int accumulate_dx, hipStream_t stream);
+
+/* BatchNorm1d (+fused ReLU)  (models/mvformer.py:78-79, resnet_c2d.py:118-119); SyncBN = caller merges the
+ * (mean, var) / (s1, s2) vectors across ranks between the two halves (train.py:283) */
+int mvf_bn_stats(const float* x, int rows, int C, float* mean, float* var, hipStream_t stream);
+int mvf_bn_fwd(const float* x, const float* mean, const float* var, const float* g, const float* b, float* y, int rows,
+               int C, float eps, int relu, hipStream_t stream);
+int mvf_bn_bwd_reduce(const float* dy, const float* x, const float* mean, const float* var, const float* g, const float* b,
+                      float* s1, float* s2, int rows, int C, float eps, int relu, hipStream_t stream);
+int mvf_bn_bwd_apply(const float* dy, const float* x, const float* mean, const float* var, const float* g, const float* b,
+                     const float* s1, const float* s2, float* dx, int rows, int C, float eps, int relu, float count,
+                     hipStream_t stream);
+
+/* entity one-hot concat (mvformer.py:144-149), entity reduction (mvformer.py:181-195), F.normalize (transformer.py:228) */
+int mvf_concat_onehot(const float* x, float* out, int rows, int cin, int ntok, int div, hipStream_t stream);
+int mvf_final_reduce_fwd(const float* x, float* y, int* arg, int B, int ntok, int T, int D, int mode, hipStream_t stream);
+int mvf_final_reduce_bwd(const float* dy, const int* arg, float* dx, int B, int ntok, int T, int D, int mode,
+                         hipStream_t stream);
+int mvf_l2norm_fwd(const float* x, float* y, float* nrm, int rows, int D, float eps, hipStream_t stream);
+int mvf_l2norm_bwd(const float* dy, const float* y, const float* nrm, float* dx, int rows, int D, float eps,
+                   hipStream_t stream);
+
+/* temporal multi-head self-attention (models/utils.py:11-44,88-104); qkv [B*S, 3*Dm], mask [B,S] or NULL */
+int mvf_tattn_fwd(const float* qkv, const float* mask, float* o, float* lse, int B, int S, int H, int Dm,
+                  hipStream_t stream);
+int mvf_tattn_bwd(const float* qkv, const float* mask, const float* o, const float* lse, const float* d_o, float* dqkv,
+                  int B, int S, int H, int Dm, hipStream_t stream);
+
+/* LSTP learned-query pooling passes over the tap tensors (models/mvformer.py:243-266,352-414) */
+int mvf_lstp_scores(const void* const* taps_host, int n_taps, int dtype, int D, int F, int N, int T, int nq,
+                    const float* vec, int per_frame, float* scores, hipStream_t stream);
+int mvf_lstp_wsum(const void* const* taps_host, int n_taps, int dtype, int D, int F, int N, int T, int nq, const float* w,
+                  float* out, hipStream_t stream);
+int mvf_lstp_softmax_fwd(const float* scores, float* P, float* Pm, float* rowsum, int F, int N, int nq, float inv_sqrt_d,
+                         int disjoint, hipStream_t stream);
+int mvf_lstp_softmax_bwd(const float* P, const float* Pm, const float* dP, const float* drow, float* dS, int F, int N,
+                         int nq, float inv_sqrt_d, hipStream_t stream);
+int mvf_lstp_reduce_frames(const float* G, float* out, int Bc, int nq, int T, int C, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sequence-contrastive loss (algos/scl.py:52-105), fused forward / backward
+ *   negative_flags: bit0 'single' in NEGATIVE_TYPE, bit1 'noself' in NEGATIVE_TYPE
+ * ---------------------------------------------------------------------------------------------- */
+int mvf_scl_fwd(const float* emb, const float* step, const float* len, const float* mask, float* S, float* R, float* c,
+                float* lossrow, float* loss, int M, int E, int T, int negative_flags, float temperature,
+                float label_variance, hipStream_t stream);
+int mvf_scl_bwd(const float* emb, const float* step, const float* len, const float* mask, const float* S, const float* R,
+                const float* c, const float* gout, float* dE, int M, int E, int T, int row0, int rows, int negative_flags,
+                float temperature, float label_variance, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser: global-norm clip + Adam(L2) on one flat buffer (train.py:124-133,147-149; utils/optimizer.py:60-66)
+ * ---------------------------------------------------------------------------------------------- */
+int mvf_grad_norm(const float* g, size_t n, const float* extra_sq, float* scratch, float* norm_out, hipStream_t stream);
+int mvf_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, float clip, const float* norm, float gscale, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVF_HIP_H_ */

@@ -1,0 +1,415 @@
+"""GPU parity tests, kernel by kernel: every HIP entry point (called through the C ABI via
+video_rep_learning_amd.ops / _lib) against the CPU oracle or a plain fp64/fp32 torch restatement of the same op
+on the same seeded inputs.  Tolerances are written next to each check: fp32 kernels <= 1e-3 relative (the
+north-star gate; most are ~1e-6), bf16 kernels report their own error against the fp32 reference."""
+import ctypes
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from video_rep_learning_amd import _lib, ops  # noqa: E402
+from oracle import head as OH  # noqa: E402
+from oracle import scl as OS  # noqa: E402
+from oracle import vit as OV  # noqa: E402
+import _cases as C  # noqa: E402
+import gen_golden as G  # noqa: E402
+
+DEV = 'cuda'
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def relerr(got, ref):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def check(got, ref, tol, what=''):
+    e = relerr(got, ref)
+    assert math.isfinite(e) and e <= tol, '%s: max-rel err %.3e > %.1e' % (what, e, tol)
+    return e
+
+
+def S():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ------------------------------------------------------------------------------------------------ gemm_tc
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('M,N,K', [(300, 256, 768), (128, 128, 64), (1000, 2304, 768), (197 * 3, 768, 3072)])
+def test_gemm_tc_store_gelu(dtype, M, N, K):
+    code, tdt = ops._dt(dtype)
+    g = gen(1)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.05
+    b = torch.randn(N, generator=g)
+    Ad, Wd = A.to(DEV).to(tdt), W.to(DEV).to(tdt)
+    ref = Ad.double().cpu() @ Wd.double().cpu().t() + b.double()
+    for epi, f in ((_lib.EPI_STORE, lambda x: x), (_lib.EPI_GELU, OV.gelu_erf)):
+        Cd = torch.zeros(M, N, device=DEV, dtype=tdt)
+        _lib.call('mvf_gemm_tc', code, epi, Ad.data_ptr(), K, Wd.data_ptr(), K, b.to(DEV).data_ptr(), Cd.data_ptr(), N,
+                  None, 0, None, 0, None, None, 0, M, N, K, S())
+        check(Cd, f(ref), 2e-5 if dtype == 'f32' else 1e-2, 'gemm_tc epi %d %s' % (epi, dtype))
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_gemm_tc_resid_tap_patch(dtype):
+    code, tdt = ops._dt(dtype)
+    g = gen(2)
+    F, tpf, N, K = 3, 5, 256, 128
+    M = F * tpf
+    A = torch.randn(M, K, generator=g).to(DEV).to(tdt)
+    W = (torch.randn(N, K, generator=g) * 0.1).to(DEV).to(tdt)
+    b = torch.randn(N, generator=g).to(DEV)
+    ls = torch.randn(N, generator=g).to(DEV)
+    resid0 = torch.randn(M, N, generator=g).to(DEV)
+    resid = resid0.clone()
+    tap = torch.full((F * (tpf - 1), N), 7.0, device=DEV, dtype=tdt)
+    _lib.call('mvf_gemm_tc', code, _lib.EPI_RESID, A.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), None, 0,
+              resid.data_ptr(), N, tap.data_ptr(), N, None, ls.data_ptr(), tpf, M, N, K, S())
+    ref = resid0.double().cpu() + ls.double().cpu() * (A.double().cpu() @ W.double().cpu().t() + b.double().cpu())
+    tol = 2e-5 if dtype == 'f32' else 1e-2
+    check(resid, ref, tol, 'resid')
+    ref_tap = ref.view(F, tpf, N)[:, 1:].reshape(-1, N)
+    check(tap, ref_tap, tol if dtype == 'f32' else 2e-2, 'tap')
+    # patch epilogue: rows f*P+p -> f*tpf+1+p, + pos[1+p]
+    P = tpf - 1
+    Ap = torch.randn(F * P, K, generator=g).to(DEV).to(tdt)
+    pos = torch.randn(tpf, N, generator=g).to(DEV)
+    x = torch.zeros(F * tpf, N, device=DEV)
+    _lib.call('mvf_gemm_tc', code, _lib.EPI_PATCH, Ap.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), None, 0,
+              x.data_ptr(), N, None, 0, pos.data_ptr(), None, tpf, F * P, N, K, S())
+    refp = (Ap.double().cpu() @ W.double().cpu().t() + b.double().cpu()).view(F, P, N) + pos.double().cpu()[1:]
+    check(x.view(F, tpf, N)[:, 1:], refp, tol, 'patch')
+    assert x.view(F, tpf, N)[:, 0].abs().max().item() == 0.0
+
+
+def test_patchify_and_layernorm():
+    g = gen(3)
+    img = torch.randn(2, 3, 32, 32, generator=g)
+    for dtype in ('f32', 'bf16'):
+        code, tdt = ops._dt(dtype)
+        out = torch.empty(2 * 4, 768, device=DEV, dtype=tdt)
+        _lib.call('mvf_patchify', code, img.to(DEV).data_ptr(), out.data_ptr(), 2, 32, 32, 16, S())
+        check(out, OV.patchify(img, 16).reshape(8, 768), 0 if dtype == 'f32' else 4e-3, 'patchify')
+    x = torch.randn(37, 768, generator=g) * 3 + 1
+    w, b = torch.randn(768, generator=g), torch.randn(768, generator=g)
+    ref = OV.layer_norm(x.double(), w.double(), b.double(), 1e-6)
+    for dtype in ('f32', 'bf16'):
+        code, tdt = ops._dt(dtype)
+        y = torch.empty(37, 768, device=DEV, dtype=tdt)
+        _lib.call('mvf_layernorm_fwd', code, x.to(DEV).data_ptr(), 768, w.to(DEV).data_ptr(), b.to(DEV).data_ptr(),
+                  y.data_ptr(), 768, 37, 768, 1e-6, S())
+        check(y, ref, 1e-5 if dtype == 'f32' else 8e-3, 'layernorm ' + dtype)
+
+
+# ------------------------------------------------------------------------------------------------ ViT attention
+def _attn_ref(qkv, F, N, H):
+    D = qkv.shape[1] // 3
+    q, k, v = qkv.double().view(F, N, 3, H, D // H).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(D // H)
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(F * N, D)
+
+
+@pytest.mark.parametrize('N', [197, 5, 785])
+@pytest.mark.parametrize('dtype,variant', [('f32', 0), ('bf16', 0), ('bf16', 1)])
+def test_vit_attention(N, dtype, variant):
+    code, tdt = ops._dt(dtype)
+    F, H, D = 2, 3, 192
+    qkv = (torch.randn(F * N, 3 * D, generator=gen(4)) * 1.5).to(DEV).to(tdt)
+    out = torch.empty(F * N, D, device=DEV, dtype=tdt)
+    _lib.call('mvf_vit_attn_fwd', code, qkv.data_ptr(), out.data_ptr(), F, N, H, D, variant, S())
+    check(out, _attn_ref(qkv.cpu(), F, N, H), 2e-5 if dtype == 'f32' else 2e-2, 'vit_attn N=%d %s v%d' % (N, dtype, variant))
+
+
+# ------------------------------------------------------------------------------------------------ whole ViT
+def _pack(w, depth, dim, heads, patch, img, taps, dtype):
+    return ops.PackedViT({k: v.to(DEV) for k, v in w.items()}, depth, dim, heads, patch, img, taps, dtype)
+
+
+@pytest.mark.parametrize('dim,depth,heads,patch,img,F', [(128, 2, 2, 16, 32, 3), (768, 12, 12, 16, 224, 2),
+                                                          (384, 12, 6, 8, 64, 2)])
+def test_vit_forward_fp32_vs_oracle(dim, depth, heads, patch, img, F):
+    w = OV.init_vit_weights(dim, depth, patch, img, seed=11)
+    w = {k: (v * 3.0 if ('qkv.weight' in k or 'fc' in k or 'proj.weight' in k) else v) for k, v in w.items()}
+    taps = (3, 7, 11) if depth == 12 else (0, 1)
+    x = torch.randn(F, 3, img, img, generator=gen(12))
+    with torch.no_grad():
+        feats, cls = OV.vit_forward(x, w, heads, patch, taps)
+    pk = _pack(w, depth, dim, heads, patch, img, taps, 'f32')
+    for chunk in (0, 1):
+        got, gcls = ops.vit_forward(x.to(DEV), pk, frames_per_chunk=chunk)
+        for j in range(len(taps)):
+            ref = feats[:, 1:, j * dim:(j + 1) * dim].reshape(-1, dim)
+            check(got[j], ref, 1e-3, 'tap %d (chunk %d)' % (taps[j], chunk))   # north-star gate: 1e-3 rel
+        check(gcls, cls, 1e-3, 'cls')
+
+
+def test_vit_forward_bf16_error():
+    dim, depth, heads, patch, img, F = 768, 12, 12, 16, 224, 2
+    w = OV.init_vit_weights(dim, depth, patch, img, seed=11)
+    x = torch.randn(F, 3, img, img, generator=gen(12))
+    with torch.no_grad():
+        feats, cls = OV.vit_forward(x, w, heads, patch, (3, 7, 11))
+    for variant in (0, 1):
+        got, gcls = ops.vit_forward(x.to(DEV), _pack(w, depth, dim, heads, patch, img, (3, 7, 11), 'bf16'),
+                                    attn_variant=variant)
+        for j in range(3):
+            e = relerr(got[j].float(), feats[:, 1:, j * dim:(j + 1) * dim].reshape(-1, dim))
+            print('bf16 ViT tap %d variant %d: max-rel err vs fp32 oracle %.3e' % (j, variant, e))
+            assert e < 5e-2, e
+
+
+# ------------------------------------------------------------------------------------------------ head ops
+def _leaf(t):
+    return t.clone().to(DEV).requires_grad_(True)
+
+
+@pytest.mark.parametrize('M,N,K', [(768, 512, 387), (768, 256, 512), (70, 33, 19), (768, 1024, 256)])
+@pytest.mark.parametrize('relu', [False, True])
+def test_linear_fwd_bwd(M, N, K, relu):
+    g = gen(20)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    gy = torch.randn(M, N, generator=g)
+    xr, wr, br = [t.double().requires_grad_(True) for t in (x, w, b)]
+    yr = xr @ wr.t() + br
+    yr = torch.relu(yr) if relu else yr
+    (yr * gy.double()).sum().backward()
+    xd, wd, bd = _leaf(x), _leaf(w), _leaf(b)
+    y = ops.linear(xd, wd, bd, relu=relu)
+    (y * gy.to(DEV)).sum().backward()
+    check(y, yr, 2e-5, 'linear y')
+    check(xd.grad, xr.grad, 2e-5, 'linear dx')
+    check(wd.grad, wr.grad, 2e-5, 'linear dw')
+    check(bd.grad, br.grad, 2e-5, 'linear db')
+
+
+def test_linear_table_and_matmul():
+    g = gen(21)
+    x, w = torch.randn(24 * 8, 32, generator=g), torch.randn(16, 32, generator=g)
+    tab = torch.randn(8, 16, generator=g)
+    y = ops.linear(x.to(DEV), w.to(DEV), None, table=tab.to(DEV), tab_div=1, tab_mod=8)
+    ref = (x.double() @ w.double().t()).view(24, 8, 16) + tab.double()
+    check(y, ref.view(-1, 16), 2e-5, 'linear+table')
+    a, b = torch.randn(3, 384, generator=g), torch.randn(384, 2304, generator=g)
+    ar, br = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    gc = torch.randn(3, 2304, generator=g)
+    ((ar @ br) * gc.double()).sum().backward()
+    ad, bd = _leaf(a), _leaf(b)
+    c = ops.matmul(ad, bd)
+    (c * gc.to(DEV)).sum().backward()
+    check(c, ar @ br, 2e-5, 'matmul')
+    check(ad.grad, ar.grad, 2e-5, 'matmul da')
+    check(bd.grad, br.grad, 2e-5, 'matmul db')
+
+
+def test_layer_norm_fwd_bwd():
+    g = gen(22)
+    x, w, b = torch.randn(50, 256, generator=g) * 2 + 0.5, torch.randn(256, generator=g), torch.randn(256, generator=g)
+    gy = torch.randn(50, 256, generator=g)
+    xr, wr, br = [t.double().requires_grad_(True) for t in (x, w, b)]
+    (OH.layer_norm(xr, wr, br) * gy.double()).sum().backward()
+    xd, wd, bd = _leaf(x), _leaf(w), _leaf(b)
+    y = ops.layer_norm(xd, wd, bd)
+    (y * gy.to(DEV)).sum().backward()
+    check(y, OH.layer_norm(xr, wr, br), 1e-5, 'ln y')
+    check(xd.grad, xr.grad, 1e-4, 'ln dx')
+    check(wd.grad, wr.grad, 1e-4, 'ln dg')
+    check(bd.grad, br.grad, 1e-4, 'ln db')
+
+
+@pytest.mark.parametrize('training', [True, False])
+@pytest.mark.parametrize('relu', [True, False])
+def test_batch_norm_fwd_bwd(training, relu):
+    g = gen(23)
+    R, Cn = 96, 70
+    x = torch.randn(R, Cn, generator=g) * 2 + 1
+    p = {}
+    C._bn(p, g, 'bn', Cn)
+    gy = torch.randn(R, Cn, generator=g)
+    pr = {k: (v.double().requires_grad_(True) if v.dtype.is_floating_point and 'running' not in k else v.clone().double())
+          for k, v in p.items()}
+    xr = x.double().requires_grad_(True)
+    yr = OH.batch_norm1d(xr, pr, 'bn', training, update_running=training)
+    yr = torch.relu(yr) if relu else yr
+    (yr * gy.double()).sum().backward()
+    xd, gd, bd = _leaf(x), _leaf(p['bn.weight']), _leaf(p['bn.bias'])
+    rm, rv = p['bn.running_mean'].clone().to(DEV), p['bn.running_var'].clone().to(DEV)
+    y = ops.batch_norm(xd, gd, bd, rm, rv, training, relu=relu)
+    (y * gy.to(DEV)).sum().backward()
+    check(y, yr, 1e-5, 'bn y')
+    check(xd.grad, xr.grad, 2e-4, 'bn dx')
+    check(gd.grad, pr['bn.weight'].grad, 1e-4, 'bn dgamma')
+    check(bd.grad, pr['bn.bias'].grad, 1e-4, 'bn dbeta')
+    if training:
+        check(rm, pr['bn.running_mean'], 1e-5, 'running_mean')
+        check(rv, pr['bn.running_var'], 1e-5, 'running_var')
+
+
+@pytest.mark.parametrize('B,S,H,Dm,pad', [(3, 96, 8, 256, 7), (2, 24, 4, 32, 0), (2, 200, 8, 256, 33), (1, 130, 2, 128, 1)])
+def test_temporal_attention_fwd_bwd(B, S, H, Dm, pad):
+    g = gen(24)
+    qkv = torch.randn(B * S, 3 * Dm, generator=g)
+    mask = torch.ones(B, S)
+    if pad:
+        mask[-1, S - pad:] = 0
+        mask[0, 3] = 0
+    go = torch.randn(B * S, Dm, generator=g)
+    qr = qkv.double().requires_grad_(True)
+    q, k, v = [t.reshape(B, S, H, Dm // H).transpose(1, 2) for t in qr.view(B, S, 3, Dm).unbind(2)]
+    o, _ = OH.attention(q, k, v, mask.view(B, 1, 1, S))
+    o = o.transpose(1, 2).reshape(B * S, Dm)
+    (o * go.double()).sum().backward()
+    qd = _leaf(qkv)
+    od = ops.temporal_attention(qd, mask.to(DEV), B, S, H)
+    (od * go.to(DEV)).sum().backward()
+    check(od, o, 2e-5, 'tattn o')
+    check(qd.grad, qr.grad, 1e-4, 'tattn dqkv')
+
+
+def test_small_row_ops():
+    g = gen(25)
+    x = torch.randn(2 * 3 * 4, 5, generator=g)
+    y = ops.concat_onehot(x.to(DEV), 3, 4)
+    eye = torch.eye(3).view(1, 3, 1, 3).expand(2, 3, 4, 3).reshape(-1, 3)
+    check(y, torch.cat([x, eye], 1), 0, 'concat_onehot')
+    x4 = torch.randn(2, 3, 4, 6, generator=g)
+    gy = torch.randn(2, 4, 6, generator=g)
+    for mode, f in (('one', lambda t: t[:, 0]), ('avg', lambda t: t.mean(1)), ('max', lambda t: t.max(1)[0])):
+        xr = x4.double().requires_grad_(True)
+        (f(xr) * gy.double()).sum().backward()
+        xd = _leaf(x4)
+        yd = ops.final_reduce(xd, mode)
+        (yd * gy.to(DEV)).sum().backward()
+        check(yd, f(xr), 1e-6, 'final_reduce ' + mode)
+        check(xd.grad, xr.grad, 1e-6, 'final_reduce grad ' + mode)
+    x = torch.randn(40, 128, generator=g)
+    gy = torch.randn(40, 128, generator=g)
+    xr = x.double().requires_grad_(True)
+    (OH.l2_normalize(xr) * gy.double()).sum().backward()
+    xd = _leaf(x)
+    yd = ops.l2_normalize(xd)
+    (yd * gy.to(DEV)).sum().backward()
+    check(yd, OH.l2_normalize(xr), 1e-6, 'l2norm')
+    check(xd.grad, xr.grad, 1e-5, 'l2norm grad')
+
+
+def test_dropout_add():
+    st = ops.DropoutState(seed=5)
+    x = torch.ones(1 << 16, device=DEV, requires_grad=True)
+    r = torch.full((1 << 16,), 2.0, device=DEV, requires_grad=True)
+    y = ops.dropout_add(x, r, 0.1, True, st)
+    kept = (y > 2.5)
+    frac = kept.float().mean().item()
+    assert abs(frac - 0.9) < 0.01, frac
+    assert torch.allclose(y[kept], torch.full_like(y[kept], 2.0 + 1.0 / 0.9))
+    y.sum().backward()
+    assert torch.equal(x.grad > 0, kept) and torch.allclose(r.grad, torch.ones_like(r.grad))
+    y2 = ops.dropout_add(x.detach(), r.detach(), 0.1, True, st)     # new offset -> new mask
+    assert not torch.equal(y2 > 2.5, kept)
+    assert ops.dropout_add(x, None, 0.1, False, st) is x             # eval: identity
+
+
+# ------------------------------------------------------------------------------------------------ LSTP pooling
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('nq,disjoint', [(3, False), (6, False), (3, True)])
+def test_lstp_pool_vs_plain_attention(dtype, nq, disjoint):
+    """The streaming rewrite (scores -> softmax -> weighted sum -> W_V) equals the reference's
+    K/V-projection + attention (oracle.lstp_cross_att), forward and gradients."""
+    code, tdt = ops._dt(dtype)
+    Bc, T, N, D, ntap, spc = 2, 4, 49, 64, 3, 24
+    Cc = D * ntap
+    F = Bc * T
+    d = C.Dims(C=Cc, n_taps=ntap, spc=spc, nst=nq, disjoint=disjoint)
+    p = {k[len('pooling.'):]: v for k, v in C.head_params(d, 30).items() if k.startswith('pooling.')}
+    feat = torch.randn(F, N, Cc, generator=gen(31))
+    feat_q = feat.to(tdt).float()    # the values the kernel actually sees
+    pr = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    cfg = OH.HeadCfg(nst=nq, spc=spc, disjoint=disjoint, n_taps=ntap)
+    outs = [OH.lstp_cross_att(feat_q.double().view(Bc, T, N, Cc)[c], pr, 'cross_att.', cfg)[0] for c in range(Bc)]
+    ref = torch.cat(outs, 0)                                     # [F, nq, spc]
+    gy = torch.randn(F, nq, spc, generator=gen(32))
+    (ref * gy.double()).sum().backward()
+
+    taps = [feat[:, :, j * D:(j + 1) * D].reshape(F * N, D).contiguous().to(DEV).to(tdt) for j in range(ntap)]
+    pd = {k: _leaf(v) for k, v in p.items()}
+    q = (pd['cross_att.Q_s'] + pd['cross_att.Q_s_b'])[0]                     # [nq, spc]
+    wq = ops.matmul(q, pd['cross_att.linear_K2d.weight'])                   # [nq, C]
+    holder = {}
+    pooled = ops.lstp_pool(wq, taps, F, N, T, nq, spc, disjoint=disjoint, holder=holder)   # [Bc, nq, T, C]
+    out = ops.linear(pooled, pd['cross_att.linear_V2d.weight'], None)
+    bv = pd['cross_att.linear_V2d.bias']
+    out = out + (bv if not disjoint else holder['rowsum'].view(Bc, T, nq).transpose(1, 2).unsqueeze(-1) * bv)
+    got = out.permute(0, 2, 1, 3).reshape(F, nq, spc)            # back to (f, j)
+    (got * gy.to(DEV)).sum().backward()
+    tol = 1e-4 if dtype == 'f32' else 2e-4   # the oracle consumed the same bf16-rounded features
+    check(got, ref, tol, 'lstp out')
+    check(pd['cross_att.Q_s'].grad, pr['cross_att.Q_s'].grad, 10 * tol, 'dQ_s')
+    check(pd['cross_att.Q_s_b'].grad, pr['cross_att.Q_s_b'].grad, 10 * tol, 'dQ_s_b')
+    check(pd['cross_att.linear_K2d.weight'].grad, pr['cross_att.linear_K2d.weight'].grad, 10 * tol, 'dW_K')
+    check(pd['cross_att.linear_V2d.weight'].grad, pr['cross_att.linear_V2d.weight'].grad, 10 * tol, 'dW_V')
+    if not disjoint:
+        check(pd['cross_att.linear_V2d.bias'].grad, pr['cross_att.linear_V2d.bias'].grad, 10 * tol, 'db_V')
+
+
+# ------------------------------------------------------------------------------------------------ SCL loss
+@pytest.mark.parametrize('name', sorted(G.SCL_CASES))
+def test_scl_vs_golden_and_oracle(golden, name):
+    gs = golden('scl')
+    b, t, e, pad, neg = G.SCL_CASES[name]
+    seed = 2000 + sorted(G.SCL_CASES).index(name)
+    embs, seq_lens, steps, masks = C.scl_inputs(b, t, e, seed, pad)
+    ed = _leaf(embs.reshape(-1, e))
+    lens = seq_lens.view(b, 2, 1).expand(b, 2, t)
+    loss = ops.scl_loss(ed, steps.to(DEV), lens.to(DEV), masks.to(DEV), t, neg, 0.1, 10.0)
+    loss.backward()
+    check(loss, torch.tensor(gs[name + '/loss']), 1e-4, 'scl loss (golden from the reference)')
+    check(ed.grad.view(b, 2, t, e), torch.tensor(gs[name + '/gembs']), 1e-3, 'scl dE (golden)')
+    er = embs.double().requires_grad_(True)
+    lo = OS.scl_loss(er, seq_lens, steps, masks, negative_type=neg)
+    lo.backward()
+    check(loss, lo, 1e-5, 'scl loss (oracle fp64)')
+    check(ed.grad.view(b, 2, t, e), er.grad, 2e-4, 'scl dE (oracle fp64)')
+
+
+def test_scl_row_slice():
+    b, t, e = 8, 32, 128
+    embs, seq_lens, steps, masks = C.scl_inputs(b, t, e, 99, 12)
+    lens = seq_lens.view(b, 2, 1).expand(b, 2, t)
+    ed = _leaf(embs.reshape(-1, e))
+    ops.scl_loss(ed, steps.to(DEV), lens.to(DEV), masks.to(DEV), t, 'batch_noself', 0.1, 10.0).backward()
+    full = ed.grad.clone()
+    ed2 = _leaf(embs.reshape(-1, e))
+    M = b * 2 * t
+    ops.scl_loss(ed2, steps.to(DEV), lens.to(DEV), masks.to(DEV), t, 'batch_noself', 0.1, 10.0, row0=M // 2,
+                 rows=M // 2, grad_scale=2.0).backward()
+    assert ed2.grad[:M // 2].abs().max().item() == 0.0
+    check(ed2.grad[M // 2:], 2.0 * full[M // 2:], 1e-6, 'scl row slice')
+
+
+# ------------------------------------------------------------------------------------------------ optimiser
+def test_fused_clip_adam_vs_torch():
+    g = gen(40)
+    n = 100003
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.3
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-5)
+    pd, m, v = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    scratch, norm = torch.empty(1024, device=DEV), torch.empty(1, device=DEV)
+    for step in range(1, 4):
+        gstep = gr * step
+        pr.grad = gstep.clone()
+        tn = torch.nn.utils.clip_grad_norm_([pr], 10.0)
+        opt.step()
+        gd = gstep.to(DEV)
+        ops.grad_norm(gd, scratch, norm)
+        check(norm, tn.view(1), 1e-5, 'grad norm')
+        ops.adam_step(pd, gd, m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-5, step, clip=10.0, norm=norm)
+        check(pd, pr.detach(), 1e-5, 'adam step %d' % step)

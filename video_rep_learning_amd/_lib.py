@@ -1,0 +1,110 @@
+"""ctypes binding of libmvf_hip.so (the C ABI declared in include/mvf_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call returns non-zero this raises.
+The product path never computes on the CPU."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libmvf_hip.so')
+
+F32, BF16 = 0, 1
+EPI_STORE, EPI_GELU, EPI_RESID, EPI_PATCH = 0, 1, 2, 3
+
+_P, _I, _L, _Z, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t, ctypes.c_float
+
+# name -> argument kinds (p pointer, i int, l long, z size_t, f float, u uint64_t); every function returns int
+# except mvf_vit_workspace_bytes (size_t).  Kept in the order of include/mvf_hip.h.
+SIGNATURES = {
+    'mvf_vit_workspace_bytes': 'iiiii',
+    'mvf_vit_fwd': 'pipipppziip',
+    'mvf_gemm_tc': 'iipipippipipippiiiip',
+    'mvf_patchify': 'ippiiiip',
+    'mvf_layernorm_fwd': 'ipzpppziifp',
+    'mvf_vit_attn_fwd': 'ippiiiiip',
+    'mvf_cast_f32_bf16': 'ppzp',
+    'mvf_hgemm': 'pllpllplppllii' + 'iiifiip',
+    'mvf_colsum': 'pliipip',
+    'mvf_relu_bwd': 'pppzp',
+    'mvf_dropout_add': 'pppzfuup',
+    'mvf_ln_fwd': 'ppppppiifp',
+    'mvf_ln_bwd': 'ppppppppiiip',
+    'mvf_bn_stats': 'piippp',
+    'mvf_bn_fwd': 'ppppppiifip',
+    'mvf_bn_bwd_reduce': 'ppppppppiifip',
+    'mvf_bn_bwd_apply': 'pppppppppiififp',
+    'mvf_concat_onehot': 'ppiiiip',
+    'mvf_final_reduce_fwd': 'pppiiiiip',
+    'mvf_final_reduce_bwd': 'pppiiiiip',
+    'mvf_l2norm_fwd': 'pppiifp',
+    'mvf_l2norm_bwd': 'ppppiifp',
+    'mvf_tattn_fwd': 'ppppiiiip',
+    'mvf_tattn_bwd': 'ppppppiiiip',
+    'mvf_lstp_scores': 'piiiiiiipipp',
+    'mvf_lstp_wsum': 'piiiiiiippp',
+    'mvf_lstp_softmax_fwd': 'ppppiiifip',
+    'mvf_lstp_softmax_bwd': 'pppppiiifp',
+    'mvf_lstp_reduce_frames': 'ppiiiip',
+    'mvf_scl_fwd': 'pppppppppiiiiffp',
+    'mvf_scl_bwd': 'pppppppppiiiiiiffp',
+    'mvf_grad_norm': 'pzpppp',
+    'mvf_adam_step': 'ppppzfffffifpfp',
+}
+_KIND = {'p': _P, 'i': _I, 'l': _L, 'z': _Z, 'f': _F, 'u': ctypes.c_uint64}
+
+
+class MvfVitWeights(ctypes.Structure):
+    """Mirror of `struct MvfVitWeights` (include/mvf_hip.h)."""
+    _fields_ = ([('depth', _I), ('dim', _I), ('heads', _I), ('patch', _I), ('img', _I), ('n_taps', _I),
+                 ('taps', _I * 8), ('ln_eps', _F),
+                 ('cls_token', _P), ('pos_embed', _P), ('patch_w', _P), ('patch_b', _P), ('norm_w', _P), ('norm_b', _P)]
+                + [(n, ctypes.POINTER(_P)) for n in
+                   ('ln1_w', 'ln1_b', 'qkv_w', 'qkv_b', 'proj_w', 'proj_b', 'ln2_w', 'ln2_b', 'fc1_w', 'fc1_b',
+                    'fc2_w', 'fc2_b', 'ls1', 'ls2')])
+
+
+class MvfError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads (once) and returns the ctypes handle; raises if the HIP library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MvfError('libmvf_hip.so not found at %s -- build it with `python -m video_rep_learning_amd.csrc.build` '
+                       '(there is no CPU fallback)' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, sig in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.argtypes = [_KIND[k] for k in sig]
+        fn.restype = _Z if name == 'mvf_vit_workspace_bytes' else _I
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Calls an int-returning entry point and raises MvfError on a non-zero code."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise MvfError('%s failed with code %d%s' % (name, rc, ' (bad argument)' if rc == 10001 else ''))
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be a contiguous CUDA(HIP) tensor."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MvfError('HIP op received a %s tensor: the MV-Former kernels only run on a gfx950 device' % t.device)
+    if not t.is_contiguous():
+        raise MvfError('HIP op received a non-contiguous tensor')
+    return t.data_ptr()

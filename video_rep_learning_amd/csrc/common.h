@@ -1,0 +1,71 @@
+// Shared device/host helpers for the MV-Former gfx950 kernels.
+// Wavefront = 64 lanes everywhere (CDNA4); no portability layer on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MVF_OK 0
+#define MVF_ERR_ARG 10001      // bad shape / pointer / alignment handed to an entry point
+#define MVF_ERR_UNSUPPORTED 10002
+
+#define MVF_CHECK_ARG(cond)        \
+  do {                             \
+    if (!(cond)) return MVF_ERR_ARG; \
+  } while (0)
+
+#define MVF_LAUNCH_CHECK()                         \
+  do {                                             \
+    hipError_t e__ = hipGetLastError();            \
+    if (e__ != hipSuccess) return (int)e__;        \
+  } while (0)
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even; NaN stays NaN (plain compiler cast path keeps NaNs, see MI355X guide)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <>
+struct Elem<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// ---- 64-lane wave reductions (butterfly over DPP/ds_swizzle via __shfl_xor) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,391 @@
+// Row-/column-wise fp32 kernels of the trainable head (forward and backward):
+//   LayerNorm              models/utils.py:147-159 (ResidualConnection.norm, eps 1e-5)
+//   BatchNorm1d (+ReLU)    models/mvformer.py:78-79, resnet_c2d.py:118-119 (train: batch stats; eval: running)
+//   entity one-hot concat  models/mvformer.py:144-149
+//   entity reduction       models/mvformer.py:181-195 (SMART_FINAL one|avg|max)
+//   F.normalize            models/transformer.py:228,230
+// All are HBM/L2-bound on <= 1.6 MB tensors: one wave per row (row ops) or 64 columns x 4 row-lanes per
+// workgroup (column reductions); no atomics, so results are run-to-run reproducible.
+#include "common.h"
+#include "mvf_hip_internal.h"
+
+namespace {
+
+// ---------------- LayerNorm ----------------
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                     const float* __restrict__ b, float* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows, int D,
+                                                     float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * D;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) s += xr[c];
+  const float mu = wave_sum(s) / D;
+  float ss = 0.f;
+  for (int c = lane; c < D; c += 64) { const float d = xr[c] - mu; ss += d * d; }
+  const float rs = rsqrtf(wave_sum(ss) / D + eps);
+  for (int c = lane; c < D; c += 64) y[(size_t)row * D + c] = (xr[c] - mu) * rs * g[c] + b[c];
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        const float* __restrict__ g, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, float* __restrict__ dx, int rows,
+                                                        int D, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const size_t o = (size_t)row * D;
+  const float mu = mean[row], rs = rstd[row];
+  float c1 = 0.f, c2 = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    const float dg = dy[o + c] * g[c];
+    c1 += dg;
+    c2 += dg * (x[o + c] - mu) * rs;
+  }
+  c1 = wave_sum(c1) / D;
+  c2 = wave_sum(c2) / D;
+  for (int c = lane; c < D; c += 64) {
+    const float v = rs * (dy[o + c] * g[c] - c1 - (x[o + c] - mu) * rs * c2);
+    dx[o + c] = accumulate ? dx[o + c] + v : v;
+  }
+}
+
+// dgamma[c] = sum_r dy*xhat ; dbeta[c] = sum_r dy
+__global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ dg, float* __restrict__ db, int rows, int D) {
+  __shared__ float r1[4][64], r2[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float a = 0.f, b = 0.f;
+  if (c < D)
+    for (int r = rl; r < rows; r += 4) {
+      const float d = dy[(size_t)r * D + c];
+      a += d * (x[(size_t)r * D + c] - mean[r]) * rstd[r];
+      b += d;
+    }
+  r1[rl][cl] = a; r2[rl][cl] = b;
+  __syncthreads();
+  if (rl == 0 && c < D) {
+    dg[c] = r1[0][cl] + r1[1][cl] + r1[2][cl] + r1[3][cl];
+    db[c] = r2[0][cl] + r2[1][cl] + r2[2][cl] + r2[3][cl];
+  }
+}
+
+// ---------------- BatchNorm1d ----------------
+// per-channel mean and biased variance over rows (two sweeps; data is L2 resident)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int rows, int C, float* __restrict__ mean,
+                                                       float* __restrict__ var) {
+  __shared__ float red[4][64];
+  __shared__ float mu_s[64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s = 0.f;
+  if (c < C)
+    for (int r = rl; r < rows; r += 4) s += x[(size_t)r * C + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0) mu_s[cl] = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / rows;
+  __syncthreads();
+  const float mu = mu_s[cl];
+  s = 0.f;
+  if (c < C)
+    for (int r = rl; r < rows; r += 4) { const float d = x[(size_t)r * C + c] - mu; s += d * d; }
+  __syncthreads();
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    mean[c] = mu;
+    var[c] = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / rows;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                     const float* __restrict__ var, const float* __restrict__ g,
+                                                     const float* __restrict__ b, float* __restrict__ y, size_t n, int C,
+                                                     float eps, int relu) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    float v = (x[i] - mean[c]) * rsqrtf(var[c] + eps) * g[c] + b[c];
+    y[i] = relu ? fmaxf(v, 0.f) : v;
+  }
+}
+
+// s1[c] = sum_r dy_eff ; s2[c] = sum_r dy_eff * xhat     (dy_eff = dy * [bn(x) > 0] when relu)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ var,
+                                                            const float* __restrict__ g, const float* __restrict__ b,
+                                                            float* __restrict__ s1, float* __restrict__ s2, int rows, int C,
+                                                            float eps, int relu) {
+  __shared__ float r1[4][64], r2[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float a = 0.f, bb = 0.f;
+  if (c < C) {
+    const float mu = mean[c], rs = rsqrtf(var[c] + eps), gg = g[c], be = b[c];
+    for (int r = rl; r < rows; r += 4) {
+      const float xh = (x[(size_t)r * C + c] - mu) * rs;
+      float d = dy[(size_t)r * C + c];
+      if (relu && !(xh * gg + be > 0.f)) d = 0.f;
+      a += d;
+      bb += d * xh;
+    }
+  }
+  r1[rl][cl] = a; r2[rl][cl] = bb;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    s1[c] = r1[0][cl] + r1[1][cl] + r1[2][cl] + r1[3][cl];
+    s2[c] = r2[0][cl] + r2[1][cl] + r2[2][cl] + r2[3][cl];
+  }
+}
+
+// train: dx = g*rstd*(dy_eff - s1/count - xhat*s2/count) ; eval (count <= 0): dx = g*rstd*dy_eff
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ var,
+                                                           const float* __restrict__ g, const float* __restrict__ b,
+                                                           const float* __restrict__ s1, const float* __restrict__ s2,
+                                                           float* __restrict__ dx, size_t n, int C, float eps, int relu,
+                                                           float inv_count) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const float rs = rsqrtf(var[c] + eps);
+    const float xh = (x[i] - mean[c]) * rs;
+    float d = dy[i];
+    if (relu && !(xh * g[c] + b[c] > 0.f)) d = 0.f;
+    dx[i] = g[c] * rs * (d - s1[c] * inv_count - xh * s2[c] * inv_count);
+  }
+}
+
+// ---------------- one-hot concat ----------------
+// out[r, 0:cin] = x[r, :]; out[r, cin + j] = [tok(r) == j], tok(r) = (r / div) % ntok
+__global__ void concat_onehot_kernel(const float* __restrict__ x, float* __restrict__ out, int rows, int cin, int ntok,
+                                     int div) {
+  const int cout = cin + ntok;
+  const size_t n = (size_t)rows * cout;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cout), c = (int)(i % cout);
+    out[i] = c < cin ? x[(size_t)r * cin + c] : ((r / div) % ntok == c - cin ? 1.f : 0.f);
+  }
+}
+
+// ---------------- entity reduction: x [B, ntok, T, D] -> y [B, T, D] ----------------
+// mode 0 'one' (token 0), 1 'avg', 2 'max' (argmax saved for backward)
+__global__ void final_reduce_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int* __restrict__ arg, int B,
+                                        int ntok, int T, int D, int mode) {
+  const size_t n = (size_t)B * T * D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int t = (int)((i / D) % T);
+    const int bb = (int)(i / ((size_t)D * T));
+    const float* p = x + (((size_t)bb * ntok) * T + t) * D + d;
+    const size_t ts = (size_t)T * D;
+    if (mode == 0) {
+      y[i] = p[0];
+    } else if (mode == 1) {
+      float s = 0.f;
+      for (int k = 0; k < ntok; ++k) s += p[k * ts];
+      y[i] = s / ntok;
+    } else {
+      float m = p[0];
+      int am = 0;
+      for (int k = 1; k < ntok; ++k)
+        if (p[k * ts] > m) { m = p[k * ts]; am = k; }
+      y[i] = m;
+      arg[i] = am;
+    }
+  }
+}
+
+__global__ void final_reduce_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ arg, float* __restrict__ dx,
+                                        int B, int ntok, int T, int D, int mode) {
+  const size_t n = (size_t)B * ntok * T * D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int t = (int)((i / D) % T);
+    const int k = (int)((i / ((size_t)D * T)) % ntok);
+    const int bb = (int)(i / ((size_t)D * T * ntok));
+    const size_t j = ((size_t)bb * T + t) * D + d;
+    float v;
+    if (mode == 0) v = k == 0 ? dy[j] : 0.f;
+    else if (mode == 1) v = dy[j] / ntok;
+    else v = arg[j] == k ? dy[j] : 0.f;
+    dx[i] = v;
+  }
+}
+
+// ---------------- F.normalize(dim=-1) ----------------
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         float* __restrict__ nrm, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const size_t o = (size_t)row * D;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) s += x[o + c] * x[o + c];
+  const float nn = fmaxf(sqrtf(wave_sum(s)), eps);
+  for (int c = lane; c < D; c += 64) y[o + c] = x[o + c] / nn;
+  if (lane == 0) nrm[row] = nn;
+}
+
+// y = x / n, n = max(||x||, eps):  dx = (dy - y (y.dy)) / n   (clamped branch: dx = dy / eps)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                         const float* __restrict__ nrm, float* __restrict__ dx, int rows,
+                                                         int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const size_t o = (size_t)row * D;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) s += y[o + c] * dy[o + c];
+  s = wave_sum(s);
+  const float nn = nrm[row];
+  const bool clamped = !(nn > eps);
+  for (int c = lane; c < D; c += 64) dx[o + c] = clamped ? dy[o + c] / nn : (dy[o + c] - y[o + c] * s) / nn;
+}
+
+// dx = dy * [y > 0]   (backward of the FFN's ReLU, models/utils.py:190)
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+// y = resid + dropout_p(x)  (nn.Dropout + residual add of ResidualConnection, models/utils.py:153-159; plain
+// nn.Dropout when resid == null).  Counter-based mask: keep(i) = hash(seed, offset + i) >= p * 2^32, so the
+// backward regenerates the identical mask from (seed, offset) and nothing is stored.
+__device__ __forceinline__ uint32_t mix32(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (uint32_t)((z ^ (z >> 31)) >> 16);
+}
+__global__ void dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ resid, float* __restrict__ y,
+                                   size_t n, uint32_t thresh, float scale, uint64_t seed, uint64_t offset) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float v = x[i];
+    if (thresh != 0u) v = mix32(seed * 0x2545F4914F6CDD1Dull + offset + i) >= thresh ? v * scale : 0.f;
+    y[i] = resid ? resid[i] + v : v;
+  }
+}
+
+inline int ew_grid(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256 * 8); }
+
+}  // namespace
+
+extern "C" int mvf_ln_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int rows,
+                          int D, float eps, hipStream_t st) {
+  MVF_CHECK_ARG(x && g && b && y && mean && rstd && rows > 0 && D > 0);
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, g, b, y, mean, rstd, rows, D, eps);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, float* dx,
+                          float* dg, float* db, int rows, int D, int accumulate_dx, hipStream_t st) {
+  MVF_CHECK_ARG(dy && x && g && mean && rstd && dx && rows > 0 && D > 0);
+  hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, st, dy, x, g, mean, rstd, dx, rows, D,
+                     accumulate_dx);
+  if (dg && db)
+    hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(ceil_div(D, 64)), dim3(256), 0, st, dy, x, mean, rstd, dg, db, rows, D);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_bn_stats(const float* x, int rows, int C, float* mean, float* var, hipStream_t st) {
+  MVF_CHECK_ARG(x && mean && var && rows > 0 && C > 0);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, x, rows, C, mean, var);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_bn_fwd(const float* x, const float* mean, const float* var, const float* g, const float* b, float* y,
+                          int rows, int C, float eps, int relu, hipStream_t st) {
+  MVF_CHECK_ARG(x && mean && var && g && b && y && rows > 0 && C > 0);
+  const size_t n = (size_t)rows * C;
+  hipLaunchKernelGGL(bn_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, mean, var, g, b, y, n, C, eps, relu);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_bn_bwd_reduce(const float* dy, const float* x, const float* mean, const float* var, const float* g,
+                                 const float* b, float* s1, float* s2, int rows, int C, float eps, int relu,
+                                 hipStream_t st) {
+  MVF_CHECK_ARG(dy && x && mean && var && g && b && s1 && s2 && rows > 0 && C > 0);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, dy, x, mean, var, g, b, s1, s2, rows,
+                     C, eps, relu);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+// count = number of rows the statistics were taken over (global count under SyncBN); count <= 0: eval mode
+extern "C" int mvf_bn_bwd_apply(const float* dy, const float* x, const float* mean, const float* var, const float* g,
+                                const float* b, const float* s1, const float* s2, float* dx, int rows, int C, float eps,
+                                int relu, float count, hipStream_t st) {
+  MVF_CHECK_ARG(dy && x && mean && var && g && b && s1 && s2 && dx && rows > 0 && C > 0);
+  const size_t n = (size_t)rows * C;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, st, dy, x, mean, var, g, b, s1, s2, dx, n, C,
+                     eps, relu, count > 0.f ? 1.0f / count : 0.f);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_concat_onehot(const float* x, float* out, int rows, int cin, int ntok, int div, hipStream_t st) {
+  MVF_CHECK_ARG(x && out && rows > 0 && cin > 0 && ntok > 0 && div > 0);
+  const size_t n = (size_t)rows * (cin + ntok);
+  hipLaunchKernelGGL(concat_onehot_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, out, rows, cin, ntok, div);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_final_reduce_fwd(const float* x, float* y, int* arg, int B, int ntok, int T, int D, int mode,
+                                    hipStream_t st) {
+  MVF_CHECK_ARG(x && y && (mode != 2 || arg) && mode >= 0 && mode <= 2 && B > 0 && ntok > 0 && T > 0 && D > 0);
+  const size_t n = (size_t)B * T * D;
+  hipLaunchKernelGGL(final_reduce_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, y, arg, B, ntok, T, D, mode);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_final_reduce_bwd(const float* dy, const int* arg, float* dx, int B, int ntok, int T, int D, int mode,
+                                    hipStream_t st) {
+  MVF_CHECK_ARG(dy && dx && (mode != 2 || arg) && mode >= 0 && mode <= 2 && B > 0 && ntok > 0 && T > 0 && D > 0);
+  const size_t n = (size_t)B * ntok * T * D;
+  hipLaunchKernelGGL(final_reduce_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, dy, arg, dx, B, ntok, T, D, mode);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_l2norm_fwd(const float* x, float* y, float* nrm, int rows, int D, float eps, hipStream_t st) {
+  MVF_CHECK_ARG(x && y && nrm && rows > 0 && D > 0);
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, y, nrm, rows, D, eps);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_l2norm_bwd(const float* dy, const float* y, const float* nrm, float* dx, int rows, int D, float eps,
+                              hipStream_t st) {
+  MVF_CHECK_ARG(dy && y && nrm && dx && rows > 0 && D > 0);
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, st, dy, y, nrm, dx, rows, D, eps);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_relu_bwd(const float* dy, const float* y, float* dx, size_t n, hipStream_t st) {
+  MVF_CHECK_ARG(dy && y && dx && n > 0);
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, dy, y, dx, n);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+// p in [0,1): y = resid + mask * x / (1-p)  (resid may be NULL).  The same call with x = dy, resid = NULL is the backward.
+extern "C" int mvf_dropout_add(const float* x, const float* resid, float* y, size_t n, float p, uint64_t seed,
+                               uint64_t offset, hipStream_t st) {
+  MVF_CHECK_ARG(x && y && n > 0 && p >= 0.f && p < 1.f);
+  const uint32_t thresh = p > 0.f ? (uint32_t)std::min<double>(4294967295.0, (double)p * 4294967296.0) : 0u;
+  hipLaunchKernelGGL(dropout_add_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, resid, y, n, thresh, 1.0f / (1.0f - p),
+                     seed, offset);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}

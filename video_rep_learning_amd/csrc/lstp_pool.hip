@@ -1,0 +1,328 @@
+// Learned-query spatial token pooling (LSTP cross-attention), forward and backward.
+// Reference: LSTPCrossAtt.forward / LearnableTokenPooling.forward, CARL_MVF/models/mvformer.py:243-266, 352-414
+// with `attention` from models/utils.py:11-44.
+//
+// The reference projects K = x W_K^T + b_K and V = x W_V^T + b_V for all F*N tokens (2 x 0.35 GFLOP/frame,
+// K and V round-trip HBM) and then attends with nq (= 3) queries.  Because softmax rows sum to one and the
+// queries do not depend on the token, the same numbers are
+//     scores[f,n,j] = x[f,n,:] . wq[f,j,:]  (+ q_j.b_K, constant over n -> cancels in softmax)
+//     P = softmax_n(scores / sqrt(d)),   pooled[f,j,:] = sum_n P[f,j,n] x[f,n,:],   out = pooled W_V^T + b_V
+// with wq = q W_K (tiny GEMM).  What is left on the big [F, N, C] tap tensor is two streaming passes
+// (scores, weighted sum) forward and two backward: HBM-bound, no GEMM-shaped work.  These kernels ARE those
+// passes; the tap tensors are read as separate [F*N, D] buffers per tapped block (no channel concat copy).
+//
+// Layouts: taps[t] [F*N, D] (bf16 or f32);  vec [G, nq, C] with C = n_taps*D, G = 1 (shared queries) or one
+// per frame stored as [Bc, nq, T, C];  scores / dP [F*N, nq];  P / dS [F, nq, N];  pooled [Bc, nq, T, C]
+// (rows already in the (clip, entity, frame) order the temporal encoder wants).
+#include "common.h"
+#include "mvf_hip_internal.h"
+
+namespace {
+
+constexpr int MAXQ = 8;
+constexpr int MAXTAPS = 8;
+
+struct PoolArgs {
+  const void* taps[MAXTAPS];
+  int n_taps, D, F, N, T, nq;
+  const float* vec; int per_frame;   // scores: the query-side vectors
+  float* scores;                      // [F*N, nq]
+  const float* w;                     // wsum: weights [F, nq, N]
+  float* out;                         // wsum: [Bc, nq, T, C]
+};
+
+template <typename T> struct Ld16;
+template <> struct Ld16<float> {
+  static constexpr int E = 4;
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[8]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+};
+template <> struct Ld16<bf16_t> {
+  static constexpr int E = 8;
+  static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+  }
+};
+
+// ---- pass 1: scores[f*N+n, j] = sum_c x[f,n,c] * vec[f|0, j, c] --------------------------------------------
+// grid (F, ysplit); a wave walks tokens of its frame two at a time; vec of the frame sits in LDS ([nq][C] f32).
+template <typename T>
+__global__ __launch_bounds__(256) void lstp_scores_kernel(PoolArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float svec[];  // [nq][C]
+  constexpr int E = Ld16<T>::E;
+  const int C = a.n_taps * a.D;
+  const int f = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {
+    const int b = f / a.T, t = f % a.T;
+    for (int i = threadIdx.x; i < a.nq * C; i += 256) {
+      const int j = i / C, c = i % C;
+      svec[i] = a.per_frame ? a.vec[(((size_t)b * a.nq + j) * a.T + t) * C + c] : a.vec[(size_t)j * C + c];
+    }
+  }
+  __syncthreads();
+  const int wid = blockIdx.y * 4 + wave, nw = gridDim.y * 4;
+  for (int n0 = wid * 2; n0 < a.N; n0 += nw * 2) {
+    const int n1 = min(n0 + 1, a.N - 1);
+    float acc0[MAXQ], acc1[MAXQ];
+#pragma unroll
+    for (int j = 0; j < MAXQ; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
+    for (int tp = 0; tp < a.n_taps; ++tp) {
+      const T* x0 = reinterpret_cast<const T*>(a.taps[tp]) + ((size_t)f * a.N + n0) * a.D;
+      const T* x1 = reinterpret_cast<const T*>(a.taps[tp]) + ((size_t)f * a.N + n1) * a.D;
+      for (int c = lane * E; c < a.D; c += 64 * E) {
+        float v0[8], v1[8];
+        Ld16<T>::ld(x0 + c, v0);
+        Ld16<T>::ld(x1 + c, v1);
+#pragma unroll
+        for (int j = 0; j < MAXQ; ++j) {
+          if (j < a.nq) {
+            const float* wv = svec + j * C + tp * a.D + c;
+#pragma unroll
+            for (int e = 0; e < E; e += 4) {
+              const float4 w4 = *reinterpret_cast<const float4*>(wv + e);
+              acc0[j] += v0[e] * w4.x + v0[e + 1] * w4.y + v0[e + 2] * w4.z + v0[e + 3] * w4.w;
+              acc1[j] += v1[e] * w4.x + v1[e + 1] * w4.y + v1[e + 2] * w4.z + v1[e + 3] * w4.w;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXQ; ++j) {
+      if (j < a.nq) {
+        const float s0 = wave_sum(acc0[j]), s1 = wave_sum(acc1[j]);
+        if (lane == 0) {
+          a.scores[((size_t)f * a.N + n0) * a.nq + j] = s0;
+          if (n0 + 1 < a.N) a.scores[((size_t)f * a.N + n0 + 1) * a.nq + j] = s1;
+        }
+      }
+    }
+  }
+}
+
+// ---- pass 2: out[b, j, t, tap*D + c] = sum_n w[f, j, n] * x[f, n, c] -----------------------------------------
+// grid (F, n_taps); thread = one 16-byte channel chunk x one token phase; phases combined through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void lstp_wsum_kernel(PoolArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [nq][N] weights, then reduction scratch
+  constexpr int E = Ld16<T>::E;
+  const int f = blockIdx.x, tp = blockIdx.y;
+  const int ncols = a.D / E;
+  const int phases = blockDim.x / ncols;
+  const int col = threadIdx.x % ncols, ph = threadIdx.x / ncols;
+  for (int i = threadIdx.x; i < a.nq * a.N; i += blockDim.x) sw[i] = a.w[(size_t)f * a.nq * a.N + i];
+  __syncthreads();
+  float acc[MAXQ][E];
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j)
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[j][e] = 0.f;
+  const T* x = reinterpret_cast<const T*>(a.taps[tp]) + (size_t)f * a.N * a.D + col * E;
+  if (ph < phases) {
+    for (int n = ph; n < a.N; n += phases) {
+      float v[8];
+      Ld16<T>::ld(x + (size_t)n * a.D, v);
+#pragma unroll
+      for (int j = 0; j < MAXQ; ++j) {
+        if (j < a.nq) {
+          const float wj = sw[j * a.N + n];
+#pragma unroll
+          for (int e = 0; e < E; ++e) acc[j][e] += wj * v[e];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* red = sw + a.nq * a.N;  // [phases][nq][D]
+  if (ph < phases) {
+#pragma unroll
+    for (int j = 0; j < MAXQ; ++j)
+      if (j < a.nq)
+#pragma unroll
+        for (int e = 0; e < E; ++e) red[((size_t)ph * a.nq + j) * a.D + col * E + e] = acc[j][e];
+  }
+  __syncthreads();
+  const int C = a.n_taps * a.D;
+  const int b = f / a.T, t = f % a.T;
+  for (int i = threadIdx.x; i < a.nq * a.D; i += blockDim.x) {
+    const int j = i / a.D, c = i % a.D;
+    float s = 0.f;
+    for (int p = 0; p < phases; ++p) s += red[((size_t)p * a.nq + j) * a.D + c];
+    a.out[(((size_t)b * a.nq + j) * a.T + t) * C + tp * a.D + c] = s;
+  }
+}
+
+// ---- softmax over tokens (per frame, per query) and its backward ------------------------------------------------
+// scores [F*N, nq] -> P [F, nq, N] = softmax_n(scores * inv_sqrt_d); disjoint: Pm = P * [j == argmax_j P[:, n]]
+__global__ __launch_bounds__(256) void lstp_softmax_kernel(const float* __restrict__ scores, float* __restrict__ P,
+                                                           float* __restrict__ Pm, float* __restrict__ rowsum, int N,
+                                                           int nq, float inv_sqrt_d, int disjoint) {
+  extern __shared__ float sp[];  // [nq][N]
+  const int f = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = wave; j < nq; j += 4) {
+    float mx = -1e30f;
+    for (int n = lane; n < N; n += 64) mx = fmaxf(mx, scores[((size_t)f * N + n) * nq + j] * inv_sqrt_d);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int n = lane; n < N; n += 64) {
+      const float e = expf(scores[((size_t)f * N + n) * nq + j] * inv_sqrt_d - mx);
+      sp[j * N + n] = e;
+      s += e;
+    }
+    s = wave_sum(s);
+    const float inv = 1.f / s;
+    for (int n = lane; n < N; n += 64) {
+      const float p = sp[j * N + n] * inv;
+      sp[j * N + n] = p;
+      P[((size_t)f * nq + j) * N + n] = p;
+    }
+  }
+  if (!disjoint) return;
+  __syncthreads();
+  // torch.argmax picks the FIRST maximal index
+  for (int n = threadIdx.x; n < N; n += 256) {
+    int am = 0;
+    float m = sp[n];
+    for (int j = 1; j < nq; ++j)
+      if (sp[j * N + n] > m) { m = sp[j * N + n]; am = j; }
+    for (int j = 0; j < nq; ++j) {
+      const float v = j == am ? sp[j * N + n] : 0.f;
+      Pm[((size_t)f * nq + j) * N + n] = v;
+      sp[j * N + n] = v;
+    }
+  }
+  __syncthreads();
+  for (int j = wave; j < nq; j += 4) {
+    float s = 0.f;
+    for (int n = lane; n < N; n += 64) s += sp[j * N + n];
+    s = wave_sum(s);
+    if (lane == 0) rowsum[(size_t)f * nq + j] = s;
+  }
+}
+
+// dS[f, j, n] = inv_sqrt_d * P * (g - sum_n' P g),  g = dP[f*N+n, j] * [Pm != 0 if disjoint]
+// (+ drow[f, j] added to g where selected: gradient of rowsum(Pm) used by the b_V term)
+__global__ __launch_bounds__(256) void lstp_softmax_bwd_kernel(const float* __restrict__ P, const float* __restrict__ Pm,
+                                                               const float* __restrict__ dP, const float* __restrict__ drow,
+                                                               float* __restrict__ dS, int N, int nq, float inv_sqrt_d) {
+  const int f = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = wave; j < nq; j += 4) {
+    const float* p = P + ((size_t)f * nq + j) * N;
+    const float* pm = Pm ? Pm + ((size_t)f * nq + j) * N : nullptr;
+    const float dr = drow ? drow[(size_t)f * nq + j] : 0.f;
+    float s = 0.f;
+    for (int n = lane; n < N; n += 64) {
+      float g = dP[((size_t)f * N + n) * nq + j] + dr;
+      if (pm && pm[n] == 0.f) g = 0.f;
+      s += p[n] * g;
+    }
+    s = wave_sum(s);
+    for (int n = lane; n < N; n += 64) {
+      float g = dP[((size_t)f * N + n) * nq + j] + dr;
+      if (pm && pm[n] == 0.f) g = 0.f;
+      dS[((size_t)f * nq + j) * N + n] = inv_sqrt_d * p[n] * (g - s);
+    }
+  }
+}
+
+// out[j, c] = sum_{b,t} G[b, j, t, c]     (query-vector gradient of the shared-query case)
+__global__ __launch_bounds__(256) void lstp_reduce_frames_kernel(const float* __restrict__ G, float* __restrict__ out,
+                                                                 int Bc, int nq, int T, int C) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, j = blockIdx.y;
+  float s = 0.f;
+  if (c < C)
+    for (int r = rl; r < Bc * T; r += 4) {
+      const int b = r / T, t = r % T;
+      s += G[(((size_t)b * nq + j) * T + t) * C + c];
+    }
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) out[(size_t)j * C + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+}
+
+int fill_args(PoolArgs& a, const void* const* taps, int n_taps, int dtype, int D, int F, int N, int T, int nq) {
+  MVF_CHECK_ARG(taps && n_taps > 0 && n_taps <= MAXTAPS && nq > 0 && nq <= MAXQ && F > 0 && N > 0 && T > 0 && F % T == 0);
+  MVF_CHECK_ARG(dtype == MVF_F32 || dtype == MVF_BF16);
+  const int e = dtype == MVF_BF16 ? 8 : 4;
+  MVF_CHECK_ARG(D % e == 0 && D / e <= 256);
+  for (int i = 0; i < n_taps; ++i) {
+    MVF_CHECK_ARG(taps[i] && ((uintptr_t)taps[i] & 15) == 0);
+    a.taps[i] = taps[i];
+  }
+  a.n_taps = n_taps; a.D = D; a.F = F; a.N = N; a.T = T; a.nq = nq;
+  return MVF_OK;
+}
+
+}  // namespace
+
+extern "C" int mvf_lstp_scores(const void* const* taps, int n_taps, int dtype, int D, int F, int N, int T, int nq,
+                               const float* vec, int per_frame, float* scores, hipStream_t st) {
+  PoolArgs a{};
+  int rc = fill_args(a, taps, n_taps, dtype, D, F, N, T, nq);
+  if (rc != MVF_OK) return rc;
+  MVF_CHECK_ARG(vec && scores);
+  a.vec = vec; a.per_frame = per_frame; a.scores = scores;
+  const size_t lds = (size_t)nq * n_taps * D * sizeof(float);
+  MVF_CHECK_ARG(lds <= 64 * 1024);
+  const int ysplit = F >= 512 ? 1 : (F >= 128 ? 4 : 8);
+  dim3 grid(F, ysplit);
+  if (dtype == MVF_BF16) hipLaunchKernelGGL(lstp_scores_kernel<bf16_t>, grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(lstp_scores_kernel<float>, grid, dim3(256), lds, st, a);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_lstp_wsum(const void* const* taps, int n_taps, int dtype, int D, int F, int N, int T, int nq,
+                             const float* w, float* out, hipStream_t st) {
+  PoolArgs a{};
+  int rc = fill_args(a, taps, n_taps, dtype, D, F, N, T, nq);
+  if (rc != MVF_OK) return rc;
+  MVF_CHECK_ARG(w && out);
+  a.w = w; a.out = out;
+  const int e = dtype == MVF_BF16 ? 8 : 4;
+  const int ncols = D / e;
+  const int phases = std::max(1, 256 / ncols);
+  const int threads = ncols * phases;
+  const size_t lds = ((size_t)nq * N + (size_t)phases * nq * D) * sizeof(float);
+  MVF_CHECK_ARG(lds <= 64 * 1024);
+  dim3 grid(F, n_taps);
+  if (dtype == MVF_BF16) hipLaunchKernelGGL(lstp_wsum_kernel<bf16_t>, grid, dim3(threads), lds, st, a);
+  else hipLaunchKernelGGL(lstp_wsum_kernel<float>, grid, dim3(threads), lds, st, a);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_lstp_softmax_fwd(const float* scores, float* P, float* Pm, float* rowsum, int F, int N, int nq,
+                                    float inv_sqrt_d, int disjoint, hipStream_t st) {
+  MVF_CHECK_ARG(scores && P && F > 0 && N > 0 && nq > 0 && nq <= MAXQ && (!disjoint || (Pm && rowsum)));
+  hipLaunchKernelGGL(lstp_softmax_kernel, dim3(F), dim3(256), (size_t)nq * N * sizeof(float), st, scores, P, Pm, rowsum, N,
+                     nq, inv_sqrt_d, disjoint);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_lstp_softmax_bwd(const float* P, const float* Pm, const float* dP, const float* drow, float* dS, int F,
+                                    int N, int nq, float inv_sqrt_d, hipStream_t st) {
+  MVF_CHECK_ARG(P && dP && dS && F > 0 && N > 0 && nq > 0 && nq <= MAXQ);
+  hipLaunchKernelGGL(lstp_softmax_bwd_kernel, dim3(F), dim3(256), 0, st, P, Pm, dP, drow, dS, N, nq, inv_sqrt_d);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_lstp_reduce_frames(const float* G, float* out, int Bc, int nq, int T, int C, hipStream_t st) {
+  MVF_CHECK_ARG(G && out && Bc > 0 && nq > 0 && T > 0 && C > 0);
+  hipLaunchKernelGGL(lstp_reduce_frames_kernel, dim3(ceil_div(C, 64), nq), dim3(256), 0, st, G, out, Bc, nq, T, C);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}

@@ -1,0 +1,17 @@
+// Internal (non-exported) declarations shared between the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+#include "../../include/mvf_hip.h"
+
+// ---- backbone ----
+int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C,
+                     int ldc, float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tpf, int M,
+                     int N, int K, hipStream_t st);
+int mvf_im2col_impl(int dtype, const float* img, void* out, int F, int H, int W, int P, hipStream_t st);
+int mvf_cls_row_impl(float* x, const float* cls, const float* pos, int F, int tpf, int D, hipStream_t st);
+int mvf_layernorm_impl(int out_dtype, const float* x, size_t in_stride, const float* g, const float* b, void* y,
+                       size_t out_stride, int rows, int D, float eps, hipStream_t st);
+int mvf_cast_bf16_impl(const float* in, void* out, size_t n, hipStream_t st);
+int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t st);

@@ -1,0 +1,84 @@
+// Fused global-norm gradient clip + Adam (L2 weight decay) over ONE flat fp32 parameter buffer.
+// Reference: torch.nn.utils.clip_grad_norm_(model.parameters(), GRAD_CLIP) followed by
+// torch.optim.Adam(lr, betas=(0.9, 0.999), weight_decay) -- CARL_MVF/train.py:124-133,147-149,
+// utils/optimizer.py:60-66.  The head's 4.8 M trainable parameters live in one contiguous buffer (the DDP
+// gradient bucket is the matching flat gradient buffer), so the whole optimizer is three launches instead
+// of ~10 per parameter tensor.  HBM-bound: 4 streams read + 3 written per element, float4 accesses.
+#include "common.h"
+#include "mvf_hip_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0)
+    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// norm_out[0] = sqrt(sum(part) + extra_sq[0]) ; fixed summation order -> reproducible
+__global__ void sqnorm_final_kernel(const float* __restrict__ part, int nparts, const float* __restrict__ extra_sq,
+                                    float* __restrict__ norm_out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) norm_out[0] = sqrtf(red[0] + red[1] + red[2] + red[3] + (extra_sq ? extra_sq[0] : 0.f));
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                                                   float wd, float bc1, float bc2_sqrt, float clip,
+                                                   const float* __restrict__ norm, float gscale) {
+  float coef = gscale;
+  if (clip > 0.f && norm != nullptr) coef *= fminf(1.f, clip / (norm[0] * gscale + 1e-6f));
+  const float step = lr / bc1;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float pi = p[i];
+    const float gi = g[i] * coef + wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+  }
+}
+
+}  // namespace
+
+// norm_out[0] = || g ||_2 (optionally sqrt(||g||^2 + extra_sq[0])); scratch: >= 1024 floats
+extern "C" int mvf_grad_norm(const float* g, size_t n, const float* extra_sq, float* scratch, float* norm_out,
+                             hipStream_t st) {
+  MVF_CHECK_ARG(g && scratch && norm_out && n > 0 && ((uintptr_t)g & 15) == 0);
+  const int nblk = (int)std::min<size_t>(1024, (n / 4 + 255) / 256 + 1);
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nblk), dim3(256), 0, st, g, n, scratch);
+  hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, st, scratch, nblk, extra_sq, norm_out);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+// One Adam step on flat buffers. step >= 1 (1-based, like torch). clip <= 0 disables clipping.
+// gscale multiplies every gradient first (e.g. 1/world_size when the all-reduce summed instead of averaged).
+extern "C" int mvf_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int step, float clip, const float* norm, float gscale,
+                             hipStream_t st) {
+  MVF_CHECK_ARG(p && g && m && v && n > 0 && step >= 1);
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  const int nblk = (int)std::min<size_t>(2048, (n + 255) / 256);
+  hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1,
+                     bc2s, clip, norm, gscale);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}

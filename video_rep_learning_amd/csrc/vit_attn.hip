@@ -1,0 +1,321 @@
+// Fused multi-head self-attention of the ViT blocks (no mask, head_dim 64):
+//   out[f, n, h*64:(h+1)*64] = softmax(q k^T / sqrt(64)) v       q,k,v = column slices of qkv[f*N+n, 3*D]
+// Stands in for timm Attention.forward (reached from CARL_MVF/models/transformer.py:188).  The [N,N] score
+// matrix never leaves registers.
+//
+// gfx950 design:
+//  * one workgroup (4 waves) per (frame, head) [x query chunk when N > 224]; K and V of a 224-key block are
+//    staged ONCE in LDS (K XOR-swizzled for conflict-free ds_read_b128 MFMA fragments)
+//  * scores are computed TRANSPOSED, S^T = K Q^T, so a lane owns one query column: the softmax row
+//    reduction is in-lane + two cross-lane steps (xor 16, 32), and the S^T accumulator registers are
+//    directly the B operand of the next MFMA (O^T = V^T P^T) -- no LDS round trip for P
+//  * bf16: v_mfma_f32_16x16x32_bf16, V fragments fetched with the ds_read_b64_tr_b16 transposing read
+//    (or 2-byte gathers, selectable, used to cross-check the transposing read on hardware)
+//  * f32 (parity mode): v_mfma_f32_16x16x4_f32, exact fp32
+//  * online softmax across key blocks (only one block for N = 197)
+#include "common.h"
+#include "mvf_hip_internal.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int KT = 14;          // key tiles (of 16) per LDS block
+constexpr int KB = KT * 16;     // 224 keys per block
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct AttnArgs {
+  const char* qkv;  // [F*N, 3*D]
+  char* out;        // [F*N, D]
+  int N, H, D;      // tokens per frame, heads, model dim (= H*64)
+  int rounds;       // q-tiles each wave walks through
+  int nblk;         // key blocks
+  float scale_log2; // hd^-0.5 * log2(e)
+};
+
+// ------------------------------------------------------------------------------------------------
+// bf16
+// ------------------------------------------------------------------------------------------------
+template <bool TR_READ>
+__global__ __launch_bounds__(256, 2) void vit_attn_bf16_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * KB * 128];
+  char* sk = smem;             // K block: [224][64] bf16, 128-B rows, 16-B chunks XOR-swizzled by (row & 7)
+  char* sv = smem + KB * 128;  // V block: [224][64] bf16, 128-B rows, linear
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int f = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const size_t ld = (size_t)3 * a.D;                       // qkv row stride (elements)
+  const bf16_t* base = reinterpret_cast<const bf16_t*>(a.qkv) + (size_t)f * a.N * ld;
+  const bf16_t* qb = base + h * HD;
+  const bf16_t* kbp = base + a.D + h * HD;
+  const bf16_t* vbp = base + 2 * a.D + h * HD;
+
+  for (int rd = 0; rd < a.rounds; ++rd) {
+    const int qt = (blockIdx.y * a.rounds + rd) * 4 + wave;  // query tile of this wave
+    const int qrow = min(qt * 16 + li, a.N - 1);
+    // Q fragments (MFMA B operand): lane (query li, k-group g) holds Q[q][ks*32 + 8g .. +8]
+    bf16x8_t qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      qf[ks] = *reinterpret_cast<const bf16x8_t*>(qb + (size_t)qrow * ld + ks * 32 + g * 8);
+
+    float m_run = -1e30f, l_run = 0.f;
+    f32x4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    for (int kb = 0; kb < a.nblk; ++kb) {
+      if (a.nblk > 1 || rd == 0) {
+        if (kb > 0 || rd > 0) __syncthreads();  // everyone done with the previous block
+        // ---- stage K, V block: thread -> (row = tid/8 + 32*i, chunk = tid%8) ----
+#pragma unroll
+        for (int i = 0; i < KB / 32; ++i) {
+          const int r = (tid >> 3) + 32 * i, c = tid & 7;
+          const int key = kb * KB + r;
+          uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+          if (key < a.N) {
+            kv = *reinterpret_cast<const uint4*>(kbp + (size_t)key * ld + c * 8);
+            vv = *reinterpret_cast<const uint4*>(vbp + (size_t)key * ld + c * 8);
+          }
+          *reinterpret_cast<uint4*>(sk + r * 128 + ((c ^ (r & 7)) << 4)) = kv;
+          *reinterpret_cast<uint4*>(sv + r * 128 + (c << 4)) = vv;
+        }
+        __syncthreads();
+      }
+      // ---- S^T tiles: s[kt] = K_tile(kt) . Q^T  -> lane holds S[query li][key kt*16 + 4g + r] ----
+      f32x4_t s[KT];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        s[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int row = kt * 16 + li;
+          const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sk + row * 128 + (((ks * 4 + g) ^ (li & 7)) << 4));
+          s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+        }
+      }
+      // ---- online softmax (log2 domain) ----
+      float mx = -1e30f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb * KB + kt * 16 + 4 * g + r;
+          float v = s[kt][r] * a.scale_log2;
+          v = key < a.N ? v : -1e30f;
+          s[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float ls = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
+          s[kt][r] = p;
+          ls += p;
+        }
+      ls += __shfl_xor(ls, 16, 64);
+      ls += __shfl_xor(ls, 32, 64);
+      l_run = l_run * alpha + ls;
+      m_run = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+      // ---- O^T += V^T P^T : k-step = 32 keys = score tiles (2s, 2s+1) ----
+#pragma unroll
+      for (int st = 0; st < KT / 2; ++st) {
+        union { bf16x8_t v; uint32_t u[4]; } pf;
+        pf.u[0] = pack_bf16x2(s[2 * st][0], s[2 * st][1]);
+        pf.u[1] = pack_bf16x2(s[2 * st][2], s[2 * st][3]);
+        pf.u[2] = pack_bf16x2(s[2 * st + 1][0], s[2 * st + 1][1]);
+        pf.u[3] = pack_bf16x2(s[2 * st + 1][2], s[2 * st + 1][3]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          union { bf16x8_t v; bf16x4_t h[2]; bf16_t e[8]; } vf;
+          if constexpr (TR_READ) {
+            // group of 16 lanes reads a 4-key x 16-d block transposed: lane supplies &V[key0+4g+(li>>2)][d0+4*(li&3)],
+            // receives V[key0+4g+0..3][d0+li]
+            const char* p0 = sv + (st * 32 + 4 * g + (li >> 2)) * 128 + (dt * 16 + 4 * (li & 3)) * 2;
+            vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) bf16x4_t*)(p0));
+            vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) bf16x4_t*)(p0 + 16 * 128));
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int key = st * 32 + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+              vf.e[j] = *reinterpret_cast<const bf16_t*>(sv + key * 128 + (dt * 16 + li) * 2);
+            }
+          }
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
+        }
+      }
+    }
+    // ---- write O[query li][dt*16 + 4g + r] / l ----
+    const int q = qt * 16 + li;
+    if (q < a.N) {
+      const float inv = 1.0f / l_run;
+      bf16_t* orow = reinterpret_cast<bf16_t*>(a.out) + ((size_t)f * a.N + q) * a.D + h * HD;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<uint2*>(orow + dt * 16 + 4 * g) =
+            make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 (parity mode)
+// ------------------------------------------------------------------------------------------------
+constexpr int VROW = (HD + 4) * 4;  // 272-B V rows: keys 4 apart fall on different banks for ds_read_b32
+constexpr int F32_LDS = KB * 256 + KB * VROW;
+
+__global__ __launch_bounds__(256, 1) void vit_attn_f32_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sk = smem;             // K block [224][64] f32, 256-B rows, 16-B chunks swizzled by (row & 15)
+  char* sv = smem + KB * 256;  // V block [224][68] f32
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int f = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const size_t ld = (size_t)3 * a.D;
+  const float* base = reinterpret_cast<const float*>(a.qkv) + (size_t)f * a.N * ld;
+  const float* qb = base + h * HD;
+  const float* kbp = base + a.D + h * HD;
+  const float* vbp = base + 2 * a.D + h * HD;
+
+  for (int rd = 0; rd < a.rounds; ++rd) {
+    const int qt = (blockIdx.y * a.rounds + rd) * 4 + wave;
+    const int qrow = min(qt * 16 + li, a.N - 1);
+    f32x4_t qf[4];  // lane (query li, g): Q[q][4*(g+4h) .. +4], h = 0..3
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) qf[hh] = *reinterpret_cast<const f32x4_t*>(qb + (size_t)qrow * ld + 4 * (g + 4 * hh));
+
+    float m_run = -1e30f, l_run = 0.f;
+    f32x4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    for (int kb = 0; kb < a.nblk; ++kb) {
+      if (a.nblk > 1 || rd == 0) {
+        if (kb > 0 || rd > 0) __syncthreads();
+        // thread -> (row = tid/16 + 16*i, chunk = tid%16)
+#pragma unroll
+        for (int i = 0; i < KB / 16; ++i) {
+          const int r = (tid >> 4) + 16 * i, c = tid & 15;
+          const int key = kb * KB + r;
+          float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+          if (key < a.N) {
+            kv = *reinterpret_cast<const float4*>(kbp + (size_t)key * ld + c * 4);
+            vv = *reinterpret_cast<const float4*>(vbp + (size_t)key * ld + c * 4);
+          }
+          *reinterpret_cast<float4*>(sk + r * 256 + ((c ^ (r & 15)) << 4)) = kv;
+          *reinterpret_cast<float4*>(sv + r * VROW + (c << 4)) = vv;
+        }
+        __syncthreads();
+      }
+      f32x4_t s[KT];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        s[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) {
+          const int row = kt * 16 + li;
+          const f32x4_t kf = *reinterpret_cast<const f32x4_t*>(sk + row * 256 + (((g + 4 * hh) ^ li) << 4));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[hh][e], s[kt], 0, 0, 0);
+        }
+      }
+      float mx = -1e30f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb * KB + kt * 16 + 4 * g + r;
+          float v = s[kt][r] * a.scale_log2;
+          v = key < a.N ? v : -1e30f;
+          s[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2f(m_run - m_new);
+      float ls = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = exp2f(s[kt][r] - m_new);
+          s[kt][r] = p;
+          ls += p;
+        }
+      ls += __shfl_xor(ls, 16, 64);
+      ls += __shfl_xor(ls, 32, 64);
+      l_run = l_run * alpha + ls;
+      m_run = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+      // O^T[d][q] += sum_key V[key][d] P[q][key]; MFMA step (kt, r): k-lane g <-> key kt*16 + 4g + r
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const char* vr = sv + (kt * 16 + 4 * g + r) * VROW + li * 4;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const float vv = *reinterpret_cast<const float*>(vr + dt * 64);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, s[kt][r], o[dt], 0, 0, 0);
+          }
+        }
+    }
+    const int q = qt * 16 + li;
+    if (q < a.N) {
+      const float inv = 1.0f / l_run;
+      float* orow = reinterpret_cast<float*>(a.out) + ((size_t)f * a.N + q) * a.D + h * HD;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<float4*>(orow + dt * 16 + 4 * g) =
+            make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+    }
+  }
+}
+
+}  // namespace
+
+// variant: 0 = default (transposing LDS read for V), 1 = 2-byte gather reads (cross-check path)
+int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t st) {
+  MVF_CHECK_ARG(qkv && out && F > 0 && N > 0 && H > 0 && D == H * HD);
+  MVF_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0);
+  AttnArgs a;
+  a.qkv = (const char*)qkv; a.out = (char*)out; a.N = N; a.H = H; a.D = D;
+  a.nblk = ceil_div(N, KB);
+  const int qtiles = ceil_div(N, 16);
+  int chunks;
+  if (a.nblk == 1) { a.rounds = ceil_div(qtiles, 4); chunks = 1; }
+  else { a.rounds = 1; chunks = ceil_div(qtiles, 4); }
+  a.scale_log2 = LOG2E / 8.0f;  // 64^-0.5 * log2(e)
+  dim3 grid(F * H, chunks);
+  if (dtype == MVF_BF16) {
+    if (variant == 0) hipLaunchKernelGGL(vit_attn_bf16_kernel<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(vit_attn_bf16_kernel<false>, grid, dim3(256), 0, st, a);
+  } else if (dtype == MVF_F32) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attn_f32_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, F32_LDS);
+      attr = true;
+    }
+    hipLaunchKernelGGL(vit_attn_f32_kernel, grid, dim3(256), F32_LDS, st, a);
+  } else {
+    return MVF_ERR_ARG;
+  }
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}

@@ -1,0 +1,119 @@
+// Host-side driver of the frozen ViT backbone forward: one C-ABI call enqueues the whole
+// patch-embed + depth x (LN, QKV, attention, proj, LN, FC1+GELU, FC2) chain on the caller's stream and
+// writes the tapped block outputs (CLS dropped) straight in the layout the LSTP pooling kernels read.
+//
+// Replaces: timm VisionTransformer.forward + FeatureExtractor hooks/concat + the CLS-drop / movedim /
+// reshape copies of CARL_MVF/models/transformer.py:186-214, 306-333.
+#include "common.h"
+#include "mvf_hip_internal.h"
+
+namespace {
+enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
+
+struct Ws {
+  float* x;     // residual stream  [Mc, D] fp32
+  char* h;      // LN out / attention out [Mc, D] T
+  char* qkv;    // [Mc, 3D] T
+  char* hid;    // [Mc, 4D] T   (also holds the patch rows before the embed GEMM)
+};
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+size_t carve(int dtype, int fc, int N, int D, int P, Ws* w, char* base) {
+  const size_t esz = dtype == MVF_BF16 ? 2 : 4;
+  const size_t Mc = (size_t)fc * N;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align256(bytes);
+    return p;
+  };
+  char* x = take(Mc * D * 4);
+  char* h = take(Mc * D * esz);
+  char* qkv = take(Mc * 3 * D * esz);
+  const size_t patch_bytes = (size_t)fc * (N - 1) * 3 * P * P * esz;
+  char* hid = take(std::max(Mc * 4 * D * esz, patch_bytes));
+  if (w) { w->x = (float*)x; w->h = h; w->qkv = qkv; w->hid = hid; }
+  return off;
+}
+}  // namespace
+
+extern "C" size_t mvf_vit_workspace_bytes(int dtype, int frames_per_chunk, int tokens, int dim, int patch) {
+  return carve(dtype, frames_per_chunk, tokens, dim, patch, nullptr, nullptr);
+}
+
+extern "C" int mvf_vit_fwd(const MvfVitWeights* w, int dtype, const float* frames, int F, void* const* taps_out,
+                           float* cls_out, void* workspace, size_t ws_bytes, int frames_per_chunk, int attn_variant,
+                           hipStream_t st) {
+  MVF_CHECK_ARG(w && frames && workspace && F > 0);
+  MVF_CHECK_ARG(dtype == MVF_F32 || dtype == MVF_BF16);
+  const int D = w->dim, H = w->heads, P = w->patch, img = w->img;
+  MVF_CHECK_ARG(D == H * 64 && img % P == 0 && w->depth > 0 && w->n_taps >= 0 && w->n_taps <= 8);
+  const int np = (img / P) * (img / P);
+  const int N = np + 1;
+  const int fc_max = frames_per_chunk > 0 ? std::min(frames_per_chunk, F) : F;
+  Ws ws;
+  MVF_CHECK_ARG(carve(dtype, fc_max, N, D, P, &ws, (char*)workspace) <= ws_bytes);
+  const size_t esz = dtype == MVF_BF16 ? 2 : 4;
+  const int kp = 3 * P * P;
+  int rc;
+#define RUN(call)               \
+  do {                          \
+    rc = (call);                \
+    if (rc != MVF_OK) return rc; \
+  } while (0)
+
+  for (int f0 = 0; f0 < F; f0 += fc_max) {
+    const int fc = std::min(fc_max, F - f0);
+    const int Mc = fc * N;
+    // ---- patch embed: gather patches, GEMM with bias + pos_embed fused, rows 1.. of every frame ----
+    RUN(mvf_im2col_impl(dtype, frames + (size_t)f0 * 3 * img * img, ws.hid, fc, img, img, P, st));
+    RUN(mvf_gemm_tc_impl(dtype, EPI_PATCH, ws.hid, kp, w->patch_w, kp, w->patch_b, nullptr, 0, ws.x, D, nullptr, 0,
+                         w->pos_embed, nullptr, N, fc * np, D, kp, st));
+    RUN(mvf_cls_row_impl(ws.x, w->cls_token, w->pos_embed, fc, N, D, st));
+    for (int l = 0; l < w->depth; ++l) {
+      int tap = -1;
+      for (int j = 0; j < w->n_taps; ++j)
+        if (w->taps[j] == l) tap = j;
+      RUN(mvf_layernorm_impl(dtype, ws.x, D, w->ln1_w[l], w->ln1_b[l], ws.h, D, Mc, D, w->ln_eps, st));
+      RUN(mvf_gemm_tc_impl(dtype, EPI_STORE, ws.h, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0,
+                           nullptr, nullptr, N, Mc, 3 * D, D, st));
+      RUN(mvf_vit_attn_impl(dtype, ws.qkv, ws.h, fc, N, H, D, attn_variant, st));
+      RUN(mvf_gemm_tc_impl(dtype, EPI_RESID, ws.h, D, w->proj_w[l], D, w->proj_b[l], nullptr, 0, ws.x, D, nullptr, 0,
+                           nullptr, w->ls1 ? w->ls1[l] : nullptr, N, Mc, D, D, st));
+      RUN(mvf_layernorm_impl(dtype, ws.x, D, w->ln2_w[l], w->ln2_b[l], ws.h, D, Mc, D, w->ln_eps, st));
+      RUN(mvf_gemm_tc_impl(dtype, EPI_GELU, ws.h, D, w->fc1_w[l], D, w->fc1_b[l], ws.hid, 4 * D, nullptr, 0, nullptr, 0,
+                           nullptr, nullptr, N, Mc, 4 * D, D, st));
+      void* tap_ptr = nullptr;
+      if (tap >= 0 && taps_out && taps_out[tap]) tap_ptr = (char*)taps_out[tap] + (size_t)f0 * np * D * esz;
+      RUN(mvf_gemm_tc_impl(dtype, EPI_RESID, ws.hid, 4 * D, w->fc2_w[l], 4 * D, w->fc2_b[l], nullptr, 0, ws.x, D, tap_ptr,
+                           D, nullptr, w->ls2 ? w->ls2[l] : nullptr, N, Mc, D, 4 * D, st));
+    }
+    if (cls_out)  // final LN on the CLS rows only (timm forward_head, global_pool='token')
+      RUN(mvf_layernorm_impl(MVF_F32, ws.x, (size_t)N * D, w->norm_w, w->norm_b, cls_out + (size_t)f0 * D, D, fc, D,
+                             w->ln_eps, st));
+  }
+#undef RUN
+  return MVF_OK;
+}
+
+// ---- unit-testable pieces of the same path ----
+extern "C" int mvf_gemm_tc(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C,
+                           int ldc, float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tpf,
+                           int M, int N, int K, hipStream_t st) {
+  return mvf_gemm_tc_impl(dtype, epi, A, lda, W, ldw, bias, C, ldc, resid, ldr, tap, ldt, pos, ls, tpf, M, N, K, st);
+}
+extern "C" int mvf_patchify(int dtype, const float* frames, void* out, int F, int H, int W, int P, hipStream_t st) {
+  return mvf_im2col_impl(dtype, frames, out, F, H, W, P, st);
+}
+extern "C" int mvf_layernorm_fwd(int out_dtype, const float* x, size_t in_stride, const float* g, const float* b, void* y,
+                                 size_t out_stride, int rows, int D, float eps, hipStream_t st) {
+  return mvf_layernorm_impl(out_dtype, x, in_stride, g, b, y, out_stride, rows, D, eps, st);
+}
+extern "C" int mvf_vit_attn_fwd(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant,
+                                hipStream_t st) {
+  return mvf_vit_attn_impl(dtype, qkv, out, F, N, H, D, variant, st);
+}
+extern "C" int mvf_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t st) {
+  return mvf_cast_bf16_impl(in, out, n, st);
+}

@@ -1,0 +1,152 @@
+// HBM-bound helper kernels of the ViT forward: patch gather (+cast), CLS row init, LayerNorm.
+// They stand in for the aten ops timm issues around its GEMMs (reference call site
+// CARL_MVF/models/transformer.py:188 -> timm VisionTransformer.forward).
+#include "common.h"
+#include "mvf_hip_internal.h"
+
+namespace {
+
+// frames [F,3,H,W] fp32 -> patch rows [F*gh*gw, 3*P*P] (T), k = c*P*P + ky*P + kx (Conv2d weight order).
+// One thread moves 4 consecutive kx (16 B read, coalesced along kx then px).
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, T* __restrict__ out, int F, int H,
+                                                     int W, int P) {
+  const int gh = H / P, gw = W / P;
+  const int kdim = 3 * P * P;
+  const int quads = P / 4;
+  const size_t total = (size_t)F * 3 * H * (W / 4);
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    // idx walks the image in memory order (f, c, y, x/4) -> fully coalesced reads
+    const int xq = (int)(idx % (W / 4));
+    size_t r = idx / (W / 4);
+    const int y = (int)(r % H);
+    r /= H;
+    const int c = (int)(r % 3);
+    const int f = (int)(r / 3);
+    const float4 v = *reinterpret_cast<const float4*>(img + idx * 4);
+    const int px = (xq * 4) / P, kx = (xq * 4) % P;
+    const int py = y / P, ky = y % P;
+    const size_t row = ((size_t)f * gh + py) * gw + px;
+    T* dst = out + row * kdim + (size_t)c * P * P + ky * P + kx;
+    (void)quads;
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(dst) = v;
+    } else {
+      *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    }
+  }
+}
+
+// x[f, 0, :] = cls_token + pos_embed[0]
+__global__ void cls_row_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos,
+                               int F, int tpf, int D) {
+  const int f = blockIdx.x;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) x[(size_t)f * tpf * D + d] = cls[d] + pos[d];
+}
+
+// LayerNorm over the last dim, one wave per row, row cached in registers (D <= 64*4*MAXV).
+// in: fp32 rows with stride `in_stride` rows apart (lets the final norm touch only CLS rows).
+template <typename TO, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, size_t in_stride,
+                                                        const float* __restrict__ g, const float* __restrict__ b,
+                                                        TO* __restrict__ y, size_t out_stride, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * in_stride;
+  float4 v[MAXV];
+  const int nv = D / 4;  // float4 per row
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int q = lane + i * 64;
+    if (q < nv) {
+      v[i] = *reinterpret_cast<const float4*>(xr + q * 4);
+      s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+  }
+  const float mean = wave_sum(s) / D;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int q = lane + i * 64;
+    if (q < nv) {
+      const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      ss += a * a + bb * bb + c * c + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / D + eps);
+  TO* yr = y + (size_t)row * out_stride;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int q = lane + i * 64;
+    if (q < nv) {
+      const float4 gg = *reinterpret_cast<const float4*>(g + q * 4);
+      const float4 be = *reinterpret_cast<const float4*>(b + q * 4);
+      float o[4] = {(v[i].x - mean) * rstd * gg.x + be.x, (v[i].y - mean) * rstd * gg.y + be.y,
+                    (v[i].z - mean) * rstd * gg.z + be.z, (v[i].w - mean) * rstd * gg.w + be.w};
+      if constexpr (sizeof(TO) == 4) {
+        *reinterpret_cast<float4*>(yr + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+        *reinterpret_cast<uint2*>(yr + q * 4) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+      }
+    }
+  }
+}
+
+// fp32 -> bf16 cast (weights pre-pack)
+__global__ void cast_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(in)[i];
+    reinterpret_cast<uint2*>(out)[i] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+  }
+}
+
+}  // namespace
+
+int mvf_im2col_impl(int dtype, const float* img, void* out, int F, int H, int W, int P, hipStream_t st) {
+  MVF_CHECK_ARG(img && out && F > 0 && H % P == 0 && W % P == 0 && P % 4 == 0 && W % 4 == 0);
+  const size_t total = (size_t)F * 3 * H * (W / 4);
+  const int grid = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
+  if (dtype == MVF_BF16)
+    hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, img, (bf16_t*)out, F, H, W, P);
+  else
+    hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid), dim3(256), 0, st, img, (float*)out, F, H, W, P);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+int mvf_cls_row_impl(float* x, const float* cls, const float* pos, int F, int tpf, int D, hipStream_t st) {
+  MVF_CHECK_ARG(x && cls && pos && F > 0);
+  hipLaunchKernelGGL(cls_row_kernel, dim3(F), dim3(256), 0, st, x, cls, pos, F, tpf, D);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+int mvf_layernorm_impl(int out_dtype, const float* x, size_t in_stride, const float* g, const float* b, void* y,
+                       size_t out_stride, int rows, int D, float eps, hipStream_t st) {
+  MVF_CHECK_ARG(x && g && b && y && rows > 0 && D % 4 == 0 && D <= 64 * 4 * 8);
+  MVF_CHECK_ARG(in_stride % 4 == 0 && out_stride % 4 == 0);
+  const int grid = ceil_div(rows, 4);
+  const int nv = ceil_div(D / 4, 64);
+#define LN_LAUNCH(TO, MV) \
+  hipLaunchKernelGGL((layernorm_kernel<TO, MV>), dim3(grid), dim3(256), 0, st, x, in_stride, g, b, (TO*)y, out_stride, rows, D, eps)
+  if (out_dtype == MVF_BF16) {
+    if (nv <= 1) LN_LAUNCH(bf16_t, 1); else if (nv <= 2) LN_LAUNCH(bf16_t, 2); else if (nv <= 4) LN_LAUNCH(bf16_t, 4); else LN_LAUNCH(bf16_t, 8);
+  } else {
+    if (nv <= 1) LN_LAUNCH(float, 1); else if (nv <= 2) LN_LAUNCH(float, 2); else if (nv <= 4) LN_LAUNCH(float, 4); else LN_LAUNCH(float, 8);
+  }
+#undef LN_LAUNCH
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+int mvf_cast_bf16_impl(const float* in, void* out, size_t n, hipStream_t st) {
+  MVF_CHECK_ARG(in && out && n % 4 == 0);
+  const size_t n4 = n / 4;
+  if (n4 == 0) return MVF_OK;
+  const int grid = (int)std::min<size_t>((n4 + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, st, in, (bf16_t*)out, n4);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}

@@ -1,0 +1,607 @@
+"""Functional ops of the MV-Former hot path: thin `torch.autograd.Function`s whose forward AND backward are
+calls into libmvf_hip.so (include/mvf_hip.h).  PyTorch keeps the autograd graph, owns the memory (caching
+allocator) and provides the stream; no arithmetic of the path is done by ATen here.
+
+Every op fails loudly on non-CUDA tensors or a missing library (see _lib.py) -- there is no CPU fallback.
+"""
+import math
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import call, ptr, stream, F32, BF16
+
+
+def _dt(dtype):
+    if dtype in (torch.float32, 'fp32', 'f32', F32):
+        return F32, torch.float32
+    if dtype in (torch.bfloat16, 'bf16', BF16):
+        return BF16, torch.bfloat16
+    raise ValueError('unsupported compute dtype %r' % (dtype,))
+
+
+def _mat(t):
+    """2-D fp32 matrix with unit inner stride -> (data_ptr, row stride)."""
+    if not t.is_cuda:
+        raise _lib.MvfError('HIP op received a %s tensor (no CPU fallback)' % t.device)
+    assert t.dim() == 2 and t.dtype == torch.float32, (t.shape, t.dtype)
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t, t.data_ptr(), t.stride(0) if t.shape[0] > 1 else t.shape[1]
+
+
+def _hgemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias=None, table=None, tab_si=0, tab_sn=0, tab_div=1,
+           tab_mod=1, alpha=1.0, relu=False, accumulate=False):
+    call('mvf_hgemm', A, sam, sak, B, sbk, sbn, C, ldc, ptr(bias), ptr(table), tab_si, tab_sn, tab_div, tab_mod,
+         M, N, K, alpha, int(relu), int(accumulate), stream())
+
+
+# ------------------------------------------------------------------------------------------------
+# Linear  y = act(x W^T + b [+ table[(row // div) % mod]])
+# ------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, relu, table, tab_div, tab_mod):
+        x, xp, ldx = _mat(x)
+        w, wp, ldw = _mat(w)
+        M, K = x.shape
+        N = w.shape[0]
+        assert w.shape[1] == K
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        if table is not None:
+            table = table.contiguous()
+            assert table.shape[1] == N
+        _hgemm(xp, ldx, 1, wp, 1, ldw, y.data_ptr(), N, M, N, K, bias=b, table=table,
+               tab_si=N if table is not None else 0, tab_sn=1, tab_div=tab_div, tab_mod=tab_mod, relu=relu)
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.has_bias = b is not None
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy, dyp, ldy = _mat(dy)
+        M, K = x.shape
+        N = w.shape[0]
+        if ctx.relu:
+            if ldy != N:
+                dy = dy.contiguous()
+            g = torch.empty(M, N, device=dy.device, dtype=torch.float32)
+            call('mvf_relu_bwd', dy.data_ptr(), y.data_ptr(), g.data_ptr(), M * N, stream())
+            dy, dyp, ldy = g, g.data_ptr(), N
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+            _hgemm(dyp, ldy, 1, w.data_ptr(), w.stride(0), 1, dx.data_ptr(), K, M, K, N)     # dx = dy . W
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty(N, K, device=dy.device, dtype=torch.float32)
+            _hgemm(dyp, 1, ldy, x.data_ptr(), x.stride(0), 1, dw.data_ptr(), K, N, K, M)     # dW = dy^T . x
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(N, device=dy.device, dtype=torch.float32)
+            call('mvf_colsum', dyp, ldy, M, N, db.data_ptr(), 0, stream())
+        return dx, dw, db, None, None, None, None
+
+
+def linear(x, w, b=None, relu=False, table=None, tab_div=1, tab_mod=1):
+    """x [..., K] -> [..., N]; `table` [mod, N] is added to row r as table[(r // div) % mod] (sin/cos PE)."""
+    lead = x.shape[:-1]
+    y = _Linear.apply(x.reshape(-1, x.shape[-1]), w, b, relu, table, tab_div, tab_mod)
+    return y.view(*lead, w.shape[0])
+
+
+class _MatmulNN(torch.autograd.Function):
+    """c = a @ b for small fp32 matrices (wq = q W_K of the pooling rewrite)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, ap, lda = _mat(a)
+        b, bp, ldb = _mat(b)
+        M, K = a.shape
+        N = b.shape[1]
+        c = torch.empty(M, N, device=a.device, dtype=torch.float32)
+        _hgemm(ap, lda, 1, bp, ldb, 1, c.data_ptr(), N, M, N, K)
+        ctx.save_for_backward(a, b)
+        return c
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        dc, dcp, ldc = _mat(dc)
+        M, K = a.shape
+        N = b.shape[1]
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty(M, K, device=dc.device, dtype=torch.float32)
+            _hgemm(dcp, ldc, 1, b.data_ptr(), 1, b.stride(0), da.data_ptr(), K, M, K, N)     # da = dc . b^T
+        if ctx.needs_input_grad[1]:
+            db = torch.empty(K, N, device=dc.device, dtype=torch.float32)
+            _hgemm(a.data_ptr(), 1, a.stride(0), dcp, ldc, 1, db.data_ptr(), N, K, N, M)     # db = a^T . dc
+        return da, db
+
+
+def matmul(a, b):
+    return _MatmulNN.apply(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm
+# ------------------------------------------------------------------------------------------------
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        x = x.contiguous()
+        R, D = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(R, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        call('mvf_ln_fwd', ptr(x), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), R, D, eps, stream())
+        ctx.save_for_backward(x, g, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        R, D = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.empty_like(g)
+        db = torch.empty_like(g)
+        call('mvf_ln_bwd', ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dg), ptr(db), R, D, 0, stream())
+        return dx, dg, db, None
+
+
+def layer_norm(x, g, b, eps=1e-5):
+    shp = x.shape
+    return _LayerNorm.apply(x.reshape(-1, shp[-1]), g, b, eps).view(shp)
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm1d (+ optional fused ReLU), with cross-rank statistics when `group_size > 1` (SyncBN)
+# ------------------------------------------------------------------------------------------------
+def _world(group):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, b, running_mean, running_var, momentum, eps, relu, sync, group):
+        x = x.contiguous()
+        R, C = x.shape
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        var = torch.empty_like(mean)
+        call('mvf_bn_stats', ptr(x), R, C, ptr(mean), ptr(var), stream())
+        count = float(R)
+        world = _world(group) if sync else 1
+        if world > 1:
+            # exchange (mean, biased var, count) and merge (Chan); 2C+1 floats per rank -- collective C2 of SURVEY.md
+            local = torch.cat([mean, var, mean.new_tensor([count])])
+            gathered = [torch.empty_like(local) for _ in range(world)]
+            dist.all_gather(gathered, local, group=group)
+            st = torch.stack(gathered)
+            n = st[:, -1:]
+            count = float(n.sum())
+            gm = (st[:, :C] * n).sum(0) / count
+            gv = ((st[:, C:2 * C] + (st[:, :C] - gm) ** 2) * n).sum(0) / count
+            mean, var = gm.contiguous(), gv.contiguous()
+        with torch.no_grad():
+            running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+            running_var.mul_(1 - momentum).add_(var, alpha=momentum * count / max(count - 1.0, 1.0))
+        y = torch.empty_like(x)
+        call('mvf_bn_fwd', ptr(x), ptr(mean), ptr(var), ptr(g), ptr(b), ptr(y), R, C, eps, int(relu), stream())
+        ctx.save_for_backward(x, g, b, mean, var)
+        ctx.cfg = (eps, relu, count, world, group)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, b, mean, var = ctx.saved_tensors
+        eps, relu, count, world, group = ctx.cfg
+        dy = dy.contiguous()
+        R, C = x.shape
+        s = torch.empty(2, C, device=x.device, dtype=torch.float32)
+        call('mvf_bn_bwd_reduce', ptr(dy), ptr(x), ptr(mean), ptr(var), ptr(g), ptr(b), s[0].data_ptr(),
+             s[1].data_ptr(), R, C, eps, int(relu), stream())
+        dgamma, dbeta = s[1].clone(), s[0].clone()   # local sums, like torch SyncBatchNorm
+        if world > 1:
+            dist.all_reduce(s, group=group)          # collective C3 of SURVEY.md
+        dx = torch.empty_like(x)
+        call('mvf_bn_bwd_apply', ptr(dy), ptr(x), ptr(mean), ptr(var), ptr(g), ptr(b), s[0].data_ptr(),
+             s[1].data_ptr(), ptr(dx), R, C, eps, int(relu), count, stream())
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+class _BatchNormEval(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, b, mean, var, eps, relu):
+        x = x.contiguous()
+        R, C = x.shape
+        y = torch.empty_like(x)
+        call('mvf_bn_fwd', ptr(x), ptr(mean), ptr(var), ptr(g), ptr(b), ptr(y), R, C, eps, int(relu), stream())
+        ctx.save_for_backward(x, g, b, mean, var)
+        ctx.cfg = (eps, relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, b, mean, var = ctx.saved_tensors
+        eps, relu = ctx.cfg
+        dy = dy.contiguous()
+        R, C = x.shape
+        s = torch.empty(2, C, device=x.device, dtype=torch.float32)
+        call('mvf_bn_bwd_reduce', ptr(dy), ptr(x), ptr(mean), ptr(var), ptr(g), ptr(b), s[0].data_ptr(),
+             s[1].data_ptr(), R, C, eps, int(relu), stream())
+        dx = torch.empty_like(x)
+        call('mvf_bn_bwd_apply', ptr(dy), ptr(x), ptr(mean), ptr(var), ptr(g), ptr(b), s[0].data_ptr(),
+             s[1].data_ptr(), ptr(dx), R, C, eps, int(relu), 0.0, stream())
+        return dx, s[1], s[0], None, None, None, None
+
+
+def batch_norm(x, g, b, running_mean, running_var, training, momentum=0.1, eps=1e-5, relu=False, sync=False,
+               group=None):
+    if training:
+        return _BatchNormTrain.apply(x, g, b, running_mean, running_var, momentum, eps, relu, sync, group)
+    return _BatchNormEval.apply(x, g, b, running_mean, running_var, eps, relu)
+
+
+# ------------------------------------------------------------------------------------------------
+# Temporal multi-head self-attention core
+# ------------------------------------------------------------------------------------------------
+class _TemporalAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, mask, B, S, H):
+        qkv = qkv.contiguous()
+        Dm = qkv.shape[1] // 3
+        o = torch.empty(B * S, Dm, device=qkv.device, dtype=torch.float32)
+        lse = torch.empty(B, H, S, device=qkv.device, dtype=torch.float32)
+        if mask is not None:
+            mask = mask.reshape(B, S).contiguous().float()
+        call('mvf_tattn_fwd', ptr(qkv), ptr(mask), ptr(o), ptr(lse), B, S, H, Dm, stream())
+        ctx.save_for_backward(qkv, mask, o, lse)
+        ctx.dims = (B, S, H, Dm)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        qkv, mask, o, lse = ctx.saved_tensors
+        B, S, H, Dm = ctx.dims
+        d_o = d_o.contiguous()
+        dqkv = torch.empty_like(qkv)
+        call('mvf_tattn_bwd', ptr(qkv), ptr(mask), ptr(o), ptr(lse), ptr(d_o), ptr(dqkv), B, S, H, Dm, stream())
+        return dqkv, None, None, None, None
+
+
+def temporal_attention(qkv, mask, B, S, H):
+    """qkv [B*S, 3*Dm] (q | k | v column blocks, heads contiguous inside) -> [B*S, Dm]; mask [B,S] (0 = masked key)."""
+    return _TemporalAttention.apply(qkv, mask, B, S, H)
+
+
+# ------------------------------------------------------------------------------------------------
+# small row ops
+# ------------------------------------------------------------------------------------------------
+class _ConcatOneHot(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ntok, div):
+        x = x.contiguous()
+        R, cin = x.shape
+        out = torch.empty(R, cin + ntok, device=x.device, dtype=torch.float32)
+        call('mvf_concat_onehot', ptr(x), ptr(out), R, cin, ntok, div, stream())
+        ctx.cin = cin
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return dout[:, :ctx.cin], None, None
+
+
+def concat_onehot(x, ntok, div):
+    """[R, C] -> [R, C + ntok] with one-hot of entity id (row // div) % ntok appended."""
+    return _ConcatOneHot.apply(x, ntok, div)
+
+
+_REDUCE_MODES = {'one': 0, 'avg': 1, 'max': 2}
+
+
+class _FinalReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode):
+        x = x.contiguous()
+        B, ntok, T, D = x.shape
+        y = torch.empty(B, T, D, device=x.device, dtype=torch.float32)
+        arg = torch.empty(B, T, D, device=x.device, dtype=torch.int32) if mode == 2 else None
+        call('mvf_final_reduce_fwd', ptr(x), ptr(y), ptr(arg), B, ntok, T, D, mode, stream())
+        ctx.save_for_backward(arg)
+        ctx.cfg = (B, ntok, T, D, mode)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        B, ntok, T, D, mode = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty(B, ntok, T, D, device=dy.device, dtype=torch.float32)
+        call('mvf_final_reduce_bwd', ptr(dy), ptr(arg), ptr(dx), B, ntok, T, D, mode, stream())
+        return dx, None
+
+
+def final_reduce(x, mode):
+    """x [B, ntok, T, D] -> [B, T, D]; mode in {'one','avg','max'} (SMART_FINAL)."""
+    return _FinalReduce.apply(x, _REDUCE_MODES[mode])
+
+
+class _L2Norm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = x.contiguous()
+        R, D = x.shape
+        y = torch.empty_like(x)
+        nrm = torch.empty(R, device=x.device, dtype=torch.float32)
+        call('mvf_l2norm_fwd', ptr(x), ptr(y), ptr(nrm), R, D, eps, stream())
+        ctx.save_for_backward(y, nrm)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, nrm = ctx.saved_tensors
+        dy = dy.contiguous()
+        R, D = y.shape
+        dx = torch.empty_like(y)
+        call('mvf_l2norm_bwd', ptr(dy), ptr(y), ptr(nrm), ptr(dx), R, D, ctx.eps, stream())
+        return dx, None
+
+
+def l2_normalize(x, eps=1e-12):
+    shp = x.shape
+    return _L2Norm.apply(x.reshape(-1, shp[-1]), eps).view(shp)
+
+
+class _DropoutAdd(torch.autograd.Function):
+    """y = resid + dropout_p(x); the mask is a pure function of (seed, offset, index) and is regenerated in backward."""
+
+    @staticmethod
+    def forward(ctx, x, resid, p, seed, offset):
+        x = x.contiguous()
+        if resid is not None:
+            resid = resid.contiguous()
+        y = torch.empty_like(x)
+        call('mvf_dropout_add', ptr(x), ptr(resid), ptr(y), x.numel(), p, seed, offset, stream())
+        ctx.cfg = (p, seed, offset, resid is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, offset, has_resid = ctx.cfg
+        dy = dy.contiguous()
+        dx = dy
+        if p > 0.0:
+            dx = torch.empty_like(dy)
+            call('mvf_dropout_add', ptr(dy), None, ptr(dx), dy.numel(), p, seed, offset, stream())
+        return dx, (dy if has_resid else None), None, None, None
+
+
+class DropoutState:
+    """Seed + running offset of the counter-based dropout masks (one per model; advanced per call)."""
+
+    def __init__(self, seed=0):
+        self.seed = int(seed) & 0x7FFFFFFFFFFFFFFF
+        self.offset = 0
+
+    def next(self, n):
+        o = self.offset
+        self.offset += n
+        return self.seed, o
+
+
+def dropout_add(x, resid, p, training, state):
+    """resid + dropout(x) (resid may be None).  With p == 0 or eval and no residual this is the identity."""
+    p = float(p) if training else 0.0
+    if resid is None and p == 0.0:
+        return x
+    seed, off = state.next(x.numel()) if p > 0.0 else (0, 0)
+    return _DropoutAdd.apply(x, resid, p, seed, off)
+
+
+# ------------------------------------------------------------------------------------------------
+# LSTP pooling core over the backbone taps
+# ------------------------------------------------------------------------------------------------
+def _tap_table(taps):
+    arr = (ctypes.c_void_p * len(taps))(*[ptr(t) for t in taps])
+    return arr
+
+
+class _LSTPPool(torch.autograd.Function):
+    """pooled[b, j, t, :] = sum_n softmax_n(x[f,n,:] . vec[j,:] / sqrt(d))[n] * x[f,n,:]   (f = b*T + t).
+    `vec` is [nq, C] (static queries) or [Bc, nq, T, C] (per-frame / dynamic queries)."""
+
+    @staticmethod
+    def forward(ctx, vec, taps, F, N, T, nq, inv_sqrt_d, disjoint, holder):
+        dt = BF16 if taps[0].dtype == torch.bfloat16 else F32
+        D = taps[0].shape[1]
+        C = D * len(taps)
+        dev = taps[0].device
+        vec = vec.contiguous()
+        per_frame = vec.dim() == 4
+        tab = _tap_table(taps)
+        scores = torch.empty(F * N, nq, device=dev, dtype=torch.float32)
+        call('mvf_lstp_scores', tab, len(taps), dt, D, F, N, T, nq, ptr(vec), int(per_frame), ptr(scores), stream())
+        P = torch.empty(F, nq, N, device=dev, dtype=torch.float32)
+        Pm = torch.empty_like(P) if disjoint else None
+        rowsum = torch.empty(F, nq, device=dev, dtype=torch.float32) if disjoint else None
+        call('mvf_lstp_softmax_fwd', ptr(scores), ptr(P), ptr(Pm), ptr(rowsum), F, N, nq, inv_sqrt_d, int(disjoint),
+             stream())
+        pooled = torch.empty(F // T, nq, T, C, device=dev, dtype=torch.float32)
+        call('mvf_lstp_wsum', tab, len(taps), dt, D, F, N, T, nq, ptr(Pm if disjoint else P), ptr(pooled), stream())
+        ctx.taps = taps
+        ctx.save_for_backward(P, Pm)
+        ctx.cfg = (F, N, T, nq, inv_sqrt_d, per_frame, dt, D, C)
+        if holder is not None:
+            holder['attn'] = Pm if disjoint else P
+            holder['rowsum'] = rowsum
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        P, Pm = ctx.saved_tensors
+        F, N, T, nq, inv_sqrt_d, per_frame, dt, D, C = ctx.cfg
+        taps = ctx.taps
+        tab = _tap_table(taps)
+        dev = dpooled.device
+        dpooled = dpooled.contiguous()
+        dP = torch.empty(F * N, nq, device=dev, dtype=torch.float32)
+        call('mvf_lstp_scores', tab, len(taps), dt, D, F, N, T, nq, ptr(dpooled), 1, ptr(dP), stream())
+        dS = torch.empty(F, nq, N, device=dev, dtype=torch.float32)
+        call('mvf_lstp_softmax_bwd', ptr(P), ptr(Pm), ptr(dP), None, ptr(dS), F, N, nq, inv_sqrt_d, stream())
+        G = torch.empty(F // T, nq, T, C, device=dev, dtype=torch.float32)
+        call('mvf_lstp_wsum', tab, len(taps), dt, D, F, N, T, nq, ptr(dS), ptr(G), stream())
+        if per_frame:
+            dvec = G
+        else:
+            dvec = torch.empty(nq, C, device=dev, dtype=torch.float32)
+            call('mvf_lstp_reduce_frames', ptr(G), ptr(dvec), F // T, nq, T, C, stream())
+        return dvec, None, None, None, None, None, None, None, None
+
+
+def lstp_pool(vec, taps, F, N, T, nq, d_model, disjoint=False, holder=None):
+    return _LSTPPool.apply(vec, tuple(taps), F, N, T, nq, 1.0 / math.sqrt(d_model), disjoint, holder)
+
+
+# ------------------------------------------------------------------------------------------------
+# SCL loss
+# ------------------------------------------------------------------------------------------------
+class _SCLLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, step, length, mask, T, flags, tau, var, row0, rows, grad_scale):
+        emb = emb.contiguous()
+        M, E = emb.shape
+        dev = emb.device
+        st = torch.empty(4, M, device=dev, dtype=torch.float32)  # S, R, c, lossrow
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        call('mvf_scl_fwd', ptr(emb), ptr(step), ptr(length), ptr(mask), st[0].data_ptr(), st[1].data_ptr(),
+             st[2].data_ptr(), st[3].data_ptr(), ptr(loss), M, E, T, flags, tau, var, stream())
+        ctx.save_for_backward(emb, step, length, mask, st)
+        ctx.cfg = (T, flags, tau, var, row0, rows, grad_scale)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        emb, step, length, mask, st = ctx.saved_tensors
+        T, flags, tau, var, row0, rows, grad_scale = ctx.cfg
+        M, E = emb.shape
+        g = (gout * grad_scale).reshape(1).contiguous().float()
+        dE = torch.zeros(M, E, device=emb.device, dtype=torch.float32) if rows != M else \
+            torch.empty(M, E, device=emb.device, dtype=torch.float32)
+        call('mvf_scl_bwd', ptr(emb), ptr(step), ptr(length), ptr(mask), st[0].data_ptr(), st[1].data_ptr(),
+             st[2].data_ptr(), ptr(g), dE[row0:row0 + rows].data_ptr(), M, E, T, row0, rows, flags, tau, var, stream())
+        return dE, None, None, None, None, None, None, None, None, None, None
+
+
+def scl_loss(emb, steps, seq_lens, masks, num_frames, negative_type, temperature, label_variance, row0=0, rows=None,
+             grad_scale=1.0):
+    """emb [M, E] rows ordered (video, view, frame); steps/seq_lens/masks per row [M].  `row0/rows`: only these
+    rows receive a gradient (local slice of cross-GPU gathered embeddings)."""
+    M = emb.shape[0]
+    flags = (1 if 'single' in negative_type else 0) | (2 if 'noself' in negative_type else 0)
+    return _SCLLoss.apply(emb, steps.reshape(-1).float().contiguous(), seq_lens.reshape(-1).float().contiguous(),
+                          masks.reshape(-1).float().contiguous(), num_frames, flags, float(temperature),
+                          float(label_variance), row0, M if rows is None else rows, grad_scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# frozen ViT backbone
+# ------------------------------------------------------------------------------------------------
+class PackedViT:
+    """Device-resident, dtype-converted copy of a ViT's weights in the layout mvf_vit_fwd wants, plus the
+    pointer tables of `struct MvfVitWeights`.  Built once per (module version, dtype): the backbone is frozen."""
+
+    def __init__(self, sd, depth, dim, heads, patch, img, taps, dtype, ln_eps=1e-6):
+        self.code, self.tdtype = _dt(dtype)
+        dev = sd['cls_token'].device
+        if dev.type != 'cuda':
+            raise _lib.MvfError('PackedViT needs CUDA(HIP) tensors (no CPU fallback)')
+        self.keep = []
+        self.depth, self.dim, self.heads, self.patch, self.img = depth, dim, heads, patch, img
+        self.taps = list(taps)
+
+        def f32(t):
+            t = t.detach().float().contiguous()
+            self.keep.append(t)
+            return t.data_ptr()
+
+        def mat(t):
+            t = t.detach().float().contiguous()
+            if self.code == BF16:
+                o = torch.empty(t.shape, device=dev, dtype=torch.bfloat16)
+                call('mvf_cast_f32_bf16', t.data_ptr(), o.data_ptr(), t.numel(), stream())
+                t = o
+            self.keep.append(t)
+            return t.data_ptr()
+
+        w = _lib.MvfVitWeights()
+        w.depth, w.dim, w.heads, w.patch, w.img, w.n_taps = depth, dim, heads, patch, img, len(self.taps)
+        for i, t in enumerate(self.taps):
+            w.taps[i] = t
+        w.ln_eps = ln_eps
+        w.cls_token = f32(sd['cls_token'].reshape(-1))
+        w.pos_embed = f32(sd['pos_embed'].reshape(-1, dim))
+        w.patch_w = mat(sd['patch_embed.proj.weight'].reshape(dim, -1))
+        w.patch_b = f32(sd['patch_embed.proj.bias'])
+        w.norm_w, w.norm_b = f32(sd['norm.weight']), f32(sd['norm.bias'])
+
+        def table(fmt, conv):
+            arr = (ctypes.c_void_p * depth)(*[conv(sd[fmt % i]) for i in range(depth)])
+            self.keep.append(arr)
+            return ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p))
+        w.ln1_w, w.ln1_b = table('blocks.%d.norm1.weight', f32), table('blocks.%d.norm1.bias', f32)
+        w.qkv_w, w.qkv_b = table('blocks.%d.attn.qkv.weight', mat), table('blocks.%d.attn.qkv.bias', f32)
+        w.proj_w, w.proj_b = table('blocks.%d.attn.proj.weight', mat), table('blocks.%d.attn.proj.bias', f32)
+        w.ln2_w, w.ln2_b = table('blocks.%d.norm2.weight', f32), table('blocks.%d.norm2.bias', f32)
+        w.fc1_w, w.fc1_b = table('blocks.%d.mlp.fc1.weight', mat), table('blocks.%d.mlp.fc1.bias', f32)
+        w.fc2_w, w.fc2_b = table('blocks.%d.mlp.fc2.weight', mat), table('blocks.%d.mlp.fc2.bias', f32)
+        if 'blocks.0.ls1.gamma' in sd:
+            w.ls1, w.ls2 = table('blocks.%d.ls1.gamma', f32), table('blocks.%d.ls2.gamma', f32)
+        self.struct = w
+        self.ws = None
+        self.ws_key = None
+
+    def workspace(self, fc, device):
+        tokens = (self.img // self.patch) ** 2 + 1
+        key = (fc, tokens)
+        if self.ws_key != key:
+            nbytes = _lib.load().mvf_vit_workspace_bytes(self.code, fc, tokens, self.dim, self.patch)
+            self.ws = torch.empty(nbytes, device=device, dtype=torch.uint8)
+            self.ws_key = key
+        return self.ws
+
+
+def vit_forward(frames, packed, frames_per_chunk=0, want_cls=True, attn_variant=0):
+    """frames [F,3,H,W] fp32 -> (taps: list of [F*(N-1), dim] tensors in packed.tdtype, cls [F, dim] fp32 | None)."""
+    if not frames.is_cuda:
+        raise _lib.MvfError('vit_forward received a %s tensor (no CPU fallback)' % frames.device)
+    frames = frames.contiguous().float()
+    F = frames.shape[0]
+    assert frames.shape[1:] == (3, packed.img, packed.img), frames.shape
+    np_ = (packed.img // packed.patch) ** 2
+    fc = F if frames_per_chunk <= 0 else min(frames_per_chunk, F)
+    ws = packed.workspace(fc, frames.device)
+    taps = [torch.empty(F * np_, packed.dim, device=frames.device, dtype=packed.tdtype) for _ in packed.taps]
+    cls = torch.empty(F, packed.dim, device=frames.device, dtype=torch.float32) if want_cls else None
+    tab = (ctypes.c_void_p * max(len(taps), 1))(*[t.data_ptr() for t in taps])
+    call('mvf_vit_fwd', ctypes.byref(packed.struct), packed.code, ptr(frames), F, tab, ptr(cls), ptr(ws), ws.numel(),
+         fc, attn_variant, stream())
+    return taps, cls
+
+
+# ------------------------------------------------------------------------------------------------
+# optimiser
+# ------------------------------------------------------------------------------------------------
+def grad_norm(flat_grad, scratch, out, extra_sq=None):
+    call('mvf_grad_norm', ptr(flat_grad), flat_grad.numel(), ptr(extra_sq), ptr(scratch), ptr(out), stream())
+    return out
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, clip=0.0, norm=None, gscale=1.0):
+    call('mvf_adam_step', ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step, clip,
+         ptr(norm), gscale, stream())

@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: full MV-Former SCL training steps (frozen ViT-B/16 forward + head forward/backward + SCL loss +
+gradient all-reduce + clip + Adam) on synthetic clips of BASELINE.json configs[1]:
+PennAction MV-Former, ViT-B/16, 32 frames, batch 4 per GPU (8 clips/GPU/step), bf16 backbone.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Rank 0 prints ONE JSON line.  `value` = clips/s over all N GPUs with the inputs already resident in HBM.
+`roofline` = the dominant kernel (bf16 MFMA GEMM of the backbone), timed per launch with HIP events on the launch
+stream during extra profiled steps right after the timed region.  `cpu_baseline` = the CPU oracle (a port of the
+reference's algorithm; the reference itself cannot run on CPU) on a bounded sample, rank 0, N=1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md (no 2:1 sparsity)
+TFLOP_PER_CLIP = 1.1925       # algorithmic work of config #2 per clip (fwd backbone + f/b head)
+EPI_NAMES = {0: 'gemm_tc<bf16,STORE> (qkv)', 1: 'gemm_tc<bf16,GELU> (fc1)', 2: 'gemm_tc<bf16,RESID> (proj+fc2)',
+             3: 'gemm_tc<bf16,PATCH> (patch-embed)'}
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=30)
+    p.add_argument('--warmup', type=int, default=5)
+    p.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--profile-steps', type=int, default=3)
+    return p.parse_args()
+
+
+def cpu_baseline(cfg, model):
+    """Oracle train step on a bounded sample: ONE video (2 clips x T frames) of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    from oracle import model as OM
+    import test_gpu_model as T
+    vit_cfg, head_cfg, scl_cfg = T.oracle_cfgs(cfg)
+    params = T.cpu_params(model)
+    t, s = cfg.TRAIN.NUM_FRAMES, cfg.IMAGE_SIZE
+    g = torch.Generator().manual_seed(1234)
+    batch = (torch.randn(1, 2, t, 3, s, s, generator=g), torch.full((1, 2), 100, dtype=torch.long),
+             torch.sort(torch.randint(0, 100, (1, 2, t), generator=g), dim=-1)[0], torch.ones(1, 2, t))
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    t0 = time.time()
+    OM.train_step(batch, params, {}, vit_cfg, head_cfg, scl_cfg)
+    dt = time.time() - t0
+    return {'value': round(2.0 / dt, 4), 'unit': 'clips/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '1 oracle train step on 1 video = 2 clips x %d frames (1/4 of one GPU batch), fp32, %.1f s' % (t, dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', init_method='env://', world_size=world, rank=rank)
+
+    from video_rep_learning_amd import _lib
+    from video_rep_learning_amd.utils import presets
+    from video_rep_learning_amd.utils.optimizer import construct_optimizer
+    from video_rep_learning_amd.models import build_model
+    from video_rep_learning_amd.algos import get_algo
+    from video_rep_learning_amd.train import DataParallelModel
+    from video_rep_learning_amd.datasets import synthetic
+
+    cfg = presets.baseline_config_2(compute_dtype=a.dtype)     # penn_mvf.yml + ViT-B/16, T=32, B=4 (dropout 0.1 kept)
+    torch.manual_seed(cfg.RNG_SEED)
+    model = build_model(cfg, local).to(dev)
+    if world > 1:
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    wrapped = DataParallelModel(model)
+    opt = construct_optimizer(wrapped, cfg)
+    algo = get_algo(cfg)
+    loader = synthetic.SyntheticClips(cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.NUM_FRAMES, cfg.IMAGE_SIZE, iters=1, seed=1234 + rank,
+                                      device=dev, resident=True)
+    (v0, v1), _lab, seq_lens, steps, masks, _n = next(iter(loader))
+    videos = torch.stack([v0, v1], dim=1)                     # [B, 2, T, 3, H, W], resident in HBM
+    seq_lens, steps, masks = seq_lens.to(dev), steps.to(dev), masks.to(dev)
+    model.train()
+    clip = cfg.OPTIMIZER.GRAD_CLIP
+
+    def step():
+        opt.zero_grad()
+        loss = algo.compute_loss(wrapped, videos, seq_lens, steps, masks)['loss']
+        loss.backward()
+        opt.step(max_norm=clip)
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+    last_loss = float(loss.item())
+
+    # ---- roofline of the dominant kernel: per-launch HIP-event timing during extra (untimed) steps ----
+    roof = None
+    if rank == 0:
+        _lib.call('mvf_prof_enable', 1)
+        for _ in range(max(a.profile_steps, 1)):
+            step()
+        torch.cuda.synchronize()
+        _lib.call('mvf_prof_enable', 0)
+        ms, fl, cnt = (ctypes.c_double * 4)(), (ctypes.c_double * 4)(), (ctypes.c_int * 4)()
+        _lib.call('mvf_prof_collect', ms, fl, cnt)
+        dom = max(range(4), key=lambda e: ms[e])
+        ach = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
+        tot_ms, tot_fl = sum(ms), sum(fl)
+        roof = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS if a.dtype == 'bf16' else 157.3,
+                'unit': 'TFLOP/s', 'frac': round(ach / (PEAK_BF16_TFLOPS if a.dtype == 'bf16' else 157.3), 4), 'traffic': None,
+                'kernel': EPI_NAMES[dom], 'launches': cnt[dom], 'avg_launch_us': round(ms[dom] * 1e3 / max(cnt[dom], 1), 1),
+                'flop_per_launch': fl[dom] / max(cnt[dom], 1),
+                'all_gemm': {'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 1), 'ms_per_step': round(tot_ms / max(a.profile_steps, 1), 3)},
+                'by_kernel': {EPI_NAMES[e]: {'launches': cnt[e], 'avg_us': round(ms[e] * 1e3 / max(cnt[e], 1), 1),
+                                             'tflops': round(fl[e] / (ms[e] * 1e-3) / 1e12, 1) if ms[e] > 0 else 0.0} for e in range(4)}}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        clips = world * cfg.TRAIN.BATCH_SIZE * 2 * a.steps
+        value = clips / dt
+        out = {
+            'metric': 'video-clips/sec/node, ViT-B/16 32-frame MV-Former', 'value': round(value, 2), 'unit': 'clips/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: PennAction MV-Former (penn_mvf.yml + ViT-B/16), 32 frames, '
+                                   'batch 4/GPU = 8 clips/GPU/step, full train step (frozen backbone fwd, head fwd+bwd, SCL, '
+                                   'grad all-reduce, clip+Adam), dropout 0.1', 'global_batch': 4 * world, 'frames': 32,
+                       'parallelism': 'dp%d' % world, 'frames_per_sec': round(value * 32, 1), 'samples_per_sec': round(value / 2, 2),
+                       'step_tflops_algorithmic': round(value / world * TFLOP_PER_CLIP, 1), 'last_loss': round(last_loss, 4)},
+            'roofline': roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out['cpu_baseline'] = cpu_baseline(cfg, model)
+            except Exception as e:  # the baseline must never sink the measurement
+                out['cpu_baseline'] = {'value': None, 'unit': 'clips/s', 'cores': os.cpu_count(), 'kind': 'port',
+                                       'sample': 'failed: %r' % (e,)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

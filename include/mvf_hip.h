@@ -65,6 +65,12 @@ size_t mvf_vit_workspace_bytes(int dtype, int frames_per_chunk, int tokens, int 
 int mvf_vit_fwd(const MvfVitWeights* w, int dtype, const float* frames, int F, void* const* taps_out, float* cls_out,
                 void* workspace, size_t ws_bytes, int frames_per_chunk, int attn_variant, hipStream_t stream);
 
+/* measurement hooks (bench.py roofline): when enabled, every GEMM launch of mvf_vit_fwd is bracketed by HIP events
+ * on the launch stream; collect() waits for them and returns, per epilogue kind 0..3, the summed device
+ * milliseconds, the summed algorithmic FLOPs (2*M*N*K) and the launch count.  Not for use under graph capture. */
+int mvf_prof_enable(int on);
+int mvf_prof_collect(double* ms_host, double* flops_host, int* count_host);
+
 /* pieces of the same path, exported for unit parity tests */
 int mvf_gemm_tc(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
                 float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tokens_per_frame, int M,

@@ -1,0 +1,204 @@
+"""GPU parity, model level: TransformerModel.forward, SCL.compute_loss (loss + parameter gradients) and three
+optimisation steps of the HIP path against the CPU oracle on identical seeded weights/inputs.  North-star gate:
+per-frame embeddings and SCL loss within 1e-3 relative in fp32; the bf16 path reports its own error."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from video_rep_learning_amd.utils import presets  # noqa: E402
+from video_rep_learning_amd.utils.optimizer import construct_optimizer  # noqa: E402
+from video_rep_learning_amd.models import build_model  # noqa: E402
+from video_rep_learning_amd.models.vit import VIT_ZOO  # noqa: E402
+from video_rep_learning_amd.algos import get_algo  # noqa: E402
+from video_rep_learning_amd.train import DataParallelModel  # noqa: E402
+from oracle import head as OH  # noqa: E402
+from oracle import model as OM  # noqa: E402
+
+DEV = 'cuda'
+
+
+def relerr(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def oracle_cfgs(cfg):
+    em = cfg.MODEL.EMBEDDER_MODEL
+    name = cfg.MODEL.BASE_MODEL.NETWORK[5:]
+    dim, depth, heads, patch, _ = VIT_ZOO[name]
+    taps = tuple(int(t) for t in str(em.SMART_FEATS).split(','))
+    vit_cfg = dict(heads=heads, patch=patch, taps=taps)
+    head_cfg = OH.HeadCfg(nst=em.SMART_TOKENS, nsdt=em.get('SMART_DYNAMIC_TOKENS', 0), spc=em.get('SMART_POOL_CHANNELS', 384),
+                          one_hot=em.get('SMART_ONE_HOT', 'none'), smart_final=em.get('SMART_FINAL', 'max'),
+                          num_heads=em.NUM_HEADS, num_layers=em.NUM_LAYERS, train_len=cfg.TRAIN.NUM_FRAMES,
+                          dyn_ctrl=em.get('DYNAMIC_CTRL', 'separate'), disjoint=bool(em.get('SMART_DISJOINT', False)),
+                          val_pass=bool(em.get('VAL_PASS', False)), n_taps=len(taps))
+    scl_cfg = dict(negative_type=cfg.SCL.NEGATIVE_TYPE, temperature=cfg.SCL.SOFTMAX_TEMPERATURE,
+                   label_variance=cfg.SCL.LABEL_VARIENCE)
+    return vit_cfg, head_cfg, scl_cfg
+
+
+def make(seed=0, **kw):
+    cfg = presets.make_cfg(**kw)
+    torch.manual_seed(seed)
+    model = build_model(cfg, 0)
+    # de-trivialise: timm-style init leaves LN at identity and biases at 0; jitter everything a little
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.startswith('backbone') and p.dim() > 1:
+                p.mul_(3.0)
+            elif p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    return cfg, model.to(DEV)
+
+
+def batch(cfg, seed, pad=0):
+    g = torch.Generator().manual_seed(seed)
+    b, t, s = cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.NUM_FRAMES, cfg.IMAGE_SIZE
+    videos = torch.randn(b, 2, t, 3, s, s, generator=g)
+    seq_lens = torch.full((b, 2), 100, dtype=torch.long)
+    steps = torch.sort(torch.randint(0, 100, (b, 2, t), generator=g), dim=-1)[0]
+    masks = torch.ones(b, 2, t)
+    if pad:
+        L = t - pad
+        seq_lens[0] = L
+        steps[0] = torch.arange(t).clamp(max=L - 1)
+        masks[0, :, L:] = 0
+    return videos, seq_lens, steps, masks
+
+
+def cpu_params(model, dtype=torch.float32):
+    return {k: (v.detach().cpu().to(dtype) if v.dtype.is_floating_point else v.detach().cpu().clone())
+            for k, v in model.state_dict().items()}
+
+
+SMALL = dict(network='TIMM-vit_small_patch16_224.dino', num_frames=8, batch_size=2, image_size=32, compute_dtype='fp32',
+             dropout=0.0)
+
+
+@pytest.mark.parametrize('variant', ['base', 'avg_enc_nst6', 'max_none', 'lin', 'dynamic', 'disjoint', 'batch_neg'])
+def test_small_model_loss_and_grads(variant):
+    kw = dict(SMALL)
+    if variant == 'avg_enc_nst6':
+        kw.update(SMART_FINAL='avg', SMART_ONE_HOT='enc', SMART_TOKENS=6)
+    elif variant == 'max_none':
+        kw.update(SMART_FINAL='max', SMART_ONE_HOT='none')
+    elif variant == 'lin':
+        kw.update(SMART_FINAL='lin')
+    elif variant == 'dynamic':
+        kw.update(SMART_DYNAMIC_TOKENS=2, DYNAMIC_CTRL='average')
+    elif variant == 'disjoint':
+        kw.update(SMART_DISJOINT=True)
+    cfg, model = make(3, **kw)
+    if variant == 'batch_neg':
+        cfg.SCL.NEGATIVE_TYPE = 'batch_noself'
+    vit_cfg, head_cfg, scl_cfg = oracle_cfgs(cfg)
+    videos, seq_lens, steps, masks = batch(cfg, 5, pad=3)
+    # ---- eval embeddings (project=False): the "per-frame embeddings" of the north star
+    model.eval()
+    b, t = cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.NUM_FRAMES
+    with torch.no_grad():
+        emb = model(videos.view(b * 2, t, *videos.shape[3:]).to(DEV), t, video_masks=masks.view(b * 2, 1, t).to(DEV))
+    ref = OM.model_forward(videos.view(b * 2, t, *videos.shape[3:]), cpu_params(model), vit_cfg, head_cfg,
+                           masks.view(b * 2, 1, t), project=False, training=False)
+    e = relerr(emb, ref)
+    assert e <= 1e-3, 'eval embeddings: %.3e' % e
+    # ---- train loss + gradients
+    model.train()
+    algo = get_algo(cfg)
+    p64 = cpu_params(model, torch.float64)
+    leaves = {k: p64[k].requires_grad_(True) for k in OM.trainable_names(p64)}
+    lref = OM.compute_loss(videos.double(), seq_lens, steps, masks, p64, vit_cfg, head_cfg, scl_cfg, training=True,
+                           update_running=True)
+    lref.backward()
+    loss = algo.compute_loss(model, videos.to(DEV), seq_lens, steps, masks)['loss']
+    loss.backward()
+    e = relerr(loss, lref)
+    assert e <= 1e-3, 'loss %.3e (%.6f vs %.6f)' % (e, loss.item(), lref.item())
+    gscale = max(v.grad.abs().max().item() for v in leaves.values() if v.grad is not None)
+    worst = ('', 0.0)
+    for n, p in model.named_parameters():
+        if n not in leaves:
+            continue
+        gref = leaves[n].grad if leaves[n].grad is not None else torch.zeros_like(leaves[n])
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        err = (got.double().cpu() - gref).abs().max().item()
+        # relative to the tensor's own scale, with a floor at 1e-4 of the global gradient scale (exact-zero grads)
+        rel = err / max(gref.abs().max().item(), 1e-4 * gscale)
+        if rel > worst[1]:
+            worst = (n, rel)
+    assert worst[1] <= 5e-3, 'gradient mismatch: %s rel %.3e' % worst
+    # BN running statistics were updated like torch does
+    sd = model.state_dict()
+    for k in p64:
+        if 'running_' in k and not k.startswith('backbone'):
+            assert relerr(sd[k], p64[k]) <= 1e-4, k
+
+
+def test_full_size_vitb16_fp32_and_bf16():
+    kw = dict(network='TIMM-vit_base_patch16_224.dino', num_frames=4, batch_size=1, image_size=224, dropout=0.0)
+    cfg, model = make(7, compute_dtype='fp32', **kw)
+    vit_cfg, head_cfg, scl_cfg = oracle_cfgs(cfg)
+    videos, seq_lens, steps, masks = batch(cfg, 8)
+    model.eval()
+    x = videos.view(2, 4, 3, 224, 224)
+    ref = OM.model_forward(x, cpu_params(model), vit_cfg, head_cfg, masks.view(2, 1, 4), project=False, training=False)
+    with torch.no_grad():
+        emb = model(x.to(DEV), 4, video_masks=masks.view(2, 1, 4).to(DEV))
+    e = relerr(emb, ref)
+    print('ViT-B/16 fp32 embeddings max-rel err vs oracle: %.3e' % e)
+    assert e <= 1e-3
+    model.train()
+    lref = OM.compute_loss(videos, seq_lens, steps, masks, cpu_params(model), vit_cfg, head_cfg, scl_cfg, training=True)
+    loss = get_algo(cfg).compute_loss(model, videos.to(DEV), seq_lens, steps, masks)['loss']
+    e = relerr(loss, lref)
+    print('ViT-B/16 fp32 SCL loss %.6f vs oracle %.6f (rel %.3e)' % (loss.item(), lref.item(), e))
+    assert e <= 1e-3
+    # bf16 backbone: report (not gate) its deviation from the fp32 oracle
+    model.compute_dtype = 'bf16'
+    model.eval()
+    with torch.no_grad():
+        emb16 = model(x.to(DEV), 4, video_masks=masks.view(2, 1, 4).to(DEV))
+    e16 = relerr(emb16, ref)
+    print('ViT-B/16 bf16 embeddings max-rel err vs fp32 oracle: %.3e' % e16)
+    assert e16 < 0.1
+
+
+def test_three_step_trajectory_fused_adam():
+    cfg, model = make(11, **SMALL)
+    cfg.OPTIMIZER.LR.INITIAL_LR = 1e-3
+    vit_cfg, head_cfg, scl_cfg = oracle_cfgs(cfg)
+    params = cpu_params(model)
+    wrapped = DataParallelModel(model)
+    opt = construct_optimizer(wrapped, cfg)
+    algo = get_algo(cfg)
+    model.train()
+    st = {}
+    for it in range(3):
+        b = batch(cfg, 20 + it, pad=2 if it == 1 else 0)
+        lref = OM.train_step(b, params, st, vit_cfg, head_cfg, scl_cfg, lr=1e-3, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY,
+                             grad_clip=cfg.OPTIMIZER.GRAD_CLIP)
+        opt.zero_grad()
+        loss = algo.compute_loss(wrapped, b[0].to(DEV), b[1], b[2], b[3])['loss']
+        loss.backward()
+        opt.step(max_norm=cfg.OPTIMIZER.GRAD_CLIP)
+        assert relerr(loss, lref) <= 1e-3, (it, loss.item(), lref.item())
+    # parameters with a well-conditioned gradient must track the oracle (null-gradient biases excluded, see
+    # tests/test_oracle_head.py::test_trajectory for why)
+    null = ('linear_V2d.bias', 'linear_K2d.bias', 'fc_layers.1.bias', 'fc_layers.5.bias', 'feed_forward.fc2.bias',
+            'embedding_layer.bias', 'net.0.bias', 'running_mean')
+    sd = model.state_dict()
+    for k, v in params.items():
+        if k.startswith('backbone') or not v.dtype.is_floating_point or any(k.endswith(n) for n in null):
+            continue
+        err = (sd[k].cpu() - v).abs().max().item()
+        assert err <= 2e-4 + 1e-3 * v.abs().max().item() * 0, (k, err)
+    # optimizer state dict is torch.optim.Adam-shaped
+    osd = opt.state_dict()
+    assert set(osd) == {'state', 'param_groups'} and len(osd['param_groups']) == 2
+    assert set(osd['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'}

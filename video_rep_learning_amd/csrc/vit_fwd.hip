@@ -6,6 +6,7 @@
 // reshape copies of CARL_MVF/models/transformer.py:186-214, 306-333.
 #include "common.h"
 #include "mvf_hip_internal.h"
+#include <vector>
 
 namespace {
 enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
@@ -18,6 +19,39 @@ struct Ws {
 };
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// ---- optional per-launch timing of the GEMMs with HIP events on the launch stream (bench.py roofline) ----
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> ev;   // pairs
+  std::vector<int> epi;
+  std::vector<double> flops;
+  size_t used = 0;
+} g_prof;
+
+int timed_gemm(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
+               float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tpf, int M, int N, int K,
+               hipStream_t st) {
+  const bool rec = g_prof.on && g_prof.used < 4096;
+  size_t slot = 0;
+  if (rec) {
+    slot = g_prof.used++;
+    if (g_prof.ev.size() < 2 * (slot + 1)) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return MVF_ERR_ARG;
+      g_prof.ev.push_back(a);
+      g_prof.ev.push_back(b);
+      g_prof.epi.push_back(0);
+      g_prof.flops.push_back(0.0);
+    }
+    g_prof.epi[slot] = epi;
+    g_prof.flops[slot] = 2.0 * M * (double)N * K;
+    (void)hipEventRecord(g_prof.ev[2 * slot], st);
+  }
+  const int rc = mvf_gemm_tc_impl(dtype, epi, A, lda, W, ldw, bias, C, ldc, resid, ldr, tap, ldt, pos, ls, tpf, M, N, K, st);
+  if (rec) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
+  return rc;
+}
 
 size_t carve(int dtype, int fc, int N, int D, int P, Ws* w, char* base) {
   const size_t esz = dtype == MVF_BF16 ? 2 : 4;
@@ -68,7 +102,7 @@ extern "C" int mvf_vit_fwd(const MvfVitWeights* w, int dtype, const float* frame
     const int Mc = fc * N;
     // ---- patch embed: gather patches, GEMM with bias + pos_embed fused, rows 1.. of every frame ----
     RUN(mvf_im2col_impl(dtype, frames + (size_t)f0 * 3 * img * img, ws.hid, fc, img, img, P, st));
-    RUN(mvf_gemm_tc_impl(dtype, EPI_PATCH, ws.hid, kp, w->patch_w, kp, w->patch_b, nullptr, 0, ws.x, D, nullptr, 0,
+    RUN(timed_gemm(dtype, EPI_PATCH, ws.hid, kp, w->patch_w, kp, w->patch_b, nullptr, 0, ws.x, D, nullptr, 0,
                          w->pos_embed, nullptr, N, fc * np, D, kp, st));
     RUN(mvf_cls_row_impl(ws.x, w->cls_token, w->pos_embed, fc, N, D, st));
     for (int l = 0; l < w->depth; ++l) {
@@ -76,17 +110,17 @@ extern "C" int mvf_vit_fwd(const MvfVitWeights* w, int dtype, const float* frame
       for (int j = 0; j < w->n_taps; ++j)
         if (w->taps[j] == l) tap = j;
       RUN(mvf_layernorm_impl(dtype, ws.x, D, w->ln1_w[l], w->ln1_b[l], ws.h, D, Mc, D, w->ln_eps, st));
-      RUN(mvf_gemm_tc_impl(dtype, EPI_STORE, ws.h, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0,
+      RUN(timed_gemm(dtype, EPI_STORE, ws.h, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0,
                            nullptr, nullptr, N, Mc, 3 * D, D, st));
       RUN(mvf_vit_attn_impl(dtype, ws.qkv, ws.h, fc, N, H, D, attn_variant, st));
-      RUN(mvf_gemm_tc_impl(dtype, EPI_RESID, ws.h, D, w->proj_w[l], D, w->proj_b[l], nullptr, 0, ws.x, D, nullptr, 0,
+      RUN(timed_gemm(dtype, EPI_RESID, ws.h, D, w->proj_w[l], D, w->proj_b[l], nullptr, 0, ws.x, D, nullptr, 0,
                            nullptr, w->ls1 ? w->ls1[l] : nullptr, N, Mc, D, D, st));
       RUN(mvf_layernorm_impl(dtype, ws.x, D, w->ln2_w[l], w->ln2_b[l], ws.h, D, Mc, D, w->ln_eps, st));
-      RUN(mvf_gemm_tc_impl(dtype, EPI_GELU, ws.h, D, w->fc1_w[l], D, w->fc1_b[l], ws.hid, 4 * D, nullptr, 0, nullptr, 0,
+      RUN(timed_gemm(dtype, EPI_GELU, ws.h, D, w->fc1_w[l], D, w->fc1_b[l], ws.hid, 4 * D, nullptr, 0, nullptr, 0,
                            nullptr, nullptr, N, Mc, 4 * D, D, st));
       void* tap_ptr = nullptr;
       if (tap >= 0 && taps_out && taps_out[tap]) tap_ptr = (char*)taps_out[tap] + (size_t)f0 * np * D * esz;
-      RUN(mvf_gemm_tc_impl(dtype, EPI_RESID, ws.hid, 4 * D, w->fc2_w[l], 4 * D, w->fc2_b[l], nullptr, 0, ws.x, D, tap_ptr,
+      RUN(timed_gemm(dtype, EPI_RESID, ws.hid, 4 * D, w->fc2_w[l], 4 * D, w->fc2_b[l], nullptr, 0, ws.x, D, tap_ptr,
                            D, nullptr, w->ls2 ? w->ls2[l] : nullptr, N, Mc, D, 4 * D, st));
     }
     if (cls_out)  // final LN on the CLS rows only (timm forward_head, global_pool='token')
@@ -94,6 +128,26 @@ extern "C" int mvf_vit_fwd(const MvfVitWeights* w, int dtype, const float* frame
                              w->ln_eps, st));
   }
 #undef RUN
+  return MVF_OK;
+}
+
+// ---- profiling hooks (NOT graph-capturable: mvf_prof_collect synchronises the recorded events) ----
+extern "C" int mvf_prof_enable(int on) {
+  g_prof.on = on != 0;
+  if (on) g_prof.used = 0;
+  return MVF_OK;
+}
+// per epilogue kind e in 0..3: ms[e] = summed device time, flops[e] = summed 2*M*N*K, count[e] = launches
+extern "C" int mvf_prof_collect(double* ms, double* flops, int* count) {
+  MVF_CHECK_ARG(ms && flops && count);
+  for (int e = 0; e < 4; ++e) { ms[e] = 0.0; flops[e] = 0.0; count[e] = 0; }
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return MVF_ERR_ARG;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return MVF_ERR_ARG;
+    const int e = g_prof.epi[i];
+    ms[e] += t; flops[e] += g_prof.flops[i]; count[e] += 1;
+  }
   return MVF_OK;
 }
 

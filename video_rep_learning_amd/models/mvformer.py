@@ -1,0 +1,230 @@
+"""MV-Former head: learned-query multi-entity pooling + per-entity FC stack + joint temporal transformer.
+
+Same classes, constructor logic, optional-key probing and parameter names as CARL_MVF/models/mvformer.py
+(MultiEntityTransformerEmbModel :15-200, LearnableTokenPooling :207-266, LSTPCrossAtt :275-414) -- reference
+checkpoints load with load_state_dict -- but the forward is a chain of HIP ops and three things are laid out
+differently on purpose:
+  * input: the tapped backbone blocks arrive as separate token-major buffers [F*N, D] (`Taps`), not as one
+    channel-concatenated NCHW tensor that is then movedim'ed back (transformer.py:199-218, mvformer.py:244-246);
+  * pooling uses the streaming rewrite documented in csrc/lstp_pool.hip (no K/V projection of all tokens), all
+    clips in one launch instead of the Python loop of mvformer.py:255-264;
+  * rows are kept in (clip, entity, frame) order from the pooling output on, which is the order the temporal
+    encoder consumes, so the movedim/reshape copies of mvformer.py:154-159 disappear.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .utils import PositionalEncoder, Encoder
+
+
+class Taps:
+    """Backbone features for the head: `tensors[j]` is block taps[j]'s output, [F*N, D], CLS dropped."""
+
+    def __init__(self, tensors, n_clips, n_frames, n_tokens):
+        self.tensors = list(tensors)
+        self.n_clips, self.n_frames, self.n_tokens = n_clips, n_frames, n_tokens
+
+    @staticmethod
+    def from_nchw(x, n_taps):
+        """The reference's [B, T, C, h, w] layout (C = n_taps * D) -> Taps (copies; API-compat path only)."""
+        b, t, c, h, w = x.shape
+        d = c // n_taps
+        toks = x.reshape(b * t, c, h * w).transpose(1, 2)   # [F, N, C]
+        return Taps([toks[:, :, j * d:(j + 1) * d].reshape(b * t * h * w, d).contiguous() for j in range(n_taps)],
+                    b, t, h * w)
+
+
+def _em(cfg, key, default):
+    return cfg.MODEL.EMBEDDER_MODEL[key] if key in cfg.MODEL.EMBEDDER_MODEL else default
+
+
+class LSTPCrossAtt(nn.Module):
+    def __init__(self, cfg, num_static, num_dynamic, d_model_K, d_model_V, d_model, d_dyn_in=None, dout_p=0.0):
+        super().__init__()
+        self.cfg = cfg
+        self.d_model_K, self.d_model_V, self.d_model = d_model_K, d_model_V, d_model
+        self.pass_through = bool(_em(cfg, 'VAL_PASS', False))
+        self.disjoint_att = bool(_em(cfg, 'SMART_DISJOINT', False))
+        self.ln_keys = bool(_em(cfg, 'SMART_LN_KEYS', False))
+        self.dyn_ctrl = _em(cfg, 'DYNAMIC_CTRL', 'separate')
+        assert self.dyn_ctrl in ['separate', 'first', 'average']
+        if num_static == 0 and num_dynamic == 0:
+            print('ERROR: cannot have both num_static == 0 and num_dynamic == 0')
+            exit(-1)
+        self.linear_K2d = nn.Linear(d_model_K, d_model)
+        self.linear_V2d = nn.Identity() if self.pass_through else nn.Linear(d_model_V, d_model)
+        self.num_s, self.stat = num_static, num_static > 0
+        if self.stat:
+            self.Q_s = nn.Parameter(torch.empty([1, num_static, d_model], dtype=torch.float32))
+            nn.init.kaiming_uniform_(self.Q_s, a=math.sqrt(5))
+            self.Q_s_b = nn.Parameter(torch.empty(d_model, dtype=torch.float32))
+            fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self.Q_s)
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            nn.init.uniform_(self.Q_s_b, -bound, bound)
+        self.num_d, self.dyn = num_dynamic, num_dynamic > 0
+        if self.dyn:
+            self.d_dyn_in = d_dyn_in if d_dyn_in is not None else d_model_V
+            self.in2dynQ = nn.Linear(self.d_dyn_in, d_model * num_dynamic)
+        self.visual = True
+        self.attn_holder = nn.Identity()
+        self.attn_matrix = None
+
+    def query_vectors(self, dyn_in, n_clips, n_frames):
+        """wq = q W_K: [nq, C] for static-only queries, else [Bc, nq, T, C] (one query set per frame)."""
+        wk = self.linear_K2d.weight
+        qs = (self.Q_s + self.Q_s_b)[0] if self.stat else None            # [nst, d]
+        if not self.dyn:
+            return ops.matmul(qs, wk)
+        assert dyn_in is not None
+        d = dyn_in.view(n_clips, n_frames, -1)
+        if self.dyn_ctrl == 'first':
+            d = d[:, :1]
+        elif self.dyn_ctrl == 'average':
+            d = d.mean(1, keepdim=True)
+        qd = ops.linear(d.reshape(-1, d.shape[-1]), self.in2dynQ.weight, self.in2dynQ.bias)
+        qd = qd.view(n_clips, -1, self.num_d, self.d_model).expand(n_clips, n_frames, self.num_d, self.d_model)
+        if self.stat:
+            qd = torch.cat([qs.view(1, 1, self.num_s, self.d_model).expand(n_clips, n_frames, -1, -1), qd], 2)
+        q = qd.permute(0, 2, 1, 3).reshape(-1, self.d_model)                # rows (clip, query, frame)
+        return ops.matmul(q, wk).view(n_clips, -1, n_frames, wk.shape[1])
+
+    def forward(self, taps, dyn_in=None):
+        """-> [Bc, nq, T, d_out] rows in (clip, entity, frame) order."""
+        if self.ln_keys:
+            raise NotImplementedError('SMART_LN_KEYS (normalised projected keys) is not on the HIP path yet: it needs '
+                                      'the full key projection, which the streaming pooling kernels avoid')
+        nq = self.num_s + self.num_d
+        F = taps.n_clips * taps.n_frames
+        vec = self.query_vectors(dyn_in, taps.n_clips, taps.n_frames)
+        holder = {}
+        pooled, rowsum = ops.lstp_pool(vec, taps.tensors, F, taps.n_tokens, taps.n_frames, nq, self.d_model,
+                                       disjoint=self.disjoint_att, holder=holder)
+        if self.visual:
+            self.attn_matrix = holder['attn'].detach()                    # [F, nq, N]
+            _ = self.attn_holder(self.attn_matrix)
+        if self.pass_through:
+            return pooled
+        wv, bv = self.linear_V2d.weight, self.linear_V2d.bias
+        if not self.disjoint_att:
+            return ops.linear(pooled, wv, bv)                             # softmax rows sum to 1: plain bias
+        return ops.linear(pooled, wv, None) + rowsum.unsqueeze(-1) * bv
+
+
+class LearnableTokenPooling(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.nst = _em(cfg, 'SMART_TOKENS', 5)
+        self.nsdt = _em(cfg, 'SMART_DYNAMIC_TOKENS', 0)
+        self.spc = _em(cfg, 'SMART_POOL_CHANNELS', 384)
+        self.in_c = cfg.MODEL.BASE_MODEL.OUT_CHANNEL
+        d_dyn_in = self.in_c
+        if 'SMART_FEATS' in cfg.MODEL.EMBEDDER_MODEL:
+            sfl = str(cfg.MODEL.EMBEDDER_MODEL.SMART_FEATS)
+            if ',' in sfl:
+                d_dyn_in = int(d_dyn_in / len(sfl.split(',')))
+        self.cross_att = LSTPCrossAtt(cfg=cfg, num_static=self.nst, num_dynamic=self.nsdt, d_model_K=self.in_c,
+                                      d_model_V=self.in_c, d_model=self.spc, d_dyn_in=d_dyn_in)
+
+    def forward(self, taps, dyn_in=None):
+        return self.cross_att(taps, dyn_in if self.nsdt > 0 else None)
+
+
+class MultiEntityTransformerEmbModel(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        print('Using Smart Pooling')
+        self.cfg = cfg
+        drop_rate = cfg.MODEL.EMBEDDER_MODEL.FC_DROPOUT_RATE
+        self.drop_rate = drop_rate
+        in_channels = _em(cfg, 'SMART_POOL_CHANNELS', 384)
+        if _em(cfg, 'VAL_PASS', False):
+            in_channels = cfg.MODEL.BASE_MODEL.OUT_CHANNEL
+        self.nst = _em(cfg, 'SMART_TOKENS', 5)
+        self.nsdt = _em(cfg, 'SMART_DYNAMIC_TOKENS', 0)
+        self.one_hot_pos = _em(cfg, 'SMART_ONE_HOT', 'none')
+        assert self.one_hot_pos in ['none', 'pool', 'enc']
+        if self.one_hot_pos == 'pool':
+            in_channels += (self.nst + self.nsdt)
+        self.fwb = bool(_em(cfg, 'FIXED_WIDTH_BASELINE', False))
+        if self.fwb:
+            raise NotImplementedError('FIXED_WIDTH_BASELINE (FWBPooling ablation) is outside the MI355X hot path')
+        cap_scalar = cfg.MODEL.EMBEDDER_MODEL.CAPACITY_SCALAR
+        fc_params = _em(cfg, 'FC_LAYERS', None)
+        self.embedding_size = cfg.MODEL.EMBEDDER_MODEL.EMBEDDING_SIZE
+        hidden_channels = cfg.MODEL.EMBEDDER_MODEL.HIDDEN_SIZE
+        self.pooling = LearnableTokenPooling(cfg)
+        if fc_params is None:
+            self.fc_layers = nn.Identity()
+        else:
+            layers = []
+            for channels, _activate in fc_params:
+                channels = channels * cap_scalar
+                layers += [nn.Dropout(drop_rate), nn.Linear(in_channels, channels), nn.BatchNorm1d(channels), nn.ReLU(True)]
+                in_channels = channels
+            self.fc_layers = nn.Sequential(*layers)
+        if self.one_hot_pos == 'enc':
+            hidden_channels -= self.nst
+        self.video_emb = nn.Linear(in_channels, hidden_channels)
+        self.video_pos_enc = PositionalEncoder(cfg, hidden_channels, drop_rate, seq_len=cfg.TRAIN.NUM_FRAMES)
+        if self.one_hot_pos == 'enc':
+            hidden_channels += self.nst
+        if cfg.MODEL.EMBEDDER_MODEL.NUM_LAYERS > 0:
+            self.video_encoder = Encoder(hidden_channels, drop_rate, cfg.MODEL.EMBEDDER_MODEL.NUM_HEADS,
+                                         cfg.MODEL.EMBEDDER_MODEL.D_FF, cfg.MODEL.EMBEDDER_MODEL.NUM_LAYERS)
+        self.embedding_layer = nn.Linear(hidden_channels, self.embedding_size)
+        self.smart_final = _em(cfg, 'SMART_FINAL', 'max')
+        assert self.smart_final in ['max', 'one', 'avg', 'lin']
+        if self.smart_final == 'lin':
+            self.lin_final = nn.Linear((self.nst + self.nsdt) * hidden_channels, hidden_channels)
+        self.in_backbone_warmup = 'BACKBONE_WARMUP' in self.cfg.TRAIN
+        self.drop_state = ops.DropoutState(seed=int(cfg.RNG_SEED) if 'RNG_SEED' in cfg else 0)
+        self.sync_group = None
+
+    def set_warmup_status(self, new_status):
+        self.in_backbone_warmup = new_status
+
+    def _bn(self, x, bn, relu):
+        return ops.batch_norm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training and bn.training,
+                              momentum=bn.momentum, eps=bn.eps, relu=relu, sync=isinstance(bn, nn.SyncBatchNorm),
+                              group=self.sync_group)
+
+    def forward(self, x, video_masks=None, cls_emb=None):
+        taps = x if isinstance(x, Taps) else Taps.from_nchw(x, len(str(_em(self.cfg, 'SMART_FEATS', '11')).split(',')))
+        Bc, T = taps.n_clips, taps.n_frames
+        x = self.pooling(taps, cls_emb)                                    # [Bc, ntok, T, c]
+        ntok = x.shape[1]
+        x = x.reshape(Bc * ntok * T, -1)
+        if self.one_hot_pos == 'pool':
+            x = ops.concat_onehot(x, ntok, T)
+        if not isinstance(self.fc_layers, nn.Identity):
+            mods = list(self.fc_layers)
+            for i in range(0, len(mods), 4):
+                x = ops.dropout_add(x, None, mods[i].p, self.training, self.drop_state)
+                bn = mods[i + 2]
+                if bn.training != self.training:
+                    bn.train(self.training)
+                x = self._bn(ops.linear(x, mods[i + 1].weight, mods[i + 1].bias), bn, relu=True)
+        # video_emb GEMM with the sin/cos table added in its epilogue (row r -> frame r % T), then PE dropout
+        x = ops.linear(x, self.video_emb.weight, self.video_emb.bias, table=self.video_pos_enc.table(T, x.device),
+                       tab_div=1, tab_mod=T)
+        x = ops.dropout_add(x, None, self.video_pos_enc.dout_p, self.training, self.drop_state)
+        if self.one_hot_pos == 'enc':
+            x = ops.concat_onehot(x, ntok, T)
+        x = x.view(Bc, ntok * T, -1)
+        if self.cfg.MODEL.EMBEDDER_MODEL.NUM_LAYERS > 0:
+            vm = None
+            if video_masks is not None:
+                vm = video_masks.reshape(Bc, 1, T).expand(Bc, ntok, T).reshape(Bc, 1, ntok * T)
+            x = self.video_encoder(x, src_mask=vm, drop_state=self.drop_state)
+        x = x.view(Bc, ntok, T, -1)
+        if self.smart_final == 'lin':
+            x = x.permute(0, 2, 1, 3).reshape(Bc * T, -1)
+            x = ops.linear(x, self.lin_final.weight, self.lin_final.bias)
+        else:
+            x = ops.final_reduce(x, self.smart_final)
+        x = ops.linear(x.reshape(Bc * T, -1), self.embedding_layer.weight, self.embedding_layer.bias)
+        return x.view(Bc, T, self.embedding_size)

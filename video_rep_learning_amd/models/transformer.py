@@ -1,0 +1,118 @@
+"""TransformerModel: frozen ViT backbone -> MV-Former head -> (projection) -> L2 normalise.
+
+Same constructor contract and forward signature as CARL_MVF/models/transformer.py:16-244 for the path the
+MV-Former configs take (timm ViT backbone, fully frozen, FUSION_TYPE 'smart'); `cfg.MODEL.BASE_MODEL.OUT_CHANNEL`
+is set/multiplied exactly as transformer.py:43-54,90 does, state-dict keys are `backbone.model.*`, `embed.*`,
+`ssl_projection.*`.  The backbone runs as one C-ABI call (mvf_vit_fwd) per forward instead of per
+FRAMES_PER_BATCH chunk of T (per-frame independent, so the numbers are the same) and hands its tapped blocks to
+the head without the hook/concat/CLS-drop/movedim copies of transformer.py:199-218,322-331.
+Not on this path (raise with a clear message): ResNet-50 backbones, late fusion, partially frozen ViT
+(ViTFrontEnd/ViTBackEnd, 0 <= LAYER < depth), classification head."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from . import vit as vitlib
+from .mvformer import MultiEntityTransformerEmbModel, Taps
+from .resnet_c2d import MLPHead
+
+
+class FeatureExtractor(nn.Module):
+    """Holder that keeps the reference's key prefix `backbone.model.*` (transformer.py:306-333).  `layers` are
+    timm-style names ('blocks.3'); the taps come straight out of the HIP forward instead of forward hooks."""
+
+    def __init__(self, model, layers, return_output=True):
+        super().__init__()
+        self.model = model
+        self.layers = list(layers)
+        self.tap_ids = tuple(int(l.split('.')[-1]) for l in self.layers)
+        self.return_output = return_output
+
+    def forward(self, x, dtype='bf16', frames_per_chunk=0):
+        return self.model.forward_taps(x, self.tap_ids, dtype=dtype, frames_per_chunk=frames_per_chunk)
+
+
+class TransformerModel(nn.Module):
+    def __init__(self, cfg, local_rank=None):
+        super().__init__()
+        self.cfg = cfg
+        em = cfg.MODEL.EMBEDDER_MODEL
+        self.fusion_type = em.FUSION_TYPE if 'FUSION_TYPE' in em else 'late'
+        self.use_cls_res = bool('CLS_RES' in cfg.MODEL and cfg.MODEL.CLS_RES)
+        net = cfg.MODEL.BASE_MODEL.NETWORK
+        if 'TIMM-' not in net:
+            raise NotImplementedError('only TIMM-* ViT backbones are on the MI355X path (got %s); the ResNet-50 '
+                                      'CARL baselines are out of scope' % net)
+        if self.fusion_type != 'smart':
+            raise NotImplementedError("only MODEL.EMBEDDER_MODEL.FUSION_TYPE 'smart' (MV-Former) is on the MI355X path")
+        self.backbone_type = 'timm'
+        name = net[5:]
+        if name not in vitlib.VIT_ZOO:
+            print('ERROR: unknown/unsupported TIMM model:')
+            print(name)
+            exit()
+        dim, blk_count = vitlib.VIT_ZOO[name][0], vitlib.VIT_ZOO[name][1]
+        cfg.MODEL.BASE_MODEL.OUT_CHANNEL = dim
+        weights = cfg.MODEL.BASE_MODEL.WEIGHTS if 'WEIGHTS' in cfg.MODEL.BASE_MODEL else None
+        model = vitlib.create_model(name, pretrained=False, weights=weights, img_size=cfg.IMAGE_SIZE)
+        if self.use_cls_res:
+            self.cls_res_res = nn.Linear(dim, em.EMBEDDING_SIZE)
+        if 'SMART_FEATS' not in em:
+            extract_ids = ['blocks.11']
+        else:
+            extract_ids = ['blocks.%s' % t for t in str(em.SMART_FEATS).split(',')]
+            cfg.MODEL.BASE_MODEL.OUT_CHANNEL *= len(extract_ids)
+        layer = cfg.MODEL.BASE_MODEL.LAYER
+        if not (layer < 0 or layer >= blk_count):
+            raise NotImplementedError('partially frozen ViT (MODEL.BASE_MODEL.LAYER=%d < %d blocks) needs backward '
+                                      'kernels for the ViT blocks: SURVEY.md section 8(f) row 3, not built yet'
+                                      % (layer, blk_count))
+        self.backbone = FeatureExtractor(model, extract_ids)
+        for p in self.backbone.parameters():      # frozen: never in the optimizer, never all-reduced
+            p.requires_grad_(False)
+        self.res_finetune = nn.Identity()
+        self.embed = MultiEntityTransformerEmbModel(cfg)
+        if ('FUSION_CLS' in em and em.FUSION_CLS) or ('CLS_GRAD_ONLY' in em and em.CLS_GRAD_ONLY):
+            raise NotImplementedError('FUSION_CLS / CLS_GRAD_ONLY need a trainable backbone (not built yet)')
+        self.embedding_size = self.embed.embedding_size
+        if cfg.MODEL.PROJECTION:
+            self.ssl_projection = MLPHead(cfg)
+        if cfg.TRAINING_ALGO == 'classification':
+            raise NotImplementedError('classification algo is out of scope (configs_mvf/* all use scl)')
+        mi = cfg.MI355X if 'MI355X' in cfg else {}
+        self.compute_dtype = mi['COMPUTE_DTYPE'] if 'COMPUTE_DTYPE' in mi else \
+            ('bf16' if ('USE_AMP' in cfg and cfg.USE_AMP) else 'fp32')
+        self.frames_per_chunk = int(mi['FRAMES_PER_CHUNK']) if 'FRAMES_PER_CHUNK' in mi else 0
+
+    def train(self, mode=True):
+        super().train(mode)
+        self.backbone.eval()       # transformer.py:186: the frozen backbone always runs in eval()
+        return self
+
+    def features(self, x):
+        """[Bc, T, 3, H, W] -> (Taps, cls_emb [Bc*T, D])."""
+        bc, t, c, h, w = x.shape
+        taps, cls = self.backbone(x.reshape(bc * t, c, h, w), dtype=self.compute_dtype,
+                                  frames_per_chunk=self.frames_per_chunk)
+        ntok = (h // self.backbone.model.patch_size) * (w // self.backbone.model.patch_size)
+        return Taps(taps, bc, t, ntok), cls
+
+    def forward(self, x, num_frames=None, video_masks=None, project=False, classification=False):
+        if classification:
+            raise NotImplementedError('classification head is out of scope')
+        if video_masks is not None:
+            video_masks = video_masks.to(x.device)     # DDP's input scatter did this in the reference
+        feats, cls_emb = self.features(x)
+        x = self.embed(feats, video_masks=video_masks, cls_emb=cls_emb)
+        if self.cfg.MODEL.PROJECTION and project:
+            x = ops.l2_normalize(self.ssl_projection(x))
+        elif self.cfg.MODEL.L2_NORMALIZE:
+            x = ops.l2_normalize(x)
+        if self.use_cls_res:
+            cls_res = ops.linear(cls_emb, self.cls_res_res.weight, self.cls_res_res.bias).view(x.shape[0], x.shape[1], -1)
+            if self.cfg.MODEL.L2_NORMALIZE:
+                cls_res = ops.l2_normalize(cls_res)
+            x = x + cls_res
+            if self.cfg.MODEL.L2_NORMALIZE:
+                x = ops.l2_normalize(x)
+        return x

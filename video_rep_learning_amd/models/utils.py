@@ -1,0 +1,116 @@
+"""Temporal-transformer building blocks with the reference's class / parameter names
+(CARL_MVF/models/utils.py:47-242) so `embed.video_encoder.*` checkpoints load unchanged; every forward is a
+chain of HIP ops (video_rep_learning_amd.ops): LayerNorm -> fused QKV GEMM -> attention -> out-proj GEMM ->
+dropout+residual -> LayerNorm -> FC1+ReLU GEMM -> FC2 GEMM -> dropout+residual."""
+import math
+from copy import deepcopy
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+def generate_sincos_embedding(seq_len, d_model, train_len=None):
+    """utils.py:113-126 (vectorised; same float64 numbers).  Even channel i: sin(pos / 10000^(i/d)), odd
+    channel i: cos(pos / 10000^(i/d)) -- the exponent uses the channel index itself."""
+    pos = np.arange(seq_len, dtype=np.float64) if train_len is None else np.linspace(0, train_len - 1, num=seq_len)
+    ch = np.arange(d_model, dtype=np.float64)
+    ang = pos[:, None] / (10000.0 ** (ch[None, :] / d_model))
+    tab = np.where((np.arange(d_model) % 2 == 0)[None, :], np.sin(ang), np.cos(ang))
+    return torch.from_numpy(tab).unsqueeze(0)
+
+
+class PositionalEncoder(nn.Module):
+    """utils.py:128-145.  The table is built once per (S, d, device) and kept on the device (the reference
+    rebuilds it in a Python loop and copies it host->device every forward).  The add itself is fused into the
+    epilogue of the preceding `video_emb` GEMM (see MultiEntityTransformerEmbModel), `forward` is the plain form."""
+
+    def __init__(self, cfg, d_model, dout_p, seq_len=3660):
+        super().__init__()
+        self.cfg = cfg
+        self.d_model = d_model
+        self.dout_p = dout_p
+        self.seq_len = seq_len
+        self._tables = {}
+
+    def table(self, S, device):
+        key = (S, str(device))
+        if key not in self._tables:
+            t = generate_sincos_embedding(S, self.d_model, None if S == self.seq_len else self.seq_len)
+            self._tables[key] = t[0].float().to(device).contiguous()
+        return self._tables[key]
+
+
+class MultiheadedAttention(nn.Module):
+    def __init__(self, d_model_Q, d_model_K, d_model_V, H, dout_p=0.0, d_model=None, d_out=None):
+        super().__init__()
+        self.H = H
+        self.d_model = d_model if d_model is not None else d_model_Q
+        self.d_out = d_out if d_out is not None else d_model_Q
+        self.d_k = self.d_model // H
+        assert self.d_model % H == 0
+        self.linear_Q2d = nn.Linear(d_model_Q, self.d_model)
+        self.linear_K2d = nn.Linear(d_model_K, self.d_model)
+        self.linear_V2d = nn.Linear(d_model_V, self.d_model)
+        self.linear_d2Q = nn.Linear(self.d_model, self.d_out)
+
+    def forward(self, x, mask=None):
+        """Self-attention only (Q = K = V = x), x [B, S, D], mask [B, 1, S]."""
+        B, S, _ = x.shape
+        w = torch.cat([self.linear_Q2d.weight, self.linear_K2d.weight, self.linear_V2d.weight], 0)
+        b = torch.cat([self.linear_Q2d.bias, self.linear_K2d.bias, self.linear_V2d.bias], 0)
+        qkv = ops.linear(x.reshape(B * S, -1), w, b)
+        o = ops.temporal_attention(qkv, None if mask is None else mask.reshape(B, S), B, S, self.H)
+        return ops.linear(o, self.linear_d2Q.weight, self.linear_d2Q.bias).view(B, S, -1)
+
+
+class ResidualConnection(nn.Module):
+    def __init__(self, size, dout_p):
+        super().__init__()
+        self.norm = nn.LayerNorm(size)
+        self.dout_p = dout_p
+
+
+class PositionwiseFeedForward(nn.Module):
+    def __init__(self, d_model, d_ff, dout_p):
+        super().__init__()
+        self.fc1 = nn.Linear(d_model, d_ff)
+        self.fc2 = nn.Linear(d_ff, d_model)
+
+    def forward(self, x):
+        return ops.linear(ops.linear(x, self.fc1.weight, self.fc1.bias, relu=True), self.fc2.weight, self.fc2.bias)
+
+
+class EncoderLayer(nn.Module):
+    def __init__(self, d_model, dout_p, H=8, d_ff=None, d_hidden=None):
+        super().__init__()
+        self.res_layer0 = ResidualConnection(d_model, dout_p)
+        self.res_layer1 = ResidualConnection(d_model, dout_p)
+        d_hidden = d_model if d_hidden is None else d_hidden
+        d_ff = 4 * d_model if d_ff is None else d_ff
+        self.self_att = MultiheadedAttention(d_model, d_model, d_model, H, d_model=d_hidden)
+        self.feed_forward = PositionwiseFeedForward(d_model, d_ff, dout_p=0.0)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, x, src_mask=None, drop_state=None):
+        r0, r1 = self.res_layer0, self.res_layer1
+        h = ops.layer_norm(x, r0.norm.weight, r0.norm.bias, r0.norm.eps)
+        x = ops.dropout_add(self.self_att(h, src_mask), x, r0.dout_p, self.training, drop_state)
+        h = ops.layer_norm(x, r1.norm.weight, r1.norm.bias, r1.norm.eps)
+        return ops.dropout_add(self.feed_forward(h), x, r1.dout_p, self.training, drop_state)
+
+
+class Encoder(nn.Module):
+    def __init__(self, d_model, dout_p, H, d_ff, N, d_hidden=None):
+        super().__init__()
+        layer = EncoderLayer(d_model, dout_p, H, d_ff, d_hidden)
+        self.enc_layers = nn.ModuleList([deepcopy(layer) for _ in range(N)])
+
+    def forward(self, x, src_mask=None, drop_state=None):
+        for layer in self.enc_layers:
+            x = layer(x, src_mask, drop_state)
+        return x

@@ -1,0 +1,125 @@
+"""ViT backbone module whose forward is the HIP kernel chain (csrc/vit_fwd.hip).
+
+It takes the place of the `timm.create_model(name, pretrained=True)` object the reference builds at
+CARL_MVF/models/transformer.py:59 and keeps timm 0.9.2's parameter names (`cls_token`, `pos_embed`,
+`patch_embed.proj.*`, `blocks.N.{norm1,attn.qkv,attn.proj,norm2,mlp.fc1,mlp.fc2}.*`, `norm.*`,
+DINOv2: `blocks.N.ls{1,2}.gamma`) so timm / reference checkpoints load with `load_state_dict`.  The
+nn.Linear / nn.LayerNorm / nn.Conv2d children are parameter HOLDERS only: their torch forward is never called.
+There is no network here: weights are seeded trunc-normal(0.02) unless MODEL.BASE_MODEL.WEIGHTS points at a
+timm-format state dict.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+# name -> (embed_dim, depth, heads, patch, layerscale)   (reference name table: transformer.py:43-54)
+VIT_ZOO = {
+    'vit_small_patch16_224.dino': (384, 12, 6, 16, False),
+    'vit_small_patch8_224.dino': (384, 12, 6, 8, False),
+    'vit_base_patch16_224.dino': (768, 12, 12, 16, False),
+    'vit_base_patch8_224.dino': (768, 12, 12, 8, False),
+    'vit_small_patch14_dinov2.lvd142m': (384, 12, 6, 14, True),
+    'vit_base_patch14_dinov2.lvd142m': (768, 12, 12, 14, True),
+    'vit_large_patch14_dinov2.lvd142m': (1024, 24, 16, 14, True),
+    'vit_giant_patch14_dinov2.lvd142m': (1536, 40, 24, 14, True),
+}
+
+
+class _Holder(nn.Module):
+    pass
+
+
+class _LayerScale(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones(dim))
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, layerscale):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Holder()
+        self.attn.qkv = nn.Linear(dim, 3 * dim)
+        self.attn.proj = nn.Linear(dim, dim)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _Holder()
+        self.mlp.fc1 = nn.Linear(dim, 4 * dim)
+        self.mlp.fc2 = nn.Linear(4 * dim, dim)
+        if layerscale:
+            self.ls1, self.ls2 = _LayerScale(dim), _LayerScale(dim)
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, embed_dim, depth, num_heads, patch_size, img_size=224, layerscale=False):
+        super().__init__()
+        self.embed_dim, self.depth, self.num_heads = embed_dim, depth, num_heads
+        self.patch_size, self.img_size = patch_size, img_size
+        self.num_prefix_tokens = 1
+        self.global_pool = 'token'
+        n = (img_size // patch_size) ** 2 + 1
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, n, embed_dim))
+        self.patch_embed = _Holder()
+        self.patch_embed.proj = nn.Conv2d(3, embed_dim, patch_size, patch_size)
+        self.blocks = nn.Sequential(*[_Block(embed_dim, layerscale) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        self._packed = {}
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.trunc_normal_(p, std=0.02)
+        for m in self.modules():
+            if isinstance(m, nn.LayerNorm):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, (nn.Linear, nn.Conv2d)) and m.bias is not None:
+                nn.init.zeros_(m.bias)
+
+    def _apply(self, fn, *a, **kw):  # .cuda()/.to() invalidates the packed copy
+        self._packed = {}
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self._packed = {}
+        return super().load_state_dict(*a, **kw)
+
+    def packed(self, taps, dtype):
+        key = (tuple(taps), str(dtype))
+        if key not in self._packed:
+            sd = {k: v for k, v in self.state_dict().items()}
+            self._packed[key] = ops.PackedViT(sd, self.depth, self.embed_dim, self.num_heads, self.patch_size,
+                                              self.img_size, taps, dtype)
+        return self._packed[key]
+
+    @torch.no_grad()
+    def forward_taps(self, x, taps, dtype='bf16', frames_per_chunk=0):
+        """x [F,3,H,W] -> (list of tapped block outputs [F*(N-1), D] (CLS dropped), cls [F, D])."""
+        return ops.vit_forward(x, self.packed(taps, dtype), frames_per_chunk=frames_per_chunk)
+
+    def forward(self, x):
+        """timm's default forward: final-norm CLS embedding [F, D]."""
+        return self.forward_taps(x, (), dtype='fp32')[1]
+
+
+def create_model(name, pretrained=False, weights=None, img_size=224, seed=None):
+    """Stand-in for timm.create_model for the names the reference accepts."""
+    if name not in VIT_ZOO:
+        raise ValueError('unknown/unsupported TIMM model: %s' % name)
+    dim, depth, heads, patch, ls = VIT_ZOO[name]
+    if seed is not None:
+        with torch.random.fork_rng(devices=[]):
+            torch.manual_seed(seed)
+            m = VisionTransformer(dim, depth, heads, patch, img_size, ls)
+    else:
+        m = VisionTransformer(dim, depth, heads, patch, img_size, ls)
+    if weights:
+        sd = torch.load(weights, map_location='cpu')
+        sd = sd.get('model', sd.get('state_dict', sd))
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        if missing:
+            raise RuntimeError('backbone weights %s lack keys: %s' % (weights, missing[:5]))
+    return m

@@ -413,8 +413,10 @@ def _tap_table(taps):
 
 
 class _LSTPPool(torch.autograd.Function):
-    """pooled[b, j, t, :] = sum_n softmax_n(x[f,n,:] . vec[j,:] / sqrt(d))[n] * x[f,n,:]   (f = b*T + t).
-    `vec` is [nq, C] (static queries) or [Bc, nq, T, C] (per-frame / dynamic queries)."""
+    """pooled[b, j, t, :] = sum_n A[f,j,n] * x[f,n,:],  A = softmax_n(x[f,n,:] . vec[j,:] / sqrt(d))   (f = b*T + t)
+    (disjoint: A masked to the arg-max query per token, models/utils.py:26-33).
+    `vec` is [nq, C] (static queries) or [Bc, nq, T, C] (per-frame / dynamic queries).
+    Returns (pooled [Bc, nq, T, C], rowsum [Bc, nq, T] = sum_n A -- identically 1 unless disjoint)."""
 
     @staticmethod
     def forward(ctx, vec, taps, F, N, T, nq, inv_sqrt_d, disjoint, holder):
@@ -438,12 +440,16 @@ class _LSTPPool(torch.autograd.Function):
         ctx.save_for_backward(P, Pm)
         ctx.cfg = (F, N, T, nq, inv_sqrt_d, per_frame, dt, D, C)
         if holder is not None:
-            holder['attn'] = Pm if disjoint else P
-            holder['rowsum'] = rowsum
-        return pooled
+            holder['attn'] = Pm if disjoint else P      # [F, nq, N], like LSTPCrossAtt.attn_matrix
+        if disjoint:
+            rs = rowsum.view(F // T, T, nq).transpose(1, 2).contiguous()     # (b, j, t) like pooled
+        else:
+            rs = torch.ones(F // T, nq, T, device=dev, dtype=torch.float32)
+            ctx.mark_non_differentiable(rs)
+        return pooled, rs
 
     @staticmethod
-    def backward(ctx, dpooled):
+    def backward(ctx, dpooled, drs):
         P, Pm = ctx.saved_tensors
         F, N, T, nq, inv_sqrt_d, per_frame, dt, D, C = ctx.cfg
         taps = ctx.taps
@@ -452,8 +458,11 @@ class _LSTPPool(torch.autograd.Function):
         dpooled = dpooled.contiguous()
         dP = torch.empty(F * N, nq, device=dev, dtype=torch.float32)
         call('mvf_lstp_scores', tab, len(taps), dt, D, F, N, T, nq, ptr(dpooled), 1, ptr(dP), stream())
+        drow = None
+        if Pm is not None and drs is not None:
+            drow = drs.transpose(1, 2).contiguous().view(F, nq)             # back to (f, j)
         dS = torch.empty(F, nq, N, device=dev, dtype=torch.float32)
-        call('mvf_lstp_softmax_bwd', ptr(P), ptr(Pm), ptr(dP), None, ptr(dS), F, N, nq, inv_sqrt_d, stream())
+        call('mvf_lstp_softmax_bwd', ptr(P), ptr(Pm), ptr(dP), ptr(drow), ptr(dS), F, N, nq, inv_sqrt_d, stream())
         G = torch.empty(F // T, nq, T, C, device=dev, dtype=torch.float32)
         call('mvf_lstp_wsum', tab, len(taps), dt, D, F, N, T, nq, ptr(dS), ptr(G), stream())
         if per_frame:
@@ -465,6 +474,7 @@ class _LSTPPool(torch.autograd.Function):
 
 
 def lstp_pool(vec, taps, F, N, T, nq, d_model, disjoint=False, holder=None):
+    """-> (pooled [Bc, nq, T, C], rowsum [Bc, nq, T])."""
     return _LSTPPool.apply(vec, tuple(taps), F, N, T, nq, 1.0 / math.sqrt(d_model), disjoint, holder)
 
 

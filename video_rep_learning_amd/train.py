@@ -1,0 +1,200 @@
+"""Training entry point with the reference's CLI and loop semantics (CARL_MVF/train.py:57-341):
+
+    python -m torch.distributed.run --nproc-per-node N train.py --cfg_file configs_mvf/penn_mvf.yml \
+        --workdir W --logdir L [--opts K V ...]
+
+Per iteration (train.py:94-171): zero_grad -> algo.compute_loss(model, videos, seq_lens, chosen_steps,
+video_masks) -> backward -> clip_grad_norm_(GRAD_CLIP) -> optimizer step -> loss all-reduce(avg) for logging.
+Differences, all on purpose:
+  * device/backend are not hard-wired: HIP device + 'nccl' (= RCCL over xGMI) by default;
+  * gradient averaging is done by the optimizer's flat-buffer GradReducer over the 4.8 M TRAINABLE
+    parameters (async bucketed RCCL all-reduce overlapped with backward) instead of DDP(find_unused_parameters)
+    over all 90 M; SyncBatchNorm statistics are exchanged by the HIP BN op;
+  * clip + Adam is one fused HIP kernel pair on the flat buffers;
+  * the loss is accumulated on the device and all-reduced / synced to the host once per REPORT_INTERVAL and at
+    epoch end (same logged numbers, no per-iteration .item() stall);
+  * bf16 compute needs no GradScaler (`algo.scaler` stays None).
+"""
+import datetime
+import json
+import os
+import pprint
+import random
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .utils import distributed as du
+from .utils import logging
+from .utils.parser import parse_args, load_config, setup_train_dir
+from .utils.optimizer import construct_optimizer, construct_scheduler, get_lr
+from .models import build_model, save_checkpoint, load_checkpoint
+from .algos import get_algo
+from .datasets import synthetic
+
+logger = logging.get_logger(__name__)
+
+
+class DataParallelModel(nn.Module):
+    """Keeps the `model.module` surface of DistributedDataParallel (train.py:88,316; models/__init__.py:24).
+    Gradient synchronisation itself lives in utils.distributed.GradReducer (driven by the optimizer)."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *a, **kw):
+        return self.module(*a, **kw)
+
+
+class ScalarWriter:
+    """Minimal SummaryWriter stand-in (tensorboard is not a dependency): scalars -> LOGDIR/train_logs/scalars.jsonl."""
+
+    def __init__(self, logdir):
+        os.makedirs(logdir, exist_ok=True)
+        self.path = os.path.join(logdir, 'scalars.jsonl')
+
+    def add_scalar(self, tag, value, step):
+        if du.is_root_proc():
+            with open(self.path, 'a') as f:
+                f.write(json.dumps({'tag': tag, 'value': float(value), 'step': int(step)}) + '\n')
+
+
+def train(cfg, train_loader, model, optimizer, scheduler, algo, cur_epoch, summary_writer, data_preprocess,
+          device='cuda', max_iters=0):
+    model.train()
+    optimizer.zero_grad()
+    data_size = len(train_loader) if not max_iters else min(len(train_loader), max_iters)
+    if hasattr(train_loader.sampler, 'set_epoch'):
+        train_loader.sampler.set_epoch(cur_epoch)
+    if 'BACKBONE_WARMUP' in cfg.TRAIN:
+        model.module.embed.set_warmup_status(cur_epoch < cfg.TRAIN.BACKBONE_WARMUP)
+    total = {}      # device-side running sums of the per-iteration (NaN -> 0) local losses
+    loss = None
+    for cur_iter, (videos, _labels, seq_lens, chosen_steps, video_masks, names) in enumerate(train_loader):
+        if max_iters and cur_iter >= max_iters:
+            break
+        videos = synthetic.preproc_views(videos[0], videos[1], data_preprocess, device)
+        optimizer.zero_grad()
+        loss_dict = algo.compute_loss(model, videos, seq_lens, chosen_steps, video_masks)
+        loss = loss_dict['loss']
+        loss.backward()
+        clip = cfg.OPTIMIZER.GRAD_CLIP
+        if hasattr(optimizer, 'reducer'):
+            optimizer.step(max_norm=clip if clip > 0 else 0.0)
+        else:
+            if clip > 0:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+            optimizer.step()
+        for key in loss_dict:
+            v = torch.nan_to_num(loss_dict[key].detach(), nan=0.0)
+            total[key] = v if key not in total else total[key] + v
+        if cur_iter % cfg.LOGGING.REPORT_INTERVAL == 0:
+            logger.info(f'iter {data_size * cur_epoch + cur_iter}, training loss: {loss.item():.3f}')
+    out = {}
+    for key in total:
+        out[key] = du.all_reduce([total[key].clone()])[0].item() / data_size
+    summary_writer.add_scalar('train/learning_rate', get_lr(optimizer)[0], cur_epoch)
+    for key in out:
+        summary_writer.add_scalar(f'train/{key}', out[key], cur_epoch)
+    logger.info('epoch {}, train loss: {:.3f}'.format(cur_epoch, out.get('loss', float('nan'))))
+    if cur_epoch != cfg.TRAIN.MAX_EPOCHS - 1:
+        scheduler.step()
+    return out
+
+
+def val(cfg, val_loader, model, algo, cur_epoch, summary_writer, data_preprocess, device='cuda', max_iters=0):
+    model.eval()
+    data_size = len(val_loader) if not max_iters else min(len(val_loader), max_iters)
+    total = {}
+    with torch.no_grad():
+        for cur_iter, (videos, labels, seq_lens, chosen_steps, video_masks, names) in enumerate(val_loader):
+            if max_iters and cur_iter >= max_iters:
+                break
+            videos = synthetic.preproc_views(videos[0], videos[1], data_preprocess, device)
+            loss_dict = algo.compute_loss(model, videos, seq_lens, chosen_steps, video_masks, training=False)
+            for key in loss_dict:
+                v = torch.nan_to_num(loss_dict[key].detach(), nan=0.0)
+                total[key] = v if key not in total else total[key] + v
+    out = {k: du.all_reduce([v.clone()])[0].item() / data_size for k, v in total.items()}
+    for key in out:
+        summary_writer.add_scalar(f'val/{key}', out[key], cur_epoch)
+    logger.info('epoch {}, val loss: {:.3f}'.format(cur_epoch, out.get('loss', float('nan'))))
+    return out
+
+
+def setup_distributed(args):
+    """Process-group init from the launcher's environment (train.py:236-262), backend not hard-wired."""
+    world = int(os.getenv('WORLD_SIZE', '1'))
+    if os.environ.get('OMPI_COMM_WORLD_SIZE') is None:
+        rank = int(os.getenv('RANK', args.local_rank))
+    else:
+        rank = int(os.getenv('OMPI_COMM_WORLD_RANK')) * max(torch.cuda.device_count(), 1) + args.local_rank
+    device = args.device or ('cuda' if torch.cuda.is_available() else 'cpu')
+    backend = args.backend or ('nccl' if device == 'cuda' else 'gloo')
+    if device == 'cuda':
+        torch.cuda.set_device(args.local_rank)
+    if world > 1 or 'MASTER_ADDR' in os.environ:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        torch.distributed.init_process_group(backend=backend, init_method='env://', world_size=world, rank=rank,
+                                             timeout=datetime.timedelta(seconds=72000))
+    return device, world, rank
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    cfg = load_config(args)
+    setup_train_dir(cfg, cfg.LOGDIR, args.continue_train, args.tempcfg)
+    cfg.PATH_TO_DATASET = os.path.join(args.workdir, cfg.PATH_TO_DATASET)
+    device, world, rank = setup_distributed(args)
+    cfg.NUM_GPUS = torch.cuda.device_count()
+    args.world_size, args.rank = world, rank
+    random.seed(cfg.RNG_SEED)
+    np.random.seed(cfg.RNG_SEED)
+    torch.manual_seed(cfg.RNG_SEED)
+    logging.setup_logging(cfg.LOGDIR)
+    summary_writer = ScalarWriter(os.path.join(cfg.LOGDIR, 'train_logs'))
+    logger.info('Train with config:')
+    logger.info(pprint.pformat(cfg))
+
+    model = build_model(cfg, args.local_rank).to(device)
+    if world > 1:
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    model = DataParallelModel(model)
+    optimizer = construct_optimizer(model, cfg)
+    algo = get_algo(cfg)
+    algo.scaler = None
+
+    if not args.synthetic:
+        raise NotImplementedError('only --synthetic data is wired in this build: the video decoders / samplers of '
+                                  'CARL_MVF/datasets are host-side I/O outside the hot path (SURVEY section 2)')
+    train_loader, _ = synthetic.construct_dataloader(cfg, 'train', device=device, rank=rank)
+    val_loader, _ = synthetic.construct_dataloader(cfg, 'val', device=device, rank=rank, iters=4)
+    train_preproc = synthetic.get_data_preprocess(cfg, 'train')
+    val_preproc = synthetic.get_data_preprocess(cfg, 'val')
+
+    start_epoch = load_checkpoint(cfg, model, optimizer)
+    cfg.TRAIN.MAX_ITERS = cfg.TRAIN.MAX_EPOCHS * len(train_loader)
+    scheduler = construct_scheduler(optimizer, cfg)
+    for cur_epoch in range(start_epoch, cfg.TRAIN.MAX_EPOCHS):
+        logger.info(f'Traning epoch {cur_epoch}/{cfg.TRAIN.MAX_EPOCHS}, {len(train_loader)} iters each epoch')
+        t0 = time.time()
+        train(cfg, train_loader, model, optimizer, scheduler, algo, cur_epoch, summary_writer, train_preproc, device,
+              args.max_iters)
+        if device == 'cuda':
+            torch.cuda.synchronize()
+        print('train done in (m): ' + str((time.time() - t0) / 60.0))
+        if du.is_root_proc() and ((cur_epoch + 1) % cfg.CHECKPOINT.SAVE_INTERVAL == 0 or cur_epoch == cfg.TRAIN.MAX_EPOCHS - 1):
+            save_checkpoint(cfg, model, optimizer, cur_epoch)
+        if (cur_epoch + 1) % cfg.EVAL.VAL_INTERVAL == 0 or cur_epoch == cfg.TRAIN.MAX_EPOCHS - 1:
+            val(cfg, val_loader, model, algo, cur_epoch, summary_writer, val_preproc, device, args.max_iters)
+        du.synchronize()
+    if du.is_dist():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,171 @@
+"""Data-parallel helpers: one process per GPU over torch.distributed ('nccl' = RCCL over xGMI on ROCm, 'gloo'
+for CPU plumbing tests).
+
+Mirrors the helpers of CARL_MVF/utils/distributed.py that the train path calls (all_reduce :38-54,
+synchronize :136-148, rank/size helpers) and replaces `DistributedDataParallel(find_unused_parameters=True)`
+of train.py:285-286 -- which registers the 86 M frozen backbone parameters too -- by `GradReducer`:
+gradients of the 4.8 M TRAINABLE parameters live in ONE flat fp32 buffer cut into a few buckets; a bucket's
+all-reduce is launched asynchronously (RCCL side stream) from the autograd hook of its last gradient, so it
+overlaps the rest of backward; the optimizer waits, then divides by world size inside the fused Adam kernel.
+Also: the autograd-aware embedding all-gather that enlarges the SCL negative set (new)."""
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size():
+    return dist.get_world_size() if is_dist() else 1
+
+
+def get_rank():
+    return dist.get_rank() if is_dist() else 0
+
+
+def is_root_proc():
+    return get_rank() == 0
+
+
+def synchronize():
+    """Barrier across all ranks (distributed.py:136-148)."""
+    if is_dist() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def all_reduce(tensors, average=True):
+    """In-place all-reduce of a list of tensors, optionally averaged (distributed.py:38-54)."""
+    if not is_dist() or dist.get_world_size() == 1:
+        return tensors
+    for t in tensors:
+        dist.all_reduce(t, async_op=False)
+    if average:
+        ws = dist.get_world_size()
+        for t in tensors:
+            t.mul_(1.0 / ws)
+    return tensors
+
+
+def all_gather(tensors):
+    """Non-differentiable tensor all-gather + cat(dim 0) (distributed.py:16-35)."""
+    if not is_dist() or dist.get_world_size() == 1:
+        return tensors
+    out = []
+    for t in tensors:
+        parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, t.contiguous())
+        out.append(torch.cat(parts, dim=0))
+    return out
+
+
+class _GatherRows(torch.autograd.Function):
+    """all_gather along dim 0 whose backward hands each rank the gradient rows of ITS slice.  Every rank
+    evaluates the same global loss on the gathered rows, so d(global loss)/d(local rows) is just the local slice
+    of the upstream gradient -- no reduce-scatter needed (the loss kernel only produces those rows anyway)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ws, rk = dist.get_world_size(), dist.get_rank()
+        parts = [torch.empty_like(x) for _ in range(ws)]
+        dist.all_gather(parts, x.contiguous())
+        ctx.rows, ctx.rank = x.shape[0], rk
+        return torch.cat(parts, dim=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[ctx.rank * ctx.rows:(ctx.rank + 1) * ctx.rows].contiguous()
+
+
+def gather_rows(x):
+    if not is_dist() or dist.get_world_size() == 1:
+        return x
+    return _GatherRows.apply(x)
+
+
+class FlatBuffers:
+    """Re-homes a list of parameters into one flat fp32 buffer (and their .grad into a second one)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+        assert self.params, 'no trainable parameters'
+        dev = self.params[0].device
+        # 4-element (16 B) alignment per tensor so every view can be read with float4
+        self.offsets = []
+        n = 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        self.numel = n
+        self.flat_p = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(n, device=dev, dtype=torch.float32)
+        for p, o in zip(self.params, self.offsets):
+            v = self.flat_p[o:o + p.numel()].view_as(p)
+            v.copy_(p.data)
+            p.data = v
+            p.grad = self.flat_g[o:o + p.numel()].view_as(p)
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        for p, o in zip(self.params, self.offsets):   # re-attach in case something set .grad to None
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+                p.grad = self.flat_g[o:o + p.numel()].view_as(p)
+
+
+class GradReducer:
+    """Bucketed asynchronous gradient all-reduce (SUM) over a FlatBuffers gradient buffer."""
+
+    def __init__(self, flat, bucket_bytes=8 << 20, group=None):
+        self.flat = flat
+        self.group = group
+        self.world = get_world_size()
+        # buckets in REVERSE parameter order (gradients become ready roughly output -> input)
+        self.buckets = []          # (start, end) element ranges
+        self.bucket_of = {}
+        cur_end = flat.numel
+        cur_bytes = 0
+        idxs = []
+        for i in reversed(range(len(flat.params))):
+            idxs.append(i)
+            cur_bytes += flat.params[i].numel() * 4
+            if cur_bytes >= bucket_bytes or i == 0:
+                start = flat.offsets[i]
+                b = len(self.buckets)
+                self.buckets.append((start, cur_end))
+                for j in idxs:
+                    self.bucket_of[j] = b
+                cur_end, cur_bytes, idxs = start, 0, []
+        self.sizes = [sum(1 for j in self.bucket_of.values() if j == b) for b in range(len(self.buckets))]
+        self.pending = None
+        self.works = None
+        if self.world > 1:
+            for i, p in enumerate(flat.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+        self.reset()
+
+    def reset(self):
+        self.pending = list(self.sizes)
+        self.works = [None] * len(self.buckets)
+
+    def _launch(self, b):
+        s, e = self.buckets[b]
+        self.works[b] = dist.all_reduce(self.flat.flat_g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _make_hook(self, i):
+        def hook(_param):
+            b = self.bucket_of[i]
+            self.pending[b] -= 1
+            if self.pending[b] == 0 and self.works[b] is None:
+                self._launch(b)
+        return hook
+
+    def finish(self):
+        """Launch whatever was not triggered (parameters without a gradient this step) and wait for all."""
+        if self.world > 1:
+            for b in range(len(self.buckets)):
+                if self.works[b] is None:
+                    self._launch(b)
+            for w in self.works:
+                w.wait()
+        self.reset()
+        return 1.0 / self.world   # scale that turns the SUM into DDP's average

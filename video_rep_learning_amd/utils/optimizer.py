@@ -1,0 +1,157 @@
+"""Optimizer / LR-schedule construction with the reference's surface (CARL_MVF/utils/optimizer.py:10-117).
+
+`construct_optimizer` selects the same parameters in the same two groups (BN / non-BN; backbone skipped when
+MODEL.TRAIN_BASE == 'frozen').  For Adam -- the optimizer of every shipped config -- it returns `FusedAdam`: a
+`torch.optim.Optimizer` (so torch LR schedulers and `state_dict()` consumers keep working, checkpoints stay in
+torch.optim.Adam's format) whose parameters/gradients/moments live in flat buffers and whose step, including the
+global-norm clip of train.py:124-126, is the HIP kernel pair of csrc/optim.hip."""
+import math
+
+import numpy as np
+import torch
+
+from .. import ops
+from .distributed import FlatBuffers, GradReducer
+
+
+def select_parameters(model, cfg):
+    """(bn_params, non_bn_params) exactly as optimizer.py:26-42."""
+    bn, non_bn = [], []
+    for n, m in model.named_modules():
+        is_bn = isinstance(m, torch.nn.modules.batchnorm._NormBase) or getattr(m, '_is_batchnorm', False)
+        for p in m.parameters(recurse=False):
+            if not p.requires_grad:
+                continue
+            if 'backbone' in n and cfg.MODEL.TRAIN_BASE != 'train_all':
+                if cfg.MODEL.TRAIN_BASE == 'frozen':
+                    continue
+                if cfg.MODEL.TRAIN_BASE == 'only_bn' and is_bn:
+                    bn.append(p)
+            else:
+                (bn if is_bn else non_bn).append(p)
+    return bn, non_bn
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """Adam with L2 weight decay (== torch.optim.Adam(weight_decay=wd)) on flat buffers + fused global-norm clip."""
+
+    def __init__(self, param_groups, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, bucket_bytes=8 << 20):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                        foreach=None, capturable=False, differentiable=False, fused=None)
+        super().__init__(param_groups, defaults)
+        params = [p for g in self.param_groups for p in g['params']]
+        self.flat = FlatBuffers(params)
+        self.exp_avg = torch.zeros_like(self.flat.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat.flat_p)
+        self.step_count = 0
+        dev = self.flat.flat_p.device
+        self._scratch = torch.empty(1024, device=dev, dtype=torch.float32)
+        self._norm = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.reducer = GradReducer(self.flat, bucket_bytes)
+        # element range of every param group (groups are contiguous in the flat buffer by construction)
+        self._ranges = []
+        k = 0
+        for g in self.param_groups:
+            n = len(g['params'])
+            if n == 0:
+                self._ranges.append((0, 0))
+            else:
+                s = self.flat.offsets[k]
+                e = self.flat.offsets[k + n] if k + n < len(self.flat.params) else self.flat.numel
+                self._ranges.append((s, e))
+            k += n
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None, max_norm=0.0):
+        """Waits for the gradient all-reduce, then clip (if max_norm > 0) + Adam in place. Returns the device
+        scalar holding the (averaged) gradient norm when clipping, else None."""
+        gscale = self.reducer.finish()
+        self.step_count += 1
+        norm = None
+        if max_norm and max_norm > 0:
+            norm = ops.grad_norm(self.flat.flat_g, self._scratch, self._norm)
+        for g, (s, e) in zip(self.param_groups, self._ranges):
+            if e <= s:
+                continue
+            ops.adam_step(self.flat.flat_p[s:e], self.flat.flat_g[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e],
+                          float(g['lr']), g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], self.step_count,
+                          clip=float(max_norm or 0.0), norm=norm, gscale=gscale)
+        return norm
+
+    # ---- torch.optim.Adam-compatible (de)serialisation: CARL_MVF/models/__init__.py:22-27,42-46 ----
+    def state_dict(self):
+        state = {}
+        for i, (p, o) in enumerate(zip(self.flat.params, self.flat.offsets)):
+            n = p.numel()
+            state[i] = {'step': torch.tensor(float(self.step_count)),
+                        'exp_avg': self.exp_avg[o:o + n].view_as(p).clone(),
+                        'exp_avg_sq': self.exp_avg_sq[o:o + n].view_as(p).clone()}
+        groups, k = [], 0
+        for g in self.param_groups:
+            d = {kk: vv for kk, vv in g.items() if kk != 'params'}
+            d['params'] = list(range(k, k + len(g['params'])))
+            k += len(g['params'])
+            groups.append(d)
+        return {'state': state if self.step_count > 0 else {}, 'param_groups': groups}
+
+    def load_state_dict(self, sd):
+        for g, sg in zip(self.param_groups, sd['param_groups']):
+            for kk, vv in sg.items():
+                if kk != 'params':
+                    g[kk] = vv
+        for i, st in sd.get('state', {}).items():
+            i = int(i)
+            p, o = self.flat.params[i], self.flat.offsets[i]
+            n = p.numel()
+            self.exp_avg[o:o + n].copy_(st['exp_avg'].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+            self.step_count = int(float(st['step']))
+
+
+def construct_optimizer(model, cfg):
+    bn, non_bn = select_parameters(model, cfg)
+    wd = cfg.OPTIMIZER.WEIGHT_DECAY
+    groups = [{'params': bn, 'weight_decay': wd}, {'params': non_bn, 'weight_decay': wd}]
+    lr = cfg.OPTIMIZER.LR.INITIAL_LR
+    if cfg.OPTIMIZER.TYPE == 'AdamOptimizer':
+        return FusedAdam(groups, lr=lr, betas=(0.9, 0.999), weight_decay=wd)
+    if cfg.OPTIMIZER.TYPE == 'MomentumOptimizer':
+        return torch.optim.SGD(groups, lr=lr, momentum=0.9, weight_decay=wd)
+    if cfg.OPTIMIZER.TYPE == 'AdamWOptimizer':
+        return torch.optim.AdamW(groups, lr=lr, betas=(0.9, 0.999), weight_decay=wd)
+    raise NotImplementedError('Does not support {} optimizer'.format(cfg.OPTIMIZER.TYPE))
+
+
+def construct_scheduler(optimizer, cfg):
+    """optimizer.py:79-104 (per-epoch schedulers)."""
+    kind = cfg.OPTIMIZER.LR.DECAY_TYPE
+    if kind == 'fixed':
+        return torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda epoch: 1)
+    if kind == 'cosine':
+        return torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=cfg.TRAIN.MAX_EPOCHS + 1, eta_min=0,
+                                                          last_epoch=-1)
+    if kind == 'cosinewarmup':
+        base = cfg.OPTIMIZER.LR.INITIAL_LR
+        nw = cfg.OPTIMIZER.LR.NUM_WARMUP_STEPS
+        warm = np.linspace(cfg.OPTIMIZER.LR.WARMUP_LR / base, 1, nw)
+        it = np.arange(cfg.TRAIN.MAX_EPOCHS + 1 - nw)
+        fin = cfg.OPTIMIZER.LR.FINAL_LR / base
+        cos = np.array([fin + 0.5 * (1 - fin) * (1 + math.cos(math.pi * t / len(it))) for t in it])
+        sched = np.concatenate((warm, cos))
+        return torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda epoch: sched[epoch])
+    if kind == 'multiply':
+        dr = cfg.OPTIMIZER.LR.DECAY_RATE
+        return torch.optim.lr_scheduler.MultiplicativeLR(optimizer, lr_lambda=lambda epoch: dr)
+    raise NotImplementedError('Does not support {} scheduler'.format(kind))
+
+
+def get_lr(optimizer):
+    return [g['lr'] for g in optimizer.param_groups]
+
+
+def set_lr(optimizer, new_lr):
+    for g in optimizer.param_groups:
+        g['lr'] = new_lr

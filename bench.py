@@ -52,7 +52,8 @@ def cpu_baseline(cfg, model):
     g = torch.Generator().manual_seed(1234)
     batch = (torch.randn(1, 2, t, 3, s, s, generator=g), torch.full((1, 2), 100, dtype=torch.long),
              torch.sort(torch.randint(0, 100, (1, 2, t), generator=g), dim=-1)[0], torch.ones(1, 2, t))
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of the host (16 hardware threads); more torch threads than that only thrash
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
     torch.set_num_threads(cores)
     t0 = time.time()
     OM.train_step(batch, params, {}, vit_cfg, head_cfg, scl_cfg)

@@ -52,9 +52,10 @@ def test_gemm_tc_store_gelu(dtype, M, N, K):
     b = torch.randn(N, generator=g)
     Ad, Wd = A.to(DEV).to(tdt), W.to(DEV).to(tdt)
     ref = Ad.double().cpu() @ Wd.double().cpu().t() + b.double()
+    bd = b.to(DEV)   # device operands are held in names: a temporary's storage is recycled before the kernel runs
     for epi, f in ((_lib.EPI_STORE, lambda x: x), (_lib.EPI_GELU, OV.gelu_erf)):
         Cd = torch.zeros(M, N, device=DEV, dtype=tdt)
-        _lib.call('mvf_gemm_tc', code, epi, Ad.data_ptr(), K, Wd.data_ptr(), K, b.to(DEV).data_ptr(), Cd.data_ptr(), N,
+        _lib.call('mvf_gemm_tc', code, epi, Ad.data_ptr(), K, Wd.data_ptr(), K, bd.data_ptr(), Cd.data_ptr(), N,
                   None, 0, None, 0, None, None, 0, M, N, K, S())
         check(Cd, f(ref), 2e-5 if dtype == 'f32' else 1e-2, 'gemm_tc epi %d %s' % (epi, dtype))
 
@@ -94,18 +95,20 @@ def test_gemm_tc_resid_tap_patch(dtype):
 def test_patchify_and_layernorm():
     g = gen(3)
     img = torch.randn(2, 3, 32, 32, generator=g)
+    imgd = img.to(DEV)
     for dtype in ('f32', 'bf16'):
         code, tdt = ops._dt(dtype)
         out = torch.empty(2 * 4, 768, device=DEV, dtype=tdt)
-        _lib.call('mvf_patchify', code, img.to(DEV).data_ptr(), out.data_ptr(), 2, 32, 32, 16, S())
+        _lib.call('mvf_patchify', code, imgd.data_ptr(), out.data_ptr(), 2, 32, 32, 16, S())
         check(out, OV.patchify(img, 16).reshape(8, 768), 0 if dtype == 'f32' else 4e-3, 'patchify')
     x = torch.randn(37, 768, generator=g) * 3 + 1
     w, b = torch.randn(768, generator=g), torch.randn(768, generator=g)
     ref = OV.layer_norm(x.double(), w.double(), b.double(), 1e-6)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
     for dtype in ('f32', 'bf16'):
         code, tdt = ops._dt(dtype)
         y = torch.empty(37, 768, device=DEV, dtype=tdt)
-        _lib.call('mvf_layernorm_fwd', code, x.to(DEV).data_ptr(), 768, w.to(DEV).data_ptr(), b.to(DEV).data_ptr(),
+        _lib.call('mvf_layernorm_fwd', code, xd.data_ptr(), 768, wd.data_ptr(), bd.data_ptr(),
                   y.data_ptr(), 768, 37, 768, 1e-6, S())
         check(y, ref, 1e-5 if dtype == 'f32' else 8e-3, 'layernorm ' + dtype)
 

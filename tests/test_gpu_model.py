@@ -145,16 +145,25 @@ def test_small_model_loss_and_grads(variant):
     e = relerr(loss, lref)
     assert e <= 1e-3, 'loss %.3e (%.6f vs %.6f)' % (e, loss.item(), lref.item())
     rels = grad_errors(leaves)
-    if rels[0][0] > 5e-3 and 0 < len(near) <= 4:
+    if rels[0][0] > 5e-3 and near:
         # some pre-activations sit within 2e-5 of the ReLU kink (oracle/head.py KINK): the fp32 device run may be on the
-        # other side there.  The device gradient must then equal the oracle's for one assignment of those units.
-        import itertools
-        for k in range(1, len(near) + 1):
-            for sub in itertools.combinations(near, k):
-                _l, lv, _p, _n = oracle_grads(flip=sub)
+        # other side there.  The device gradient must then equal the oracle's for one assignment of those units
+        # (greedy search: flip the single unit that helps most, at most three times).
+        chosen = ()
+        for _round in range(3):
+            best = None
+            for u in near[:32]:
+                if u in chosen:
+                    continue
+                _l, lv, _p, _n = oracle_grads(flip=chosen + (u,))
                 r2 = grad_errors(lv)
-                if r2[0][0] < rels[0][0]:
-                    rels = r2
+                if r2[0][0] < rels[0][0] and (best is None or r2[0][0] < best[1][0][0]):
+                    best = (u, r2)
+            if best is None:
+                break
+            chosen, rels = chosen + (best[0],), best[1]
+            if rels[0][0] <= 5e-3:
+                break
     assert rels[0][0] <= 5e-3, 'gradient mismatch (rel, name, abs err, ref max; %d near-kink units): %s' % (
         len(near), '; '.join('%.2e %s %.2e %.2e' % r for r in rels[:8]))
     # BN running statistics were updated like torch does

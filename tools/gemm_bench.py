@@ -1,0 +1,58 @@
+"""GEMM-only timing / profiling driver for the backbone GEMM kernels (GPU box; not part of the judged bench).
+
+    python tools/gemm_bench.py [--variant 1|2] [--shapes qkv,proj,fc1,fc2] [--frames 256] [--iters 20]
+
+Run it under `rocprofv3 --kernel-trace --stats` or `rocprofv3 --pmc ...` to get per-kernel durations / counters for
+exactly the ViT-B/16 shapes of BASELINE configs[1] (M = frames * 197)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from video_rep_learning_amd import _lib  # noqa: E402
+
+SHAPES = {'qkv': (2304, 768, 0), 'proj': (768, 768, 2), 'fc1': (3072, 768, 1), 'fc2': (768, 3072, 2)}
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument('--variant', type=int, default=2)
+    p.add_argument('--shapes', default='qkv,proj,fc1,fc2')
+    p.add_argument('--frames', type=int, default=256)
+    p.add_argument('--iters', type=int, default=20)
+    p.add_argument('--warm', type=int, default=3)
+    a = p.parse_args()
+    dev = 'cuda'
+    M = a.frames * 197
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.call('mvf_gemm_tc_select', a.variant)
+    for name in a.shapes.split(','):
+        n, k, epi = SHAPES[name]
+        A = torch.randn(M, k, device=dev).to(torch.bfloat16)
+        W = (torch.randn(n, k, device=dev) * 0.02).to(torch.bfloat16)
+        b = torch.randn(n, device=dev)
+        C = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
+        R = torch.zeros(M, n, device=dev)
+
+        def fn():
+            _lib.call('mvf_gemm_tc', _lib.BF16, epi, A.data_ptr(), k, W.data_ptr(), k, b.data_ptr(), C.data_ptr(), n,
+                      R.data_ptr(), n, None, 0, None, None, 197, M, n, k, st)
+        for _ in range(a.warm):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / a.iters * 1e-3
+        print('variant %d %-4s M=%d N=%d K=%d  %8.1f us  %7.1f TFLOP/s' % (a.variant, name, M, n, k, t * 1e6,
+                                                                          2.0 * M * n * k / t / 1e12), flush=True)
+    _lib.call('mvf_gemm_tc_select', 0)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,59 @@
+"""Diagnostic: where a gemm_tc256 workgroup spends its cycles (s_memtime stamps of the DBG build; GPU box only).
+Reads SHARES, not absolute run time (the stamped build forbids overlaps the product kernel has)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from video_rep_learning_amd import _lib  # noqa: E402
+
+
+def main():
+    n, k = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2304, 768)
+    M = 256 * 197
+    dev = 'cuda'
+    st = torch.cuda.current_stream().cuda_stream
+    A = torch.randn(M, k, device=dev).to(torch.bfloat16)
+    W = (torch.randn(n, k, device=dev) * 0.02).to(torch.bfloat16)
+    b = torch.randn(n, device=dev)
+    C = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
+    nblk = ((M + 255) // 256) * ((n + 255) // 256)
+    buf = torch.zeros(nblk * 2 * 8, device=dev, dtype=torch.int64)
+
+    def fn():
+        _lib.call('mvf_gemm_tc', _lib.BF16, 0, A.data_ptr(), k, W.data_ptr(), k, b.data_ptr(), C.data_ptr(), n,
+                  None, 0, None, 0, None, None, 197, M, n, k, st)
+    for _ in range(3):
+        fn()
+    _lib.call('mvf_gemm_tc_debug_stamps', buf.data_ptr())
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    _lib.call('mvf_gemm_tc_debug_stamps', None)
+    s = buf.cpu().numpy().reshape(nblk, 2, 8).astype(np.int64)
+    d = np.diff(s, axis=2)          # [blk, wave-row, 7 segments]
+    names = ['prologue (issue 14 DMA + wait tile 0)', 'K tile 0', 'K tile 1', 'K tiles 2-3', 'K tiles 4..nk-1',
+             'stagger balance barrier', 'epilogue (bias + stores + drain)']
+    tot = (s[:, :, 7] - s[:, :, 0])
+    print('N=%d K=%d blocks=%d; s_memtime ticks (100 MHz reference? see guide: tick = shader cycle)' % (n, k, nblk))
+    for wrow in (0, 1):
+        print(' wave row %d: total median %d  p10 %d  p90 %d' % (wrow, np.median(tot[:, wrow]),
+                                                                   np.percentile(tot[:, wrow], 10),
+                                                                   np.percentile(tot[:, wrow], 90)))
+        for i, nm in enumerate(names):
+            v = d[:, wrow, i]
+            print('   %-40s median %7d  p10 %7d  p90 %7d  share %5.1f%%' % (nm, np.median(v), np.percentile(v, 10),
+                                                                            np.percentile(v, 90),
+                                                                            100.0 * v.sum() / tot[:, wrow].sum()))
+    # first-round blocks vs later rounds
+    first = tot[:256, 0]
+    later = tot[256:, 0]
+    print(' first 256 blocks total median %d, later blocks %d' % (np.median(first), np.median(later) if len(later) else -1))
+    span = s[:, :, 7].max() - s[:, :, 0].min()
+    print(' kernel span (first start -> last end): %d ticks' % span)
+
+
+if __name__ == '__main__':
+    main()

@@ -48,9 +48,12 @@ def main():
             R = torch.zeros(Mx, n, device=DEV)
             fn = lambda: _lib.call('mvf_gemm_tc', code, epi, A.data_ptr(), k, W.data_ptr(), k, b.data_ptr(), Cc.data_ptr(),
                                    n, R.data_ptr(), n, None, 0, None, None, N, Mx, n, k, S())
-            t = timeit(fn)
-            print('gemm_tc %-5s %-4s M=%6d N=%4d K=%4d  %8.1f us  %7.1f TFLOP/s' % (dtype, name, Mx, n, k, t * 1e6,
-                                                                                     2.0 * Mx * n * k / t / 1e12))
+            for variant in ((1, 2) if dtype == 'bf16' else (1,)):
+                _lib.call('mvf_gemm_tc_select', variant)
+                t = timeit(fn)
+                _lib.call('mvf_gemm_tc_select', 0)
+                print('gemm_tc%s %-5s %-4s M=%6d N=%4d K=%4d  %8.1f us  %7.1f TFLOP/s' % (
+                    '256' if variant == 2 else '128', dtype, name, Mx, n, k, t * 1e6, 2.0 * Mx * n * k / t / 1e12))
         qkv = torch.randn(Mx, 3 * D, device=DEV).to(tdt)
         out = torch.empty(Mx, D, device=DEV, dtype=tdt)
         for variant in ((0, 1) if dtype == 'bf16' else (0,)):

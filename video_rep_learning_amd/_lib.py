@@ -21,6 +21,8 @@ SIGNATURES = {
     'mvf_prof_enable': 'i',
     'mvf_prof_collect': 'ppp',
     'mvf_gemm_tc': 'iipipippipipippiiiip',
+    'mvf_gemm_tc_select': 'i',
+    'mvf_gemm_tc_debug_stamps': 'p',
     'mvf_patchify': 'ippiiiip',
     'mvf_layernorm_fwd': 'ipzpppziifp',
     'mvf_vit_attn_fwd': 'ippiiiiip',

@@ -30,17 +30,14 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even; NaN stays NaN (plain compiler cast path keeps NaNs, see MI355X guide)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
-
+// fp32 -> bf16, round-to-nearest-even, NaN stays NaN: the plain cast compiles to v_cvt_pk_bf16_f32 on gfx950
+// (one instruction per TWO elements; the integer bit-trick costs ~6 VALU per element and mangles some NaNs).
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_native_t;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const bf16x2_native_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 template <typename T>
 struct Elem;

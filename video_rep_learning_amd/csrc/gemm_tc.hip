@@ -16,42 +16,17 @@
 //  * 1-D grid with a bijective XCD-aware remap: workgroups that share an A row-panel land on one XCD's L2
 #include "common.h"
 #include "mvf_hip_internal.h"
+#include "gemm_tc_epi.h"
 
 namespace {
+using namespace gemm_tc;
+int g_variant = 0;
+unsigned long long* g_dbg = nullptr;
 
 constexpr int BM = 128, BN = 128, ROWB = 128;
 constexpr int TILE_BYTES = BM * ROWB;          // 16 KiB per operand per stage
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + W
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;     // 64 KiB -> 2 workgroups / CU
-
-enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
-
-struct GemmTcArgs {
-  const char* A;
-  const char* W;
-  const float* bias;
-  char* C;
-  float* resid;
-  char* tap;
-  const float* pos;
-  const float* ls;  // EPI_RESID: optional LayerScale gamma[N] (DINOv2 ls1/ls2)
-  int lda, ldw, ldc, ldr, ldt;
-  int M, N, K;
-  int tpf;  // tokens per frame (1 + patches)
-};
-
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-
-template <typename T>
-__device__ __forceinline__ void store4(char* base, size_t elem_off, const float (&v)[4]);
-template <>
-__device__ __forceinline__ void store4<float>(char* base, size_t elem_off, const float (&v)[4]) {
-  *reinterpret_cast<float4*>(base + elem_off * 4) = make_float4(v[0], v[1], v[2], v[3]);
-}
-template <>
-__device__ __forceinline__ void store4<bf16_t>(char* base, size_t elem_off, const float (&v)[4]) {
-  *reinterpret_cast<uint2*>(base + elem_off * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-}
 
 template <typename T, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_tc_kernel(GemmTcArgs a) {
@@ -151,52 +126,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tc_kernel(GemmTcArgs a) {
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wr * 64 + i * 16 + frow;
     if (m >= a.M) continue;
-    size_t out_row = (size_t)m;
-    int tap_row = -1;
-    const float* posrow = nullptr;
-    if constexpr (EPI == EPI_PATCH) {
-      const int np = a.tpf - 1;
-      const int f = m / np, p = m - f * np;
-      out_row = (size_t)f * a.tpf + 1 + p;
-      posrow = a.pos + (size_t)(1 + p) * a.N;
-    }
-    if constexpr (EPI == EPI_RESID) {
-      if (a.tap != nullptr) {
-        const int f = m / a.tpf, t = m - f * a.tpf;
-        if (t > 0) tap_row = f * (a.tpf - 1) + t - 1;
-      }
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wc * 64 + j * 16 + fgrp * 4;
       if (n >= a.N) continue;
-      float v[4];
-      float4 b = a.bias ? *reinterpret_cast<const float4*>(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-      v[0] = acc[i][j][0] + b.x;
-      v[1] = acc[i][j][1] + b.y;
-      v[2] = acc[i][j][2] + b.z;
-      v[3] = acc[i][j][3] + b.w;
-      if constexpr (EPI == EPI_STORE) {
-        store4<T>(a.C, out_row * a.ldc + n, v);
-      } else if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-        store4<T>(a.C, out_row * a.ldc + n, v);
-      } else if constexpr (EPI == EPI_RESID) {
-        float* rp = a.resid + out_row * a.ldr + n;
-        if (a.ls != nullptr) {
-          const float4 gm = *reinterpret_cast<const float4*>(a.ls + n);
-          v[0] *= gm.x; v[1] *= gm.y; v[2] *= gm.z; v[3] *= gm.w;
-        }
-        float4 o = *reinterpret_cast<const float4*>(rp);
-        v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-        *reinterpret_cast<float4*>(rp) = make_float4(v[0], v[1], v[2], v[3]);
-        if (tap_row >= 0) store4<T>(a.tap, (size_t)tap_row * a.ldt + n, v);
-      } else {  // EPI_PATCH
-        float4 pe = *reinterpret_cast<const float4*>(posrow + n);
-        v[0] += pe.x; v[1] += pe.y; v[2] += pe.z; v[3] += pe.w;
-        *reinterpret_cast<float4*>(a.resid + out_row * a.ldr + n) = make_float4(v[0], v[1], v[2], v[3]);
-      }
+      epilogue4<T, EPI>(a, m, n, acc[i][j]);
     }
   }
 }
@@ -246,5 +180,22 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
   GemmTcArgs a;
   a.A = (const char*)A; a.W = (const char*)W; a.bias = bias; a.C = (char*)C; a.resid = resid; a.tap = (char*)tap;
   a.pos = pos; a.ls = ls; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.ldt = ldt; a.M = M; a.N = N; a.K = K; a.tpf = tpf;
+  a.dbg = g_dbg;
+  // bf16 with K a multiple of 128: the 256x256 8-phase kernel (gemm_tc256.hip); g_variant 1 pins the 128x128 kernel
+  if (dtype == MVF_BF16 && g_variant != 1 && K % 128 == 0 && N % 32 == 0) return mvf_gemm_tc256_launch(epi, a, st);
+  if (g_variant == 2) return MVF_ERR_UNSUPPORTED;
   return dtype == MVF_BF16 ? dispatch<bf16_t>(epi, a, st) : dispatch<float>(epi, a, st);
+}
+
+// 0 = automatic choice, 1 = always the 128x128 kernel, 2 = only the 256x256 kernel (error where it does not apply)
+// diagnostic: stamps buffer [blocks][2][8] u64 for the gemm_tc256 DBG build (null = product kernels)
+extern "C" int mvf_gemm_tc_debug_stamps(unsigned long long* buf) {
+  g_dbg = buf;
+  return MVF_OK;
+}
+
+extern "C" int mvf_gemm_tc_select(int variant) {
+  MVF_CHECK_ARG(variant >= 0 && variant <= 2);
+  g_variant = variant;
+  return MVF_OK;
 }

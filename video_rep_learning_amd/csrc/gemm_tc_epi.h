@@ -1,0 +1,163 @@
+// Shared between the two backbone GEMM kernels (gemm_tc.hip: 128x128 tile, both dtypes; gemm_tc256.hip: 256x256
+// 8-phase bf16): the argument block and the fused epilogues (bias / GELU / residual+LayerScale+tap / patch+pos).
+#pragma once
+#include "common.h"
+
+namespace gemm_tc {
+
+enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
+
+struct GemmTcArgs {
+  const char* A;
+  const char* W;
+  const float* bias;
+  char* C;
+  float* resid;
+  char* tap;
+  const float* pos;
+  const float* ls;  // EPI_RESID: optional LayerScale gamma[N] (DINOv2 ls1/ls2)
+  int lda, ldw, ldc, ldr, ldt;
+  int M, N, K;
+  int tpf;  // tokens per frame (1 + patches)
+  unsigned long long* dbg;  // diagnostic stamps (gemm_tc256 DBG build only), normally null
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// GELU for bf16 outputs: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below bf16's 2^-9 rounding) on the
+// hardware exp2/rcp: ~14 VALU per element instead of erff's ~45 -- the exact-erf epilogue cost a third of the fc1 GEMM.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+  const float erf_abs = fmaf(-p, e, 1.0f);                 // erf(|x|/sqrt2)
+  return 0.5f * x + 0.5f * fabsf(x) * erf_abs;             // 0.5 x (1 + sign(x) erf_abs)
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(char* base, size_t elem_off, const float (&v)[4]);
+template <>
+__device__ __forceinline__ void store4<float>(char* base, size_t elem_off, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(base + elem_off * 4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <>
+__device__ __forceinline__ void store4<bf16_t>(char* base, size_t elem_off, const float (&v)[4]) {
+  *reinterpret_cast<uint2*>(base + elem_off * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+}
+
+
+// One lane's 4 consecutive output columns (n .. n+3) of row m: bias + the epilogue selected by EPI.
+template <typename T, int EPI>
+__device__ __forceinline__ void epilogue4(const GemmTcArgs& a, int m, int n, const f32x4_t& acc) {
+  size_t out_row = (size_t)m;
+  float v[4];
+  const float4 b = a.bias ? *reinterpret_cast<const float4*>(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  v[0] = acc[0] + b.x;
+  v[1] = acc[1] + b.y;
+  v[2] = acc[2] + b.z;
+  v[3] = acc[3] + b.w;
+  if constexpr (EPI == EPI_STORE) {
+    store4<T>(a.C, out_row * a.ldc + n, v);
+  } else if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = sizeof(T) == 2 ? gelu_erf_fast(v[r]) : gelu_erf(v[r]);   // fp32 parity mode: exact erf
+    store4<T>(a.C, out_row * a.ldc + n, v);
+  } else if constexpr (EPI == EPI_RESID) {
+    float* rp = a.resid + out_row * a.ldr + n;
+    if (a.ls != nullptr) {
+      const float4 gm = *reinterpret_cast<const float4*>(a.ls + n);
+      v[0] *= gm.x; v[1] *= gm.y; v[2] *= gm.z; v[3] *= gm.w;
+    }
+    const float4 o = *reinterpret_cast<const float4*>(rp);
+    v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+    *reinterpret_cast<float4*>(rp) = make_float4(v[0], v[1], v[2], v[3]);
+    if (a.tap != nullptr) {  // tapped block output, CLS row dropped
+      const int f = m / a.tpf, t = m - f * a.tpf;
+      if (t > 0) store4<T>(a.tap, (size_t)(f * (a.tpf - 1) + t - 1) * a.ldt + n, v);
+    }
+  } else {  // EPI_PATCH: row m = (frame f, patch p) -> token row f*tpf + 1 + p, + pos_embed[1+p]
+    const int np = a.tpf - 1;
+    const int f = m / np, p = m - f * np;
+    out_row = (size_t)f * a.tpf + 1 + p;
+    const float4 pe = *reinterpret_cast<const float4*>(a.pos + (size_t)(1 + p) * a.N + n);
+    v[0] += pe.x; v[1] += pe.y; v[2] += pe.z; v[3] += pe.w;
+    *reinterpret_cast<float4*>(a.resid + out_row * a.ldr + n) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// ---- bf16 epilogue of TWO adjacent 16x16 accumulator tiles (columns nb .. nb+31 of row m), gemm_tc256 ----
+// In the swapped-operand MFMA layout lane (frow, fgrp) holds 4 consecutive columns 4*fgrp.. of each tile: 8-byte bf16
+// stores, 32-byte row segments, and twice the store instructions -- the epilogue was store-ISSUE bound (40 % of a
+// K=768 tile).  One v_permlane16_swap per dword exchanges the lane rows fgrp 1<->0 and 3<->2 between the two tiles'
+// registers, after which every lane owns 8 consecutive columns (fgrp 0/2: tile 0 cols 0-7 / 8-15, fgrp 1/3: tile 1):
+// one 16-byte store per lane, 64-byte row segments, half the store instructions, no LDS round trip.
+// Cross-lane: EVERY lane must execute the swaps (rows m >= M are only masked at the store).
+__device__ __forceinline__ void swap_store_bf16x8(char* base, size_t row_elem_off, int nb, int fgrp, bool ok,
+                                                   const float (&v0)[4], const float (&v1)[4]) {
+  uint32_t x0 = pack_bf16x2(v0[0], v0[1]), x1 = pack_bf16x2(v0[2], v0[3]);
+  uint32_t y0 = pack_bf16x2(v1[0], v1[1]), y1 = pack_bf16x2(v1[2], v1[3]);
+  const auto r0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+  const auto r1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+  if (ok) {
+    const int col = nb + (fgrp & 1) * 16 + (fgrp >> 1) * 8;
+    *reinterpret_cast<uint4*>(base + (row_elem_off + col) * 2) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+  }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_pair_bf16(const GemmTcArgs& a, int m, bool ok, int nb, int fgrp,
+                                                   const f32x4_t& acc0, const f32x4_t& acc1, const float4& b0,
+                                                   const float4& b1) {
+  float v0[4] = {acc0[0] + b0.x, acc0[1] + b0.y, acc0[2] + b0.z, acc0[3] + b0.w};
+  float v1[4] = {acc1[0] + b1.x, acc1[1] + b1.y, acc1[2] + b1.z, acc1[3] + b1.w};
+  const int n0 = nb + fgrp * 4, n1 = nb + 16 + fgrp * 4;   // this lane's own columns in the two tiles
+  if constexpr (EPI == EPI_STORE) {
+    swap_store_bf16x8(a.C, (size_t)m * a.ldc, nb, fgrp, ok, v0, v1);
+  } else if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v0[r] = gelu_erf_fast(v0[r]); v1[r] = gelu_erf_fast(v1[r]); }
+    swap_store_bf16x8(a.C, (size_t)m * a.ldc, nb, fgrp, ok, v0, v1);
+  } else if constexpr (EPI == EPI_RESID) {
+    bool tap_ok = false;
+    size_t tap_off = 0;
+    if (ok) {
+      float* rp = a.resid + (size_t)m * a.ldr;
+      if (a.ls != nullptr) {
+        const float4 g0 = *reinterpret_cast<const float4*>(a.ls + n0), g1 = *reinterpret_cast<const float4*>(a.ls + n1);
+        v0[0] *= g0.x; v0[1] *= g0.y; v0[2] *= g0.z; v0[3] *= g0.w;
+        v1[0] *= g1.x; v1[1] *= g1.y; v1[2] *= g1.z; v1[3] *= g1.w;
+      }
+      const float4 o0 = *reinterpret_cast<const float4*>(rp + n0), o1 = *reinterpret_cast<const float4*>(rp + n1);
+      v0[0] += o0.x; v0[1] += o0.y; v0[2] += o0.z; v0[3] += o0.w;
+      v1[0] += o1.x; v1[1] += o1.y; v1[2] += o1.z; v1[3] += o1.w;
+      *reinterpret_cast<float4*>(rp + n0) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+      *reinterpret_cast<float4*>(rp + n1) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+      if (a.tap != nullptr) {  // tapped block output, CLS row dropped
+        const int f = m / a.tpf, t = m - f * a.tpf;
+        tap_ok = t > 0;
+        tap_off = (size_t)(f * (a.tpf - 1) + t - 1) * a.ldt;
+      }
+    }
+    if (a.tap != nullptr) swap_store_bf16x8(a.tap, tap_off, nb, fgrp, tap_ok, v0, v1);   // wave-uniform branch
+  } else {  // EPI_PATCH: row m = (frame f, patch p) -> token row f*tpf + 1 + p, + pos_embed[1+p]
+    if (ok) {
+      const int np = a.tpf - 1;
+      const int f = m / np, p = m - f * np;
+      const float* pr = a.pos + (size_t)(1 + p) * a.N;
+      float* rp = a.resid + ((size_t)f * a.tpf + 1 + p) * a.ldr;
+      const float4 p0 = *reinterpret_cast<const float4*>(pr + n0), p1 = *reinterpret_cast<const float4*>(pr + n1);
+      *reinterpret_cast<float4*>(rp + n0) = make_float4(v0[0] + p0.x, v0[1] + p0.y, v0[2] + p0.z, v0[3] + p0.w);
+      *reinterpret_cast<float4*>(rp + n1) = make_float4(v1[0] + p1.x, v1[1] + p1.y, v1[2] + p1.z, v1[3] + p1.w);
+    }
+  }
+}
+
+}  // namespace gemm_tc
+
+// gemm_tc256.hip: bf16, K % 128 == 0.  Same contract as the 128x128 kernel's launch.
+int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, hipStream_t st);

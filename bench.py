@@ -25,8 +25,24 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md (no 2:1 sparsity)
 TFLOP_PER_CLIP = 1.1925       # algorithmic work of config #2 per clip (fwd backbone + f/b head)
-EPI_NAMES = {0: 'gemm_tc<bf16,STORE> (qkv)', 1: 'gemm_tc<bf16,GELU> (fc1)', 2: 'gemm_tc<bf16,RESID> (proj+fc2)',
-             3: 'gemm_tc<bf16,PATCH> (patch-embed)'}
+PEAK_F32_TFLOPS = 157.3       # fp32-input MFMA (= vector) peak, parity mode
+# (epilogue kind, N, K) of the ViT-B/16 GEMMs; M = frames * 197 (patch-embed: frames * 196)
+GEMM_NAMES = {(0, 2304, 768): 'qkv [M,768]x[2304,768]^T', (2, 768, 768): 'proj+resid [M,768]x[768,768]^T',
+              (1, 3072, 768): 'fc1+gelu [M,768]x[3072,768]^T', (2, 768, 3072): 'fc2+resid [M,3072]x[768,3072]^T',
+              (3, 768, 768): 'patch-embed+pos [M,768]x[768,768]^T'}
+PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+
+
+def pmc_traffic(name):
+    """HBM bytes per launch of the named GEMM shape from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
+    written by tools/pmc_summary.py from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of tools/gemm_bench.py:
+    2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md section HBM).  None when not collected."""
+    try:
+        with open(PMC_FILE) as f:
+            rec = json.load(f).get(name)
+        return None if rec is None else rec['hbm_bytes_per_launch']
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def parse():
@@ -37,6 +53,7 @@ def parse():
     p.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--profile-steps', type=int, default=3)
+    p.add_argument('--no-lookahead', action='store_true', help='run backbone and head strictly in sequence')
     return p.parse_args()
 
 
@@ -100,6 +117,11 @@ def main():
     clip = cfg.OPTIMIZER.GRAD_CLIP
 
     def step():
+        # one-batch lookahead as in train.train(): the frozen-backbone forward of the NEXT batch is started on the side
+        # stream before this batch's head work is enqueued (every step still runs exactly one backbone forward and one
+        # head forward/backward/update; the resident synthetic batch is the same tensor each step)
+        if not a.no_lookahead:
+            wrapped.prefetch(videos)
         opt.zero_grad()
         loss = algo.compute_loss(wrapped, videos, seq_lens, steps, masks)['loss']
         loss.backward()
@@ -134,18 +156,29 @@ def main():
             step()
         torch.cuda.synchronize()
         _lib.call('mvf_prof_enable', 0)
-        ms, fl, cnt = (ctypes.c_double * 4)(), (ctypes.c_double * 4)(), (ctypes.c_int * 4)()
-        _lib.call('mvf_prof_collect', ms, fl, cnt)
-        dom = max(range(4), key=lambda e: ms[e])
-        ach = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
-        tot_ms, tot_fl = sum(ms), sum(fl)
-        roof = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS if a.dtype == 'bf16' else 157.3,
-                'unit': 'TFLOP/s', 'frac': round(ach / (PEAK_BF16_TFLOPS if a.dtype == 'bf16' else 157.3), 4), 'traffic': None,
-                'kernel': EPI_NAMES[dom], 'launches': cnt[dom], 'avg_launch_us': round(ms[dom] * 1e3 / max(cnt[dom], 1), 1),
-                'flop_per_launch': fl[dom] / max(cnt[dom], 1),
-                'all_gemm': {'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 1), 'ms_per_step': round(tot_ms / max(a.profile_steps, 1), 3)},
-                'by_kernel': {EPI_NAMES[e]: {'launches': cnt[e], 'avg_us': round(ms[e] * 1e3 / max(cnt[e], 1), 1),
-                                             'tflops': round(fl[e] / (ms[e] * 1e-3) / 1e12, 1) if ms[e] > 0 else 0.0} for e in range(4)}}
+        G = 16
+        ms, fl = (ctypes.c_double * G)(), (ctypes.c_double * G)()
+        cnt, epi, nn, kk = (ctypes.c_int * G)(), (ctypes.c_int * G)(), (ctypes.c_int * G)(), (ctypes.c_int * G)()
+        ng = ctypes.c_int(0)
+        _lib.call('mvf_prof_collect', ms, fl, cnt, epi, nn, kk, G, ctypes.byref(ng))
+        groups = []
+        for g in range(ng.value):
+            name = GEMM_NAMES.get((epi[g], nn[g], kk[g]), 'gemm epi%d N=%d K=%d' % (epi[g], nn[g], kk[g]))
+            groups.append({'name': name, 'launches': cnt[g], 'ms': ms[g], 'flop': fl[g],
+                           'avg_us': round(ms[g] * 1e3 / max(cnt[g], 1), 1),
+                           'tflops': round(fl[g] / (ms[g] * 1e-3) / 1e12, 1) if ms[g] > 0 else 0.0})
+        dom = max(groups, key=lambda r: r['ms'])       # the GEMM shape the step spends most time in
+        peak = PEAK_BF16_TFLOPS if a.dtype == 'bf16' else PEAK_F32_TFLOPS
+        ach = dom['flop'] / (dom['ms'] * 1e-3) / 1e12
+        tot_ms, tot_fl = sum(r['ms'] for r in groups), sum(r['flop'] for r in groups)
+        kern = ('gemm_tc256_kernel' if a.dtype == 'bf16' else 'gemm_tc_kernel<float>') + ' / ' + dom['name']
+        roof = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                'traffic': pmc_traffic(dom['name']), 'kernel': kern, 'launches': dom['launches'],
+                'avg_launch_us': dom['avg_us'], 'flop_per_launch': dom['flop'] / max(dom['launches'], 1),
+                'all_gemm': {'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 1), 'frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4),
+                             'ms_per_step': round(tot_ms / max(a.profile_steps, 1), 3)},
+                'by_kernel': {r['name']: {'launches': r['launches'], 'avg_us': r['avg_us'], 'tflops': r['tflops']}
+                              for r in groups}}
     if world > 1:
         dist.barrier()
 

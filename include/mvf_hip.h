@@ -66,10 +66,12 @@ int mvf_vit_fwd(const MvfVitWeights* w, int dtype, const float* frames, int F, v
                 void* workspace, size_t ws_bytes, int frames_per_chunk, int attn_variant, hipStream_t stream);
 
 /* measurement hooks (bench.py roofline): when enabled, every GEMM launch of mvf_vit_fwd is bracketed by HIP events
- * on the launch stream; collect() waits for them and returns, per epilogue kind 0..3, the summed device
- * milliseconds, the summed algorithmic FLOPs (2*M*N*K) and the launch count.  Not for use under graph capture. */
+ * on the launch stream; collect() waits for them and returns, per GEMM shape (epilogue kind, N, K) -- group g <
+ * *n_groups -- the summed device milliseconds, the summed algorithmic FLOPs (2*M*N*K) and the launch count.  Not for
+ * use under graph capture. */
 int mvf_prof_enable(int on);
-int mvf_prof_collect(double* ms_host, double* flops_host, int* count_host);
+int mvf_prof_collect(double* ms_host, double* flops_host, int* count_host, int* epi_host, int* n_host, int* k_host,
+                     int max_groups, int* n_groups_host);
 
 /* pieces of the same path, exported for unit parity tests */
 int mvf_gemm_tc(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,

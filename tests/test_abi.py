@@ -1,0 +1,56 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports exactly the
+entry points include/mvf_hip.h declares with the argument kinds the ctypes binding assumes.  No compute calls
+(there is no GPU here); bad-argument paths that return before any launch ARE exercised."""
+import ctypes
+import os
+
+import pytest
+
+from abi_util import header_signatures, ROOT
+from video_rep_learning_amd import _lib
+
+
+@pytest.fixture(scope='module')
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        from video_rep_learning_amd.csrc import build
+        build.build()
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    decl = header_signatures()
+    assert len(decl) >= 37
+    for name, kinds in decl.items():
+        assert hasattr(lib, name), 'declared in include/mvf_hip.h but not exported: %s' % name
+        assert name in _lib.SIGNATURES, 'no ctypes signature for %s' % name
+        assert _lib.SIGNATURES[name] == kinds, (name, _lib.SIGNATURES[name], kinds)
+    assert set(_lib.SIGNATURES) == set(decl), set(_lib.SIGNATURES) ^ set(decl)
+
+
+def test_header_cites_the_reference():
+    src = open(os.path.join(ROOT, 'include', 'mvf_hip.h')).read()
+    for cite in ('models/transformer.py', 'models/mvformer.py', 'models/utils.py', 'algos/scl.py', 'train.py',
+                 'utils/optimizer.py', 'resnet_c2d.py'):
+        assert cite in src, cite
+
+
+def test_argument_errors_are_reported_before_any_launch(lib):
+    # NULL pointers / bad shapes are rejected on the host with MVF_ERR_ARG (10001) -- no GPU needed
+    assert lib.mvf_gemm_tc(_lib.BF16, 0, None, 0, None, 0, None, None, 0, None, 0, None, 0, None, None, 0, 0, 0, 0, None) == 10001
+    assert lib.mvf_scl_fwd(None, None, None, None, None, None, None, None, None, 0, 0, 0, 0, 0.1, 10.0, None) == 10001
+    assert lib.mvf_gemm_tc_select(7) == 10001
+    assert lib.mvf_gemm_tc_select(0) == 0
+    assert lib.mvf_vit_workspace_bytes(_lib.BF16, 256, 197, 768, 16) >= 256 * 197 * 768 * (4 + 2 + 6 + 8)
+    with pytest.raises(_lib.MvfError):
+        _lib.call('mvf_layernorm_fwd', 0, None, 0, None, None, None, 0, 0, 0, 1e-6, None)
+
+
+def test_product_path_refuses_cpu_tensors():
+    import torch
+    from video_rep_learning_amd import ops
+    x = torch.randn(4, 8)
+    with pytest.raises(_lib.MvfError):
+        ops.linear(x, torch.randn(3, 8))
+    with pytest.raises(_lib.MvfError):
+        ops.vit_forward(torch.randn(1, 3, 32, 32), None)

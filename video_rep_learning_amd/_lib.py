@@ -19,7 +19,7 @@ SIGNATURES = {
     'mvf_vit_workspace_bytes': 'iiiii',
     'mvf_vit_fwd': 'pipipppziip',
     'mvf_prof_enable': 'i',
-    'mvf_prof_collect': 'ppp',
+    'mvf_prof_collect': 'ppppppip',
     'mvf_gemm_tc': 'iipipippipipippiiiip',
     'mvf_gemm_tc_select': 'i',
     'mvf_gemm_tc_debug_stamps': 'p',

@@ -24,7 +24,7 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct Prof {
   bool on = false;
   std::vector<hipEvent_t> ev;   // pairs
-  std::vector<int> epi;
+  std::vector<int> epi, n, k;
   std::vector<double> flops;
   size_t used = 0;
 } g_prof;
@@ -42,9 +42,13 @@ int timed_gemm(int dtype, int epi, const void* A, int lda, const void* W, int ld
       g_prof.ev.push_back(a);
       g_prof.ev.push_back(b);
       g_prof.epi.push_back(0);
+      g_prof.n.push_back(0);
+      g_prof.k.push_back(0);
       g_prof.flops.push_back(0.0);
     }
     g_prof.epi[slot] = epi;
+    g_prof.n[slot] = N;
+    g_prof.k[slot] = K;
     g_prof.flops[slot] = 2.0 * M * (double)N * K;
     (void)hipEventRecord(g_prof.ev[2 * slot], st);
   }
@@ -137,17 +141,27 @@ extern "C" int mvf_prof_enable(int on) {
   if (on) g_prof.used = 0;
   return MVF_OK;
 }
-// per epilogue kind e in 0..3: ms[e] = summed device time, flops[e] = summed 2*M*N*K, count[e] = launches
-extern "C" int mvf_prof_collect(double* ms, double* flops, int* count) {
-  MVF_CHECK_ARG(ms && flops && count);
-  for (int e = 0; e < 4; ++e) { ms[e] = 0.0; flops[e] = 0.0; count[e] = 0; }
+// launches are grouped by (epilogue kind, N, K) = one GEMM shape of the backbone: for group g < *n_groups,
+// ms[g] = summed device time, flops[g] = summed 2*M*N*K, count[g] = launches, epi/n/k[g] = the key
+extern "C" int mvf_prof_collect(double* ms, double* flops, int* count, int* epi, int* n, int* k, int max_groups,
+                                int* n_groups) {
+  MVF_CHECK_ARG(ms && flops && count && epi && n && k && n_groups && max_groups > 0);
+  int ng = 0;
   for (size_t i = 0; i < g_prof.used; ++i) {
     if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return MVF_ERR_ARG;
     float t = 0.f;
     if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return MVF_ERR_ARG;
-    const int e = g_prof.epi[i];
-    ms[e] += t; flops[e] += g_prof.flops[i]; count[e] += 1;
+    int g = 0;
+    while (g < ng && !(epi[g] == g_prof.epi[i] && n[g] == g_prof.n[i] && k[g] == g_prof.k[i])) ++g;
+    if (g == ng) {
+      if (ng == max_groups) continue;
+      epi[g] = g_prof.epi[i]; n[g] = g_prof.n[i]; k[g] = g_prof.k[i];
+      ms[g] = 0.0; flops[g] = 0.0; count[g] = 0;
+      ++ng;
+    }
+    ms[g] += t; flops[g] += g_prof.flops[i]; count[g] += 1;
   }
+  *n_groups = ng;
   return MVF_OK;
 }
 

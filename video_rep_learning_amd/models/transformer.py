@@ -89,11 +89,54 @@ class TransformerModel(nn.Module):
         self.backbone.eval()       # transformer.py:186: the frozen backbone always runs in eval()
         return self
 
+    # ---- backbone pipeline: the frozen ViT runs on its own HIP stream, optionally one batch ahead of the head ----
+    # The backbone has no trainable state, so the ViT forward of batch i+1 does not depend on the optimizer step of
+    # batch i: `prefetch(x_next)` enqueues it on the side stream while the (latency-bound, mostly-idle-CU) head
+    # forward/backward of batch i runs on the caller's stream.  `forward(x)` consumes the oldest prefetched result
+    # for the same tensor, or launches the backbone itself when there is none -- the numbers are identical either way.
+    @staticmethod
+    def _key(x):
+        return (x.data_ptr(), tuple(x.shape), x._version)
+
+    def _launch_backbone(self, x, ready_event=None):
+        bc, t, c, h, w = x.shape
+        cur = torch.cuda.current_stream(x.device)
+        if getattr(self, '_side', None) is None or self._side.device != x.device:
+            self._side = torch.cuda.Stream(device=x.device)
+        if ready_event is None:            # "x is ready": everything enqueued on the caller's stream so far
+            ready_event = torch.cuda.Event()
+            ready_event.record(cur)
+        self._side.wait_event(ready_event)
+        with torch.cuda.stream(self._side):
+            taps, cls = self.backbone(x.reshape(bc * t, c, h, w), dtype=self.compute_dtype,
+                                      frames_per_chunk=self.frames_per_chunk)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        x.record_stream(self._side)
+        return taps, cls, done
+
+    def prefetch(self, x, ready_event=None):
+        """Enqueue the backbone forward of x [Bc, T, 3, H, W] (the NEXT batch) on the side stream.  Call it right after
+        x has been produced and BEFORE enqueuing the current batch's head work, or pass the event that marks x ready."""
+        if not x.is_cuda:
+            raise ops._lib.MvfError('prefetch received a %s tensor (no CPU fallback)' % x.device)
+        if not hasattr(self, '_stash'):
+            self._stash = []
+        self._stash.append((self._key(x),) + self._launch_backbone(x, ready_event))
+
     def features(self, x):
         """[Bc, T, 3, H, W] -> (Taps, cls_emb [Bc*T, D])."""
         bc, t, c, h, w = x.shape
-        taps, cls = self.backbone(x.reshape(bc * t, c, h, w), dtype=self.compute_dtype,
-                                  frames_per_chunk=self.frames_per_chunk)
+        key, hit = self._key(x), None
+        for i, e in enumerate(getattr(self, '_stash', [])):
+            if e[0] == key:
+                hit = self._stash.pop(i)
+                break
+        taps, cls, done = hit[1:] if hit is not None else self._launch_backbone(x)
+        cur = torch.cuda.current_stream(x.device)
+        cur.wait_event(done)
+        for tns in list(taps) + ([cls] if cls is not None else []):
+            tns.record_stream(cur)
         ntok = (h // self.backbone.model.patch_size) * (w // self.backbone.model.patch_size)
         return Taps(taps, bc, t, ntok), cls
 

@@ -165,6 +165,24 @@ def _world(group):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def sync_bn_stats(mean, var, count, group=None):
+    """Cross-rank batch statistics for SyncBatchNorm (train.py:283): every rank contributes (mean, biased var, row
+    count) of its local rows -- 2C+1 floats, collective C2 of SURVEY.md -- and all ranks merge them with Chan's
+    parallel-variance formula, which equals BatchNorm statistics over the rank-concatenated batch.
+    Plain torch + torch.distributed (no kernel): runs on gloo/CPU in the tests and on RCCL in training."""
+    C = mean.numel()
+    world = dist.get_world_size(group)
+    local = torch.cat([mean, var, mean.new_tensor([float(count)])])
+    gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local, group=group)
+    st = torch.stack(gathered)
+    n = st[:, -1:]
+    total = float(n.sum())
+    gm = (st[:, :C] * n).sum(0) / total
+    gv = ((st[:, C:2 * C] + (st[:, :C] - gm) ** 2) * n).sum(0) / total
+    return gm.contiguous(), gv.contiguous(), total
+
+
 class _BatchNormTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, g, b, running_mean, running_var, momentum, eps, relu, sync, group):
@@ -177,15 +195,7 @@ class _BatchNormTrain(torch.autograd.Function):
         world = _world(group) if sync else 1
         if world > 1:
             # exchange (mean, biased var, count) and merge (Chan); 2C+1 floats per rank -- collective C2 of SURVEY.md
-            local = torch.cat([mean, var, mean.new_tensor([count])])
-            gathered = [torch.empty_like(local) for _ in range(world)]
-            dist.all_gather(gathered, local, group=group)
-            st = torch.stack(gathered)
-            n = st[:, -1:]
-            count = float(n.sum())
-            gm = (st[:, :C] * n).sum(0) / count
-            gv = ((st[:, C:2 * C] + (st[:, :C] - gm) ** 2) * n).sum(0) / count
-            mean, var = gm.contiguous(), gv.contiguous()
+            mean, var, count = sync_bn_stats(mean, var, count, group)
         with torch.no_grad():
             running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
             running_var.mul_(1 - momentum).add_(var, alpha=momentum * count / max(count - 1.0, 1.0))

@@ -48,6 +48,12 @@ class DataParallelModel(nn.Module):
     def forward(self, *a, **kw):
         return self.module(*a, **kw)
 
+    def prefetch(self, videos):
+        """videos [B, V, T, 3, H, W] of the NEXT iteration: start its frozen-backbone forward on the side stream."""
+        if hasattr(self.module, 'prefetch') and videos.is_cuda:
+            b, v = videos.shape[:2]
+            self.module.prefetch(videos.view(b * v, *videos.shape[2:]))
+
 
 class ScalarWriter:
     """Minimal SummaryWriter stand-in (tensorboard is not a dependency): scalars -> LOGDIR/train_logs/scalars.jsonl."""
@@ -73,10 +79,21 @@ def train(cfg, train_loader, model, optimizer, scheduler, algo, cur_epoch, summa
         model.module.embed.set_warmup_status(cur_epoch < cfg.TRAIN.BACKBONE_WARMUP)
     total = {}      # device-side running sums of the per-iteration (NaN -> 0) local losses
     loss = None
-    for cur_iter, (videos, _labels, seq_lens, chosen_steps, video_masks, names) in enumerate(train_loader):
-        if max_iters and cur_iter >= max_iters:
-            break
-        videos = synthetic.preproc_views(videos[0], videos[1], data_preprocess, device)
+    # one-batch lookahead: batch i+1 is fetched + augmented, and its frozen-backbone forward is started on the side
+    # stream, BEFORE the head work of batch i is enqueued (models/transformer.py "backbone pipeline")
+    def batches():
+        for cur_iter, (videos, _labels, seq_lens, chosen_steps, video_masks, names) in enumerate(train_loader):
+            if max_iters and cur_iter >= max_iters:
+                return
+            videos = synthetic.preproc_views(videos[0], videos[1], data_preprocess, device)
+            if hasattr(model, 'prefetch'):
+                model.prefetch(videos)
+            yield cur_iter, videos, seq_lens, chosen_steps, video_masks
+    stream_it = batches()
+    nxt = next(stream_it, None)
+    while nxt is not None:
+        cur_iter, videos, seq_lens, chosen_steps, video_masks = nxt
+        nxt = next(stream_it, None)
         optimizer.zero_grad()
         loss_dict = algo.compute_loss(model, videos, seq_lens, chosen_steps, video_masks)
         loss = loss_dict['loss']

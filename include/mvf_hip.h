@@ -78,7 +78,8 @@ int mvf_gemm_tc(int dtype, int epi, const void* A, int lda, const void* W, int l
                 float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tokens_per_frame, int M,
                 int N, int K, hipStream_t stream);
 /* kernel choice for mvf_gemm_tc / mvf_vit_fwd (A/B measurements and tests): 0 automatic (bf16 and K % 128 == 0 ->
- * 256x256 8-phase kernel, else 128x128), 1 always 128x128, 2 only 256x256 (MVF_ERR_UNSUPPORTED where it cannot run) */
+ * persistent 256x256 8-phase kernel, else 128x128), 1 always 128x128, 2 only 256x256 (MVF_ERR_UNSUPPORTED where it
+ * cannot run), 3 the 256x256 kernel with one workgroup per tile instead of one per CU */
 int mvf_gemm_tc_select(int variant);
 /* diagnostic build of the 256x256 kernel: per-block s_memtime stamps into buf[blocks][2][8] (NULL = off, the default) */
 int mvf_gemm_tc_debug_stamps(unsigned long long* buf);

@@ -71,7 +71,7 @@ def test_gemm_tc256_equals_tc128_bitwise(M, N, K, epi):
 
     ref = run(1)
     for rep in range(6):
-        got = run(2)
+        got = run(2 if rep % 2 == 0 else 3)     # persistent (product form) / one workgroup per tile
         for x, y, what in zip(got, ref, ('C', 'resid', 'tap')):
             if x is not None:
                 assert torch.equal(x, y), 'gemm_tc256 != gemm_tc128 (%s, repeat %d): max diff %g' % (

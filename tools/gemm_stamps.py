@@ -20,6 +20,7 @@ def main():
     b = torch.randn(n, device=dev)
     C = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
     nblk = ((M + 255) // 256) * ((n + 255) // 256)
+    ntile = nblk
     buf = torch.zeros(nblk * 2 * 8, device=dev, dtype=torch.int64)
 
     def fn():
@@ -28,14 +29,19 @@ def main():
     for _ in range(3):
         fn()
     _lib.call('mvf_gemm_tc_debug_stamps', buf.data_ptr())
+    _lib.call('mvf_gemm_tc_select', int(os.environ.get('VARIANT', '2')))
     for _ in range(2):
         fn()
+    _lib.call('mvf_gemm_tc_select', 0)
     torch.cuda.synchronize()
     _lib.call('mvf_gemm_tc_debug_stamps', None)
     s = buf.cpu().numpy().reshape(nblk, 2, 8).astype(np.int64)
+    s = s[s[:, 0, 7] != 0]          # workgroups that ran (persistent launch: one per CU)
+    for q in range(1, 7):            # unused stamp slots (fewer than 3 tiles) -> carry forward
+        s[:, :, q] = np.where(s[:, :, q] == 0, s[:, :, q - 1], s[:, :, q])
     d = np.diff(s, axis=2)          # [blk, wave-row, 7 segments]
-    names = ['prologue (issue 14 DMA + wait tile 0)', 'K tile 0', 'K tile 1', 'K tiles 2-3', 'K tiles 4..nk-1',
-             'stagger balance barrier', 'epilogue (bias + stores + drain)']
+    names = ['cold prologue (14 DMA + wait)', 'tile 0: K loop', 'tile 0: epilogue', 'tile 1: K loop', 'tile 1: epilogue',
+             'tile 2: K loop', 'rest (tiles 2.. + drain)']
     tot = (s[:, :, 7] - s[:, :, 0])
     print('N=%d K=%d blocks=%d; s_memtime ticks (100 MHz reference? see guide: tick = shader cycle)' % (n, k, nblk))
     for wrow in (0, 1):
@@ -48,9 +54,6 @@ def main():
                                                                             np.percentile(v, 90),
                                                                             100.0 * v.sum() / tot[:, wrow].sum()))
     # first-round blocks vs later rounds
-    first = tot[:256, 0]
-    later = tot[256:, 0]
-    print(' first 256 blocks total median %d, later blocks %d' % (np.median(first), np.median(later) if len(later) else -1))
     span = s[:, :, 7].max() - s[:, :, 0].min()
     print(' kernel span (first start -> last end): %d ticks' % span)
 

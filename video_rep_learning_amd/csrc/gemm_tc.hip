@@ -182,12 +182,14 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
   a.pos = pos; a.ls = ls; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.ldt = ldt; a.M = M; a.N = N; a.K = K; a.tpf = tpf;
   a.dbg = g_dbg;
   // bf16 with K a multiple of 128: the 256x256 8-phase kernel (gemm_tc256.hip); g_variant 1 pins the 128x128 kernel
-  if (dtype == MVF_BF16 && g_variant != 1 && K % 128 == 0 && N % 32 == 0) return mvf_gemm_tc256_launch(epi, a, st);
-  if (g_variant == 2) return MVF_ERR_UNSUPPORTED;
+  if (dtype == MVF_BF16 && g_variant != 1 && K % 128 == 0 && N % 32 == 0)
+    return mvf_gemm_tc256_launch(epi, a, /*persistent=*/g_variant != 3, st);
+  if (g_variant >= 2) return MVF_ERR_UNSUPPORTED;
   return dtype == MVF_BF16 ? dispatch<bf16_t>(epi, a, st) : dispatch<float>(epi, a, st);
 }
 
-// 0 = automatic choice, 1 = always the 128x128 kernel, 2 = only the 256x256 kernel (error where it does not apply)
+// 0 = automatic choice, 1 = always the 128x128 kernel, 2 = only the 256x256 kernel (error where it does not apply),
+// 3 = the 256x256 kernel launched one workgroup per tile instead of persistent (A/B measurements)
 // diagnostic: stamps buffer [blocks][2][8] u64 for the gemm_tc256 DBG build (null = product kernels)
 extern "C" int mvf_gemm_tc_debug_stamps(unsigned long long* buf) {
   g_dbg = buf;
@@ -195,7 +197,7 @@ extern "C" int mvf_gemm_tc_debug_stamps(unsigned long long* buf) {
 }
 
 extern "C" int mvf_gemm_tc_select(int variant) {
-  MVF_CHECK_ARG(variant >= 0 && variant <= 2);
+  MVF_CHECK_ARG(variant >= 0 && variant <= 3);
   g_variant = variant;
   return MVF_OK;
 }

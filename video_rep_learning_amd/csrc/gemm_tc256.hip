@@ -1,5 +1,5 @@
 // 256x256-tile bf16 MFMA GEMM for the frozen ViT backbone (the dominant kernel of the training step):
-//     C[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]),  K % 128 == 0
+//     C[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]),  K % 128 == 0, N % 32 == 0
 // Same contract and epilogues as gemm_tc.hip (which stays the fp32 parity kernel and the odd-K fallback); replaces
 // the ATen/cuBLAS GEMMs behind timm's nn.Linear / Conv2d(patch) calls reached from CARL_MVF/models/transformer.py:188.
 //
@@ -10,24 +10,40 @@
 //    of both wave rows, B0/B1 the n-quadrant 0/1 rows of all four wave columns; two K-tile buffers = 128 KiB.
 //  * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, lane-linear image, XOR swizzle applied on the
 //    per-lane SOURCE address and on the ds_read_b128 address) -- never through VGPRs.
-//  * 4 phases per K tile, one output quadrant (64 x 32 per wave, 16 MFMAs) and one half-tile prefetch each:
-//        P0: read B0(4) + A0(8)   MFMA (A0,B0)   issue (t+1).A1
-//        P1: read B1(4)           MFMA (A0,B1)   issue (t+2).B0
-//        P2: read A1(8)           MFMA (A1,B1)   issue (t+2).A0
-//        P3: --                   MFMA (A1,B0)   issue (t+2).B1 ; s_waitcnt vmcnt(6)
+//  * 4 phases per K tile, one output quadrant (64 x 32 per wave, 16 MFMAs) and one half-tile prefetch each
+//    (g = running K-tile index of the workgroup):
+//        P0: read B0(4) + A0(8)   MFMA (A0,B0)   issue (g+1).A1
+//        P1: read B1(4)           MFMA (A0,B1)   issue (g+2).B0
+//        P2: read A1(8)           MFMA (A1,B1)   issue (g+2).A0
+//        P3: --                   MFMA (A1,B0)   issue (g+2).B1 ; s_waitcnt vmcnt(6)
 //    Each phase is  {ds_reads, LDS-DMA issue} s_barrier {MFMAs} s_barrier.  The wave row wr = 1 runs ONE barrier
 //    behind wr = 0, so on every SIMD one wave is in its MFMA segment while its partner loads (matrix pipe kept busy).
+//  * PERSISTENT: one workgroup per CU walks several output tiles and the staging schedule above never stops at a
+//    tile boundary -- K tiles g+1, g+2 simply belong to the NEXT output tile (the issue-side pointers switch to it in
+//    the second-to-last K tile).  So only the very first tile of a workgroup pays the cold prologue; every other
+//    tile starts with its first two K tiles already in flight while the previous tile's epilogue stores drain
+//    (measured on the one-tile-per-workgroup form: prologue + first-tiles stall = 17 %, epilogue = 13 % of a K = 768
+//    tile).  At a tile boundary the two wave rows are re-aligned (one extra barrier each side) so that both run their
+//    epilogues in the same interval instead of one after the other.
 //  * hazards (slots = intervals between workgroup barriers; wr=0 loads in slot 2k, computes in 2k+1; wr=1 one later):
-//      RAW  a tile's last half-tile (A1) is issued 4 phases before the tile's P3 wait; vmcnt(6) leaves exactly the 3
-//           younger half-tiles (2 LDS-DMAs per wave each) in flight; every wave waits BEFORE the first barrier of P3
-//           and the first read of the new tile comes after that barrier in both wave rows.
+//      RAW  a K tile's last half-tile (A1) is issued 4 phases before the previous K tile's P3 wait; vmcnt(6) leaves
+//           exactly the 3 younger half-tiles (2 LDS-DMAs per wave each) in flight; every wave waits BEFORE the first
+//           barrier of P3 and the first read of the new K tile comes after that barrier in both wave rows.  Epilogue
+//           loads/stores and the bias DMA are issued between a P3 and the next P0, i.e. they are OLDER than every
+//           DMA the next vmcnt(6) leaves in flight: the count stays exact (the wait is only more conservative).
 //      WAR  B0 is re-staged one phase after its reads: they are retired by lgkmcnt(8) before P0's first barrier
 //           (B reads are issued first; order pinned by sched_barrier).  A0, B1, A1 are re-staged two phases after
 //           their reads, whose lgkmcnt(0) precedes the reading phase's second barrier in both wave rows.
+//           The tile-boundary barriers and the epilogue only add distance.
 //  * no vmcnt(0) / __syncthreads inside the loop; all LDS is one dynamic array (a second __shared__ object makes
-//    hipcc drain the DMA queue before every ds_read).
-//  * operands swapped (W fragment as MFMA-A) so a lane owns 4 consecutive output columns -> 8/16-byte stores.
-//  * 1-D grid, bijective XCD-aware remap: the tiles of one A row-panel run on one XCD and share its L2.
+//    hipcc drain the DMA queue before every ds_read).  The tile's bias slice travels by LDS-DMA too (a VGPR load in
+//    the epilogue would make hipcc drain the next tile's DMAs).
+//  * operands swapped (W fragment as MFMA-A) so a lane owns 4 consecutive output columns; v_permlane16_swap pairs two
+//    tiles into 16-byte stores (gemm_tc_epi.h).
+//  * tried and rejected (PMC): rotating the K loop per A row-panel to shorten W's L2 re-use distance -- the L2 hits come
+//    from workgroups reading the SAME slices at the SAME time; rotation cut the hit rate from 74 % to 47 % (fc2).
+//  * XCD-aware static tile walk: workgroups b, b+8, ... share an XCD (round-robin dispatch, speed only); XCD x owns a
+//    contiguous chunk of the tile list (tiles of one A row-panel are neighbours) and its workgroups walk it in step.
 #include "common.h"
 #include "mvf_hip_internal.h"
 #include "gemm_tc_epi.h"
@@ -36,9 +52,10 @@ namespace {
 using namespace gemm_tc;
 
 constexpr int BM = 256, BN = 256, ROWB = 128;
-constexpr int HALF_BYTES = 128 * ROWB;      // 16 KiB: 128 rows x 64 bf16
-constexpr int BUF_BYTES = 4 * HALF_BYTES;   // A0 A1 B0 B1
-constexpr int LDS_BYTES = 2 * BUF_BYTES;    // 128 KiB -> one workgroup per CU
+constexpr int HALF_BYTES = 128 * ROWB;          // 16 KiB: 128 rows x 64 bf16
+constexpr int BUF_BYTES = 4 * HALF_BYTES;       // A0 A1 B0 B1
+constexpr int BIAS_OFF = 2 * BUF_BYTES;         // 8 waves x 64 floats behind the two K-tile buffers
+constexpr int LDS_BYTES = BIAS_OFF + 8 * 256;   // 130 KiB -> one workgroup per CU
 constexpr int OFF_A0 = 0, OFF_A1 = HALF_BYTES, OFF_B0 = 2 * HALF_BYTES, OFF_B1 = 3 * HALF_BYTES;
 
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -51,9 +68,9 @@ constexpr int OFF_A0 = 0, OFF_A1 = HALF_BYTES, OFF_B0 = 2 * HALF_BYTES, OFF_B1 =
     SCHED_FENCE();                \
   } while (0)
 
-// DBG (diagnostic build only, selected with mvf_gemm_tc_select(3); never on the product path): lane 0 of waves 0 and 4
-// stamps s_memtime at kernel start, after the prologue wait, after K tiles 0/1/nk-1 and after the epilogue into
-// a.dbg[block][2][8] (a buffer of its own; no output depends on it).
+// DBG (diagnostic build only, reached through mvf_gemm_tc_debug_stamps; never on the product path): lane 0 of waves 0
+// and 4 stamps s_memtime at kernel start, after the prologue wait, after the K loop and the epilogue of the
+// workgroup's first two tiles, and at the end, into a.dbg[block][2][8] (a buffer of its own; no output depends on it).
 template <int EPI, bool DBG>
 __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -65,48 +82,66 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   int nstamp = 0;
 #define STAMP()                                                                              \
   if constexpr (DBG) {                                                                       \
-    SCHED_FENCE();                                                                           \
-    unsigned long long t_;                                                                   \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
-    SCHED_FENCE();                                                                           \
-    stamps[nstamp++] = t_;                                                                   \
+    if (nstamp < 7) {                                                                        \
+      SCHED_FENCE();                                                                         \
+      unsigned long long t_;                                                                 \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+      SCHED_FENCE();                                                                         \
+      stamps[nstamp++] = t_;                                                                 \
+    }                                                                                        \
   }
   STAMP();
 
-  // ---- XCD-aware, bijective block remap (blocks b and b+8 share an XCD) ----
+  // ---- static tile walk: XCD x (= blockIdx & 7) owns tiles [start, end); its workgroups take them round-robin ----
   const int nbn = (a.N + BN - 1) / BN;
+  const int ntiles = ((a.M + BM - 1) / BM) * nbn;
   const int nwg = gridDim.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7;
-  const int xcd = blockIdx.x & 7;
-  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-  const int m0 = (lid / nbn) * BM;
-  const int n0 = (lid % nbn) * BN;
-  const int nk = a.K >> 6;  // K tiles of 64 (even: K % 128 == 0)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bpx = (nwg - xcd + 7) >> 3;            // workgroups on this XCD
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int end = start + q8 + (xcd < r8 ? 1 : 0);
+  int lid = start + slot;                          // tile being computed
+  if (lid >= end) return;                          // whole workgroup (only when tiles are unevenly spread over XCDs)
+  const int nk = a.K >> 6;                         // K tiles of 64 (even: K % 128 == 0)
 
-  // ---- LDS-DMA source pointers: per half-tile every wave issues 2 pieces of 1 KiB = 8 rows x 128 B ----
-  // piece p = i*8 + wave covers half-tile rows p*8 .. p*8+7; lane -> (row = p*8 + lane/8, physical chunk = lane%8)
+  // ---- LDS-DMA source pointers of the tile being STAGED (runs up to two K tiles ahead of the compute side) ----
+  // per half-tile every wave issues 2 pieces of 1 KiB = 8 rows x 128 B: piece p = i*8 + wave covers half-tile rows
+  // p*8 .. p*8+7; lane -> (row = p*8 + lane/8, physical chunk = lane%8)
   const int prow = lane >> 3;
   const int lchunk = (lane & 7) ^ prow;  // logical 16-B chunk fetched into physical chunk lane%8 (row & 7 == prow)
   const char* asrc[2][2];                // [half][piece]
   const char* wsrc[2][2];
+  auto set_sources = [&](int tile) {
+    const int tm0 = (tile / nbn) * BM, tn0 = (tile % nbn) * BN;
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = (i * 8 + wave) * 8 + prow;                 // row inside the half-tile, 0..127
-      const int am = (r >> 6) * 128 + h * 64 + (r & 63);       // A: wave row r>>6, m-quadrant h
-      const int wn = (r >> 5) * 64 + h * 32 + (r & 31);        // W: wave column r>>5, n-quadrant h
-      const int gm = min(m0 + am, a.M - 1);
-      const int gn = min(n0 + wn, a.N - 1);
-      asrc[h][i] = a.A + (size_t)gm * a.lda * 2 + lchunk * 16;
-      wsrc[h][i] = a.W + (size_t)gn * a.ldw * 2 + lchunk * 16;
-    }
+      for (int i = 0; i < 2; ++i) {
+        const int r = (i * 8 + wave) * 8 + prow;                 // row inside the half-tile, 0..127
+        const int am = (r >> 6) * 128 + h * 64 + (r & 63);       // A: wave row r>>6, m-quadrant h
+        const int wn = (r >> 5) * 64 + h * 32 + (r & 31);        // W: wave column r>>5, n-quadrant h
+        const int gm = min(tm0 + am, a.M - 1);
+        const int gn = min(tn0 + wn, a.N - 1);
+        asrc[h][i] = a.A + (size_t)gm * a.lda * 2 + lchunk * 16;
+        wsrc[h][i] = a.W + (size_t)gn * a.ldw * 2 + lchunk * 16;
+      }
+  };
+  set_sources(lid);
   const int piece0 = wave * 1024, piece1 = (8 + wave) * 1024;
   auto stage = [&](int buf, int off, const char* const (&src)[2], int kt) {
     char* dst = smem + buf * BUF_BYTES + off;
     const size_t koff = (size_t)kt * ROWB;
     __builtin_amdgcn_global_load_lds(GLB_PTR(src[0] + koff), LDS_PTR(dst + piece0), 16, 0, 0);
     __builtin_amdgcn_global_load_lds(GLB_PTR(src[1] + koff), LDS_PTR(dst + piece1), 16, 0, 0);
+  };
+  // this wave's 64 bias values -> its private 256 B of LDS, one LDS-DMA (4 B per lane)
+  char* sbias = smem + BIAS_OFF + wave * 256;
+  auto stage_bias = [&](int tile) {
+    if (a.bias != nullptr) {
+      const int n = min((tile % nbn) * BN + wc * 64 + lane, a.N - 1);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(a.bias + n), LDS_PTR(sbias), 4, 0, 0);
+    }
   };
 
   // ---- fragment read offsets: lane (frow, fgrp) reads row frow of a 16-row tile, 16-B chunk (ks*4 + fgrp) ^ (frow&7)
@@ -121,7 +156,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  // ---- prologue: tile 0 complete, tile 1 except A1 (issued in P0 of tile 0) ----
+  // ---- cold prologue (first tile of the workgroup only): K tile 0 complete, K tile 1 except A1 ----
+  stage_bias(lid);
   stage(0, OFF_B0, wsrc[0], 0);
   stage(0, OFF_A0, asrc[0], 0);
   stage(0, OFF_B1, wsrc[1], 0);
@@ -132,7 +168,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   WAIT_VMCNT(6);
   WG_BARRIER();
   STAMP();
-  if (wr == 1) WG_BARRIER();  // stagger: wave row 1 runs one barrier behind wave row 0
 
   bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
 
@@ -155,6 +190,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
         __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][ks], af[i][ks], acc[(MQ) * 4 + i][(NQ) * 2 + j], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0);
 
+// K tile T of the current output tile, read from LDS buffer BUF.  The staged K tile index is T+1 / T+2 of the current
+// tile, or -- once `kwrap` = -nk, i.e. the issue-side pointers have moved on -- K tile 0 / 1 of the NEXT output tile.
+#define CAN_ISSUE(D) ((t + (D) < nk) || have_next)
 #define K_TILE(BUF, T)                                                                                       \
   {                                                                                                          \
     const char* base = smem + (BUF) * BUF_BYTES;                                                             \
@@ -163,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     LOAD_B(bf0, OFF_B0);                                                                                     \
     SCHED_FENCE();                                                                                           \
     LOAD_A(OFF_A0);                                                                                          \
-    if (t + 1 < nk) stage((BUF) ^ 1, OFF_A1, asrc[1], t + 1);                                                \
+    if (CAN_ISSUE(1)) stage((BUF) ^ 1, OFF_A1, asrc[1], t + 1 + kwrap);                                      \
     SCHED_FENCE();                                                                                           \
     WAIT_LGKM(8);                                                                                            \
     WG_BARRIER();                                                                                            \
@@ -171,9 +209,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     SCHED_FENCE();                                                                                           \
     MFMA_QUAD(0, 0, bf0);                                                                                    \
     WG_BARRIER();                                                                                            \
+    if ((BUF) == 0 && t == nk - 2 && have_next) { /* from here on the NEXT output tile is staged */          \
+      set_sources(lid_next);                                                                                 \
+      kwrap = -nk;                                                                                           \
+    }                                                                                                        \
     /* P1 */                                                                                                 \
     LOAD_B(bf1, OFF_B1);                                                                                     \
-    if (t + 2 < nk) stage((BUF), OFF_B0, wsrc[0], t + 2);                                                    \
+    if (CAN_ISSUE(2)) stage((BUF), OFF_B0, wsrc[0], t + 2 + kwrap);                                          \
     WG_BARRIER();                                                                                            \
     WAIT_LGKM(0);                                                                                            \
     SCHED_FENCE();                                                                                           \
@@ -181,15 +223,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     WG_BARRIER();                                                                                            \
     /* P2 */                                                                                                 \
     LOAD_A(OFF_A1);                                                                                          \
-    if (t + 2 < nk) stage((BUF), OFF_A0, asrc[0], t + 2);                                                    \
+    if (CAN_ISSUE(2)) stage((BUF), OFF_A0, asrc[0], t + 2 + kwrap);                                          \
     WG_BARRIER();                                                                                            \
     WAIT_LGKM(0);                                                                                            \
     SCHED_FENCE();                                                                                           \
     MFMA_QUAD(1, 1, bf1);                                                                                    \
     WG_BARRIER();                                                                                            \
     /* P3 */                                                                                                 \
-    if (t + 2 < nk) {                                                                                        \
-      stage((BUF), OFF_B1, wsrc[1], t + 2);                                                                  \
+    if (CAN_ISSUE(2)) {                                                                                      \
+      stage((BUF), OFF_B1, wsrc[1], t + 2 + kwrap);                                                          \
       WAIT_VMCNT(6);                                                                                         \
     } else {                                                                                                 \
       WAIT_VMCNT(0);                                                                                         \
@@ -199,71 +241,108 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     WG_BARRIER();                                                                                            \
   }
 
-  for (int kt = 0; kt < nk; kt += 2) {
-    K_TILE(0, kt);
-    if constexpr (DBG) { if (kt == 0) { STAMP(); } }
-    K_TILE(1, kt + 1);
-    if constexpr (DBG) { if (kt == 0 || kt == 2 || kt + 2 >= nk) { STAMP(); } }
+  for (;;) {
+    const int lid_next = lid + bpx;
+    const bool have_next = lid_next < end;
+    const int m0 = (lid / nbn) * BM, n0 = (lid % nbn) * BN;   // compute-side tile
+    int kwrap = 0;
+    if (wr == 1) WG_BARRIER();  // stagger: wave row 1 runs one barrier behind wave row 0
+
+    for (int kt = 0; kt < nk; kt += 2) {
+      K_TILE(0, kt);
+      K_TILE(1, kt + 1);
+    }
+    if (wr == 0) WG_BARRIER();  // re-align the wave rows: both run the epilogue in the same interval
+    STAMP();
+
+    // ---- epilogue: two adjacent 16x16 tiles at a time (gemm_tc_epi.h epilogue_pair_bf16); bias from LDS ----
+    float4 bj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      bj[j] = a.bias != nullptr ? *reinterpret_cast<const float4*>(sbias + (j * 16 + fgrp * 4) * 4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + frow;
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        const int nb = n0 + wc * 64 + jp * 32;
+        // N % 32 == 0: a tile pair is in range or out as a whole
+        epilogue_pair_bf16<EPI>(a, m, m < a.M && nb < a.N, nb, fgrp, acc[i][2 * jp], acc[i][2 * jp + 1], bj[2 * jp],
+                                bj[2 * jp + 1]);
+      }
+    }
+    STAMP();
+    if (!have_next) break;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    lid = lid_next;
+    WAIT_LGKM(0);        // this wave's bias reads are done before its bias slot is re-staged
+    stage_bias(lid);     // older than every DMA the coming vmcnt(6) waits leave in flight
   }
-  if (wr == 0) WG_BARRIER();  // balance the stagger barrier of wave row 1
-  STAMP();
 
 #undef K_TILE
+#undef CAN_ISSUE
 #undef MFMA_QUAD
 #undef LOAD_A
 #undef LOAD_B
 
-  // ---- epilogue: two adjacent 16x16 tiles at a time (gemm_tc_epi.h epilogue_pair_bf16); bias loaded once ----
-  float4 bj[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = n0 + wc * 64 + j * 16 + fgrp * 4;
-    bj[j] = (a.bias != nullptr && n < a.N) ? *reinterpret_cast<const float4*>(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + frow;
-#pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-      const int nb = n0 + wc * 64 + jp * 32;
-      // N % 32 == 0: a tile pair is in range or out as a whole
-      epilogue_pair_bf16<EPI>(a, m, m < a.M && nb < a.N, nb, fgrp, acc[i][2 * jp], acc[i][2 * jp + 1], bj[2 * jp],
-                              bj[2 * jp + 1]);
-    }
-  }
   if constexpr (DBG) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP();
+    while (nstamp < 7) stamps[nstamp++] = 0ull;
+    {
+      SCHED_FENCE();
+      unsigned long long t_;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+      SCHED_FENCE();
+      stamps[7] = t_;
+    }
     if (a.dbg != nullptr && lane == 0 && (wave == 0 || wave == 4))
-      for (int q = 0; q < 8; ++q) a.dbg[((size_t)blockIdx.x * 2 + (wave >> 2)) * 8 + q] = q < nstamp ? stamps[q] : 0ull;
+      for (int q = 0; q < 8; ++q) a.dbg[((size_t)blockIdx.x * 2 + (wave >> 2)) * 8 + q] = stamps[q];
   }
 #undef STAMP
 }
 
+int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
 template <int EPI, bool DBG = false>
-int launch(const GemmTcArgs& a, hipStream_t st) {
+int launch(const GemmTcArgs& a, bool persistent, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tc256_kernel<EPI, DBG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
-  const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_tc256_kernel<EPI, DBG>), dim3(nbm * nbn), dim3(512), LDS_BYTES, st, a);
+  const int ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  // persistent: one workgroup per CU (a multiple of 8 so that every XCD gets the same number); otherwise (A/B
+  // measurements) one workgroup per tile -- the same kernel, every workgroup then runs the cold prologue
+  const int grid = persistent ? std::min(ntiles, std::max(8, num_cus() & ~7)) : ntiles;
+  hipLaunchKernelGGL((gemm_tc256_kernel<EPI, DBG>), dim3(grid), dim3(512), LDS_BYTES, st, a);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }
 
 }  // namespace
 
-int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, hipStream_t st) {
+int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, bool persistent, hipStream_t st) {
   if (a.K % 128 != 0 || a.K < 128 || a.N % 32 != 0) return MVF_ERR_ARG;
-  if (a.dbg != nullptr) return epi == EPI_STORE ? launch<EPI_STORE, true>(a, st) : MVF_ERR_UNSUPPORTED;
+  if (a.dbg != nullptr) return epi == EPI_STORE ? launch<EPI_STORE, true>(a, persistent, st) : MVF_ERR_UNSUPPORTED;
   switch (epi) {
-    case EPI_STORE: return launch<EPI_STORE>(a, st);
-    case EPI_GELU: return launch<EPI_GELU>(a, st);
-    case EPI_RESID: return launch<EPI_RESID>(a, st);
-    case EPI_PATCH: return launch<EPI_PATCH>(a, st);
+    case EPI_STORE: return launch<EPI_STORE>(a, persistent, st);
+    case EPI_GELU: return launch<EPI_GELU>(a, persistent, st);
+    case EPI_RESID: return launch<EPI_RESID>(a, persistent, st);
+    case EPI_PATCH: return launch<EPI_PATCH>(a, persistent, st);
   }
   return MVF_ERR_ARG;
 }

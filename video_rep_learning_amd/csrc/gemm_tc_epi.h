@@ -160,4 +160,4 @@ __device__ __forceinline__ void epilogue_pair_bf16(const GemmTcArgs& a, int m, b
 }  // namespace gemm_tc
 
 // gemm_tc256.hip: bf16, K % 128 == 0.  Same contract as the 128x128 kernel's launch.
-int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, hipStream_t st);
+int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, bool persistent, hipStream_t st);

@@ -98,6 +98,20 @@ int mvf_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t stream);
 int mvf_hgemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
               const float* bias, const float* table, long tab_si, long tab_sn, int tab_div, int tab_mod, int M, int N,
               int K, float alpha, int relu, int accumulate, hipStream_t stream);
+/* the same with dropout and the residual connection fused into the epilogue: C = [resid +] dropout_p(act(...))
+ *   (ResidualConnection `x + drop(sub(LN(x)))`, models/utils.py:153-159, when `sub` ends in a Linear); the dropout mask
+ *   is the counter-based one of mvf_dropout_add with element index m*ldc + n */
+int mvf_hgemm_ex(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
+                 const float* bias, const float* table, long tab_si, long tab_sn, int tab_div, int tab_mod, int M, int N,
+                 int K, float alpha, int relu, int accumulate, const float* resid, long ldr, float drop_p,
+                 uint64_t drop_seed, uint64_t drop_offset, hipStream_t stream);
+/* backward of y = x W^T + b in ONE launch (x [M,K], W [N,K], dy [M,N]): g = pre(dy) with pre_mode 0 none | 1 ReLU mask
+ * (dy * [ymask > 0], models/utils.py:190) | 2 dropout mask (dy * keep/(1-p), the forward's mask);
+ * dx = g W (may be NULL); dW (+)= g^T x; db (+)= colsum(g) (may be NULL).  accumulate_params: add into dW/db (the flat
+ * gradient buffer) instead of overwriting */
+int mvf_hlinear_bwd(const float* dy, long ldy, int pre_mode, const float* ymask, float drop_p, uint64_t drop_seed,
+                    uint64_t drop_offset, const float* x, long ldx, const float* W, long ldw, float* dx, long lddx,
+                    float* dW, long lddw, float* db, int M, int N, int K, int accumulate_params, hipStream_t stream);
 int mvf_colsum(const float* x, long ld, int rows, int cols, float* out, int accumulate, hipStream_t stream);
 
 /* dx = dy * [y > 0]  (ReLU backward of the FFN, models/utils.py:190) */
@@ -112,7 +126,7 @@ int mvf_dropout_add(const float* x, const float* resid, float* y, size_t n, floa
 int mvf_ln_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int rows, int D,
                float eps, hipStream_t stream);
 int mvf_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, float* dx, float* dg,
-               float* db, int rows, int D, int accumulate_dx, hipStream_t stream);
+               float* db, int rows, int D, int accumulate_dx, int accumulate_params, hipStream_t stream);
 
 /* BatchNorm1d (+fused ReLU)  (models/mvformer.py:78-79, resnet_c2d.py:118-119); SyncBN = caller merges the
  * (mean, var) / (s1, s2) vectors across ranks between the two halves (train.py:283) */

@@ -234,6 +234,58 @@ def test_linear_fwd_bwd(M, N, K, relu):
     check(bd.grad, br.grad, 2e-5, 'linear db')
 
 
+@pytest.mark.parametrize('M,N,K,p', [(768, 256, 1024, 0.1), (96, 64, 48, 0.5), (70, 36, 19, 0.0)])
+def test_linear_fused_dropout_residual_and_gradient_slots(M, N, K, p):
+    """y = resid + dropout(x W^T + b) in ONE GEMM epilogue and dX/dW/db in ONE backward launch must equal the unfused
+    chain (ops.linear -> ops.dropout_add with the same counter-based mask), and gradients accumulated straight into
+    flat-gradient slots must equal the ones autograd accumulates."""
+    g = gen(26)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    r, gy = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    seed, off = 1234, 777
+    # unfused reference chain on the device
+    x0, w0, b0, r0 = _leaf(x), _leaf(w), _leaf(b), _leaf(r)
+    st = ops.DropoutState(seed)
+    st.offset = off
+    y0 = ops.dropout_add(ops.linear(x0, w0, b0), r0, p, True, st)
+    (y0 * gy.to(DEV)).sum().backward()
+    # fused
+    x1, w1, b1, r1 = _leaf(x), _leaf(w), _leaf(b), _leaf(r)
+    y1 = ops.linear(x1, w1, b1, resid=r1, drop=(p, seed, off) if p > 0 else None)
+    (y1 * gy.to(DEV)).sum().backward()
+    check(y1, y0, 1e-6, 'fused y')
+    for a_, b_, what in ((x1, x0, 'dx'), (w1, w0, 'dw'), (b1, b0, 'db'), (r1, r0, 'dresid')):
+        check(a_.grad, b_.grad, 2e-6, 'fused ' + what)
+    if p == 0.0:   # against fp64 too
+        check(y1, x.double() @ w.double().t() + b.double() + r.double(), 2e-5, 'fused y vs fp64')
+    # gradient slots: a second backward into pre-filled slots accumulates
+    x2, w2, b2 = _leaf(x), _leaf(w), _leaf(b)
+    w2._mvf_grad = torch.full_like(w2, 0.5)
+    b2._mvf_grad = torch.full_like(b2, -0.25)
+    y2 = ops.linear(x2, w2, b2, relu=True)
+    (y2 * gy.to(DEV)).sum().backward()
+    x3, w3, b3 = _leaf(x), _leaf(w), _leaf(b)
+    (ops.linear(x3, w3, b3, relu=True) * gy.to(DEV)).sum().backward()
+    assert w2.grad is None and b2.grad is None           # nothing travelled through autograd
+    check(w2._mvf_grad - 0.5, w3.grad, 2e-5, 'slot dw')
+    check(b2._mvf_grad + 0.25, b3.grad, 2e-5, 'slot db')
+    check(x2.grad, x3.grad, 1e-6, 'slot dx')
+
+
+def test_layer_norm_gradient_slots():
+    g = gen(27)
+    x, w, b = torch.randn(770, 259, generator=g), torch.randn(259, generator=g), torch.randn(259, generator=g)
+    gy = torch.randn(770, 259, generator=g)
+    xr, wr, br = [t.double().requires_grad_(True) for t in (x, w, b)]
+    (OV.layer_norm(xr, wr, br, 1e-5) * gy.double()).sum().backward()
+    xd, wd, bd = _leaf(x), _leaf(w), _leaf(b)
+    wd._mvf_grad, bd._mvf_grad = torch.ones_like(wd), torch.ones_like(bd)
+    (ops.layer_norm(xd, wd, bd, 1e-5) * gy.to(DEV)).sum().backward()
+    check(xd.grad, xr.grad, 2e-5, 'ln dx')
+    check(wd._mvf_grad - 1, wr.grad, 2e-5, 'ln slot dg')
+    check(bd._mvf_grad - 1, br.grad, 2e-5, 'ln slot db')
+
+
 def test_linear_table_and_matmul():
     g = gen(21)
     x, w = torch.randn(24 * 8, 32, generator=g), torch.randn(16, 32, generator=g)

@@ -28,11 +28,13 @@ SIGNATURES = {
     'mvf_vit_attn_fwd': 'ippiiiiip',
     'mvf_cast_f32_bf16': 'ppzp',
     'mvf_hgemm': 'pllpllplppllii' + 'iiifiip',
+    'mvf_hgemm_ex': 'pllpllplppllii' + 'iiifii' + 'plfuup',
+    'mvf_hlinear_bwd': 'plipfuuplplplplpiiiip',
     'mvf_colsum': 'pliipip',
     'mvf_relu_bwd': 'pppzp',
     'mvf_dropout_add': 'pppzfuup',
     'mvf_ln_fwd': 'ppppppiifp',
-    'mvf_ln_bwd': 'ppppppppiiip',
+    'mvf_ln_bwd': 'ppppppppiiiip',
     'mvf_bn_stats': 'piippp',
     'mvf_bn_fwd': 'ppppppiifip',
     'mvf_bn_bwd_reduce': 'ppppppppiifip',

@@ -64,5 +64,17 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// counter-based dropout mask shared by dropout_add_kernel and the fused GEMM pre-/post-ops:
+// keep(i) = hash(seed, offset + i) >= p * 2^32  (splitmix64 finaliser)
+__device__ __forceinline__ uint32_t mix32(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (uint32_t)((z ^ (z >> 31)) >> 16);
+}
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t offset, uint64_t i, uint32_t thresh) {
+  return mix32(seed * 0x2545F4914F6CDD1Dull + offset + i) >= thresh;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

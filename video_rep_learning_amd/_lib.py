@@ -29,7 +29,7 @@ SIGNATURES = {
     'mvf_cast_f32_bf16': 'ppzp',
     'mvf_hgemm': 'pllpllplppllii' + 'iiifiip',
     'mvf_hgemm_ex': 'pllpllplppllii' + 'iiifii' + 'plfuup',
-    'mvf_hlinear_bwd': 'plipfuuplplplplpiiiip',
+    'mvf_hlinear_bwd': 'plplplplplpiiiip',
     'mvf_colsum': 'pliipip',
     'mvf_relu_bwd': 'pppzp',
     'mvf_dropout_add': 'pppzfuup',

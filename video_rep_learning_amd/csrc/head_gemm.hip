@@ -1,25 +1,28 @@
 // fp32 MFMA GEMM with generic strides for the (small, latency-bound) trainable head:
-//     C[m, n] (+)= post( act( alpha * sum_k pre(A(m,k)) * B(k,n) + bias[n] + table[idx(m), n] ) )
+//     C[m, n] (+)= [resid +] dropout( act( alpha * sum_k A(m,k) * B(k,n) + bias[n] + table[idx(m), n] ) )
 // A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]: one kernel serves forward (x . W^T), input
 // gradient (dy . W) and weight gradient (dy^T . x) of every nn.Linear on the path
 // (CARL_MVF/models/mvformer.py:77,86,97; models/utils.py:65-68,182-183; resnet_c2d.py:117-120) by
 // passing different strides -- no transposed copies.
 //
 // Fusions (each removes a launch and an HBM/L2 round trip of a [768, <=1024] fp32 tensor):
-//   pre  : A elements can be masked on load -- ReLU backward (dy * [y > 0], models/utils.py:190) or dropout backward
-//          (dy * keep / (1-p), the counter-based mask of mvf_dropout_add) -- so the backward of `drop(relu(fc(x)))`
-//          chains needs no elementwise kernels;
-//   post : y = resid + dropout(v): the residual connection `x + drop(sub(LN(x)))` of models/utils.py:153-159 ends in
-//          the epilogue of the sub-layer's last Linear;
-//   rowsum: out[m] (+)= sum_k pre(A(m,k)) -- in the weight-gradient problem A = dy^T, so this IS the bias gradient;
-//   mvf_hlinear_bwd: dX, dW and db of one Linear in ONE launch (two tile ranges of one grid).
+//   epilogue: bias, sin/cos PE table, ReLU, dropout, residual add -- the residual connection
+//             `x + drop(sub(LN(x)))` of models/utils.py:153-159 ends in the epilogue of the sub-layer's last Linear;
+//   rowsum  : out[m] (+)= sum_k A(m,k) -- in the weight-gradient problem A = dy^T, so this IS the bias gradient;
+//   mvf_hlinear_bwd: dX, dW and db of one Linear in ONE launch (two tile ranges of one grid), parameter gradients
+//             accumulated in place (flat gradient buffer).
+//   (Tried and dropped: applying the ReLU / dropout backward mask to dy while loading it -- every output tile re-hashes
+//   or re-loads the mask, 2.5x slower than one 5-us elementwise pass.)
 //
-// gfx950 design: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).  The matrices are <= a few MB and L2-resident and
-// M is 768 rows, so the kernel is latency- not bandwidth-bound: fragments are loaded straight from global/L2 into the
-// MFMA operand registers (float4 along k when the operand is k-contiguous, using the k-permutation trick: element s
-// of lane (r, g) is k = k0 + 4g + s for BOTH operands), no LDS, no barriers, and the NEXT k-step's fragments are
-// requested before the current step's 16 MFMAs are issued (register double buffer) so that L2 latency hides under
-// the matrix pipe.  64x64 tile per workgroup (4 waves x 32x32); operands swapped so a lane owns 4 consecutive n.
+// gfx950 design: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain), 64x64 output tile per workgroup (4 waves x 32x32),
+// 32-deep k steps.  Whatever the operand's layout -- k contiguous (x, W in the forward), or k strided with the tile
+// index contiguous (dy and x in dW = dy^T x, W in dX = dy W) -- its [32 k][64 rows] tile is fetched with coalesced
+// 16-byte loads along the CONTIGUOUS direction and put into LDS k-major ([k][row]), from where
+// each lane reads the one element per MFMA the 16x16x4 layout wants (lane (r, g): row r, k = 4q + g): scalar LDS
+// reads, conflict-free (row stride 80 floats + an XOR swizzle of the 4-float column groups).  Two LDS buffers; the next tile's global loads are issued before the current tile's 32 MFMAs
+// and written to the other buffer after them: one barrier per k step, global latency hidden under the matrix pipe.
+// The matrices are a few MB and L2-resident and M is 768 rows, so this is latency- not bandwidth-bound work; operands
+// swapped in the MFMA so a lane owns 4 consecutive n (16-byte stores).
 #include "common.h"
 #include "mvf_hip_internal.h"
 
@@ -34,59 +37,77 @@ struct HGemmArgs {
   int M, N, K;
   int relu, accumulate;
   float alpha;
-  // pre-op on A: 0 none, 1 relu mask (amask[same index] > 0), 2 dropout mask
-  int a_mode;
-  const float* amask;
-  // dropout parameters of the A pre-op (a_mode 2) or of the epilogue (post_drop)
-  uint32_t d_thresh; float d_scale; uint64_t d_seed, d_offset;
-  int post_drop;                      // epilogue: v = dropout(v) before the residual add
-  const float* resid; long ldr;       // epilogue: C = resid + dropout(v)
-  float* rowsum; int rowsum_acc;      // rowsum[m] (+)= sum_k pre(A(m,k)); written by the blockIdx.x == 0 column of tiles
+  uint32_t d_thresh; float d_scale; uint64_t d_seed, d_offset;   // epilogue dropout (d_thresh != 0)
+  const float* resid; long ldr;                                   // epilogue: C = resid + ...
+  float* rowsum; int rowsum_acc;   // rowsum[m] (+)= sum_k A(m,k); written by the first column of tiles
 };
 
-template <bool VEC, int MODE>
-__device__ __forceinline__ f32x4_t load_frag(const HGemmArgs& a, const float* base, long row_off, long sk, int k0, int g,
-                                             int K) {
-  // returns {X(row, k0+4g+0..3)}; zero beyond K.  MODE != 0 only for the A operand.
-  f32x4_t v;
-  const int k = k0 + 4 * g;
-  if constexpr (VEC) {
-    v = *reinterpret_cast<const f32x4_t*>(base + row_off + k);
-    if constexpr (MODE == 1) {
-      const f32x4_t m = *reinterpret_cast<const f32x4_t*>(a.amask + row_off + k);
+constexpr int TK = 32;            // k step
+constexpr int LDT = 80;           // LDS row stride (floats): rows g, g+1 of a fragment read land 16 banks apart
+constexpr int TILE_F = TK * LDT;  // floats per operand tile
+// element (k, c) of a tile lives at k*LDT + (c ^ SW(k)): the XOR moves whole 4-float groups, so the 16-byte k-major
+// stores stay contiguous, fragment reads (16 consecutive c at fixed k) stay conflict-free, and the TRANSPOSING scalar
+// stores of a k-contiguous operand (8 lanes = 8 different k-quads, same c) spread over 8 banks instead of 1
+__device__ __forceinline__ int lds_at(int k, int c) { return k * LDT + (c ^ (((k >> 2) & 7) << 2)); }
+
+// Global -> registers for one [TK][64] operand tile.  X(r, k) = X[r*sr + k*sk], r = tile row (m or n), exactly one of
+// sr, sk is 1.  KMAJOR (sr == 1): thread -> (k = t/16 [+16], rows 4*(t%16)..+3), float4 along the rows.
+// else (sk == 1): thread -> (row = t/8 [+32], k = 4*(t%8)..+3), float4 along k.
+template <bool KMAJOR>
+__device__ __forceinline__ void tile_load(const float* X, long sr, long sk, int r0, int R, int k0, int K, bool vec,
+                                          f32x4_t (&v)[2]) {
+  const int t = threadIdx.x;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) v[s] = m[s] > 0.f ? v[s] : 0.f;
-    } else if constexpr (MODE == 2) {
+  for (int h = 0; h < 2; ++h) {
+    f32x4_t x = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (KMAJOR) {
+      const int k = k0 + (t >> 4) + 16 * h, r = r0 + (t & 15) * 4;
+      if (k < K) {
+        const float* p = X + (long)k * sk + r;
+        if (vec && r + 3 < R) x = *reinterpret_cast<const f32x4_t*>(p);
+        else {
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-        v[s] = drop_keep(a.d_seed, a.d_offset, (uint64_t)(row_off + k + s), a.d_thresh) ? v[s] * a.d_scale : 0.f;
+          for (int s = 0; s < 4; ++s) x[s] = r + s < R ? p[s] : 0.f;
+        }
+      }
+    } else {
+      const int r = r0 + (t >> 3) + 32 * h, k = k0 + (t & 7) * 4;
+      if (r < R) {
+        const float* p = X + (long)r * sr + k;
+        if (vec && k + 3 < K) x = *reinterpret_cast<const f32x4_t*>(p);
+        else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) x[s] = k + s < K ? p[s] : 0.f;
+        }
+      }
     }
-  } else {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const long idx = row_off + (long)(k + s) * sk;
-      float x = (k + s < K) ? base[idx] : 0.f;
-      if constexpr (MODE == 1) x = (k + s < K && a.amask[idx] > 0.f) ? x : 0.f;
-      if constexpr (MODE == 2) x = (k + s < K && drop_keep(a.d_seed, a.d_offset, (uint64_t)idx, a.d_thresh)) ? x * a.d_scale : 0.f;
-      v[s] = x;
-    }
+    v[h] = x;
   }
-  return v;
 }
 
-// one 64x64 output tile (bx, by) of the problem `a`
-template <bool AVEC, bool BVEC, int MODE>
-__device__ __forceinline__ void hgemm_tile(const HGemmArgs& a, int bx, int by) {
+// registers -> LDS tile [k][row]
+template <bool KMAJOR>
+__device__ __forceinline__ void tile_store(float* T, const f32x4_t (&v)[2]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if constexpr (KMAJOR) {
+      *reinterpret_cast<f32x4_t*>(T + lds_at((t >> 4) + 16 * h, (t & 15) * 4)) = v[h];
+    } else {
+      const int r = (t >> 3) + 32 * h, k = (t & 7) * 4;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) T[lds_at(k + s, r)] = v[h][s];
+    }
+  }
+}
+
+// one 64x64 output tile (bx, by) of the problem `a`; lds: 4 * TILE_F floats
+template <bool AKM, bool BKM>
+__device__ __forceinline__ void hgemm_tile(const HGemmArgs& a, int bx, int by, float* lds, bool avec, bool bvec) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int m_base = by * 64 + (wave >> 1) * 32;
-  const int n_base = bx * 64 + (wave & 1) * 32;
-  long aoff[2], boff[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    aoff[i] = (long)min(m_base + i * 16 + li, a.M - 1) * a.sam;
-    boff[i] = (long)min(n_base + i * 16 + li, a.N - 1) * a.sbn;
-  }
+  const int m0 = by * 64, n0 = bx * 64;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   f32x4_t acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -95,34 +116,42 @@ __device__ __forceinline__ void hgemm_tile(const HGemmArgs& a, int bx, int by) {
   float rs[2] = {0.f, 0.f};
   const bool want_rs = a.rowsum != nullptr && bx == 0 && (wave & 1) == 0;
 
-  f32x4_t af[2], bf[2], afn[2], bfn[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) af[i] = load_frag<AVEC, MODE>(a, a.A, aoff[i], a.sak, 0, g, a.K);
-#pragma unroll
-  for (int j = 0; j < 2; ++j) bf[j] = load_frag<BVEC, 0>(a, a.B, boff[j], a.sbk, 0, g, a.K);
-  for (int k0 = 0; k0 < a.K; k0 += 16) {
-    const int kn = k0 + 16;
-    if (kn < a.K) {   // request the next step's fragments before this step's MFMAs
-#pragma unroll
-      for (int i = 0; i < 2; ++i) afn[i] = load_frag<AVEC, MODE>(a, a.A, aoff[i], a.sak, kn, g, a.K);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) bfn[j] = load_frag<BVEC, 0>(a, a.B, boff[j], a.sbk, kn, g, a.K);
+  f32x4_t ra[2], rb[2];
+  const int nt = (a.K + TK - 1) / TK;
+  tile_load<AKM>(a.A, a.sam, a.sak, m0, a.M, 0, a.K, avec, ra);
+  tile_load<BKM>(a.B, a.sbn, a.sbk, n0, a.N, 0, a.K, bvec, rb);
+  tile_store<AKM>(lds, ra);
+  tile_store<BKM>(lds + TILE_F, rb);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const float* As = lds + (t & 1) * 2 * TILE_F;
+    const float* Bs = As + TILE_F;
+    if (t + 1 < nt) {   // request the next tile before this tile's MFMAs
+      tile_load<AKM>(a.A, a.sam, a.sak, m0, a.M, (t + 1) * TK, a.K, avec, ra);
+      tile_load<BKM>(a.B, a.sbn, a.sbk, n0, a.N, (t + 1) * TK, a.K, bvec, rb);
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int q = 0; q < TK / 4; ++q) {
+      float af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = As[lds_at(4 * q + g, wm + i * 16 + li)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = Bs[lds_at(4 * q + g, wn + j * 16 + li)];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][s], af[i][s], acc[i][j], 0, 0, 0);
-    if (want_rs) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) rs[i] += af[i][0] + af[i][1] + af[i][2] + af[i][3];
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[i][j], 0, 0, 0);
+      if (want_rs) { rs[0] += af[0]; rs[1] += af[1]; }
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { af[i] = afn[i]; bf[i] = bfn[i]; }
+    if (t + 1 < nt) {
+      float* An = lds + ((t + 1) & 1) * 2 * TILE_F;
+      tile_store<AKM>(An, ra);
+      tile_store<BKM>(An + TILE_F, rb);
+    }
+    __syncthreads();
   }
 
+  const int m_base = m0 + wm, n_base = n0 + wn;
   if (want_rs) {   // combine the 4 k-groups (lanes li, li+16, li+32, li+48)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -156,7 +185,7 @@ __device__ __forceinline__ void hgemm_tile(const HGemmArgs& a, int bx, int by) {
         if (a.relu) v[r] = fmaxf(v[r], 0.f);
       }
       float* cp = a.C + (long)m * a.ldc + n;
-      if (a.post_drop) {          // dropout(v); mask index = element index of the dense [M, ldc] output
+      if (a.d_thresh != 0u) {     // dropout(v); mask index = element index of the dense [M, ldc] output
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           v[r] = drop_keep(a.d_seed, a.d_offset, (uint64_t)((long)m * a.ldc + n + r), a.d_thresh) ? v[r] * a.d_scale : 0.f;
@@ -182,18 +211,21 @@ __device__ __forceinline__ void hgemm_tile(const HGemmArgs& a, int bx, int by) {
   }
 }
 
-template <bool AVEC, bool BVEC, int MODE>
-__global__ __launch_bounds__(256) void hgemm_kernel(HGemmArgs a) {
-  hgemm_tile<AVEC, BVEC, MODE>(a, blockIdx.x, blockIdx.y);
+// operand forms: A k-major <=> sak != 1 (then sam == 1); B k-major <=> sbk != 1 (then sbn == 1)
+template <bool AKM, bool BKM>
+__global__ __launch_bounds__(256) void hgemm_kernel(HGemmArgs a, int avec, int bvec) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * TILE_F];
+  hgemm_tile<AKM, BKM>(a, blockIdx.x, blockIdx.y, lds, avec != 0, bvec != 0);
 }
 
-// Backward of y = x W^T + b in one launch: tiles [0, nx) compute dX = pre(dy) . W, tiles [nx, nx + nw) compute
-// dW (+)= pre(dy)^T . x and, in their first tile column, db (+)= colsum(pre(dy)).
-template <bool DXVEC, int MODE>
-__global__ __launch_bounds__(256) void hlinear_bwd_kernel(HGemmArgs dx, HGemmArgs dw, int nx, int dx_tiles_n, int dw_tiles_n) {
+// Backward of y = x W^T + b in one launch: tiles [0, nx) compute dX = dy . W (A = dy k-contiguous, B = W k-major),
+// tiles [nx, nx + nw) compute dW (+)= dy^T . x (both k-major) and, in their first tile column, db (+)= colsum(dy).
+__global__ __launch_bounds__(256) void hlinear_bwd_kernel(HGemmArgs dx, HGemmArgs dw, int nx, int dx_tiles_n, int dw_tiles_n,
+                                                          int dx_avec, int dx_bvec, int dw_avec, int dw_bvec) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * TILE_F];
   const int b = blockIdx.x;
-  if (b < nx) hgemm_tile<DXVEC, false, MODE>(dx, b % dx_tiles_n, b / dx_tiles_n);
-  else hgemm_tile<false, false, MODE>(dw, (b - nx) % dw_tiles_n, (b - nx) / dw_tiles_n);
+  if (b < nx) hgemm_tile<false, true>(dx, b % dx_tiles_n, b / dx_tiles_n, lds, dx_avec != 0, dx_bvec != 0);
+  else hgemm_tile<true, true>(dw, (b - nx) % dw_tiles_n, (b - nx) / dw_tiles_n, lds, dw_avec != 0, dw_bvec != 0);
 }
 
 // out[c] (+)= sum_r x[r*ld + c]   -- bias gradients that are not attached to a weight-gradient GEMM
@@ -213,21 +245,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
-void fill_dropout(HGemmArgs& a, float p, uint64_t seed, uint64_t offset) {
-  a.d_thresh = p > 0.f ? (uint32_t)std::min<double>(4294967295.0, (double)p * 4294967296.0) : 0u;
-  a.d_scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
-  a.d_seed = seed;
-  a.d_offset = offset;
-}
-
-template <int MODE>
-void launch_generic(const HGemmArgs& a, bool avec, bool bvec, hipStream_t st) {
-  dim3 grid(ceil_div(a.N, 64), ceil_div(a.M, 64));
-  if (avec && bvec) hipLaunchKernelGGL((hgemm_kernel<true, true, MODE>), grid, dim3(256), 0, st, a);
-  else if (avec) hipLaunchKernelGGL((hgemm_kernel<true, false, MODE>), grid, dim3(256), 0, st, a);
-  else if (bvec) hipLaunchKernelGGL((hgemm_kernel<false, true, MODE>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((hgemm_kernel<false, false, MODE>), grid, dim3(256), 0, st, a);
-}
+// 16-byte loads along the contiguous direction are legal when base and the other stride keep 16-B alignment
+bool can_vec(const float* p, long other_stride) { return ((uintptr_t)p & 15) == 0 && other_stride % 4 == 0; }
 
 }  // namespace
 
@@ -239,7 +258,7 @@ extern "C" int mvf_hgemm(const float* A, long sam, long sak, const float* B, lon
 }
 
 // mvf_hgemm + fused dropout / residual epilogue: C = [resid +] dropout_p(act(...)) (mask index = m*ldc + n, the element
-// index of a dense [M, ldc] output -- the same indexing mvf_dropout_add uses, so the backward pre-op matches)
+// index of a dense [M, ldc] output -- the same indexing mvf_dropout_add uses, so its backward is that kernel on dy)
 extern "C" int mvf_hgemm_ex(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
                             const float* bias, const float* table, long tab_si, long tab_sn, int tab_div, int tab_mod,
                             int M, int N, int K, float alpha, int relu, int accumulate, const float* resid, long ldr,
@@ -247,52 +266,46 @@ extern "C" int mvf_hgemm_ex(const float* A, long sam, long sak, const float* B, 
   MVF_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0);
   MVF_CHECK_ARG(table == nullptr || (tab_div > 0 && tab_mod > 0));
   MVF_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && !((resid != nullptr || drop_p > 0.f) && accumulate));
+  MVF_CHECK_ARG((sam == 1 || sak == 1) && (sbk == 1 || sbn == 1));   // each operand contiguous along m/n or along k
   HGemmArgs a{};
   a.A = A; a.sam = sam; a.sak = sak; a.B = B; a.sbk = sbk; a.sbn = sbn; a.C = C; a.ldc = ldc; a.bias = bias;
   a.table = table; a.tab_si = tab_si; a.tab_sn = tab_sn; a.tab_div = tab_div > 0 ? tab_div : 1;
   a.tab_mod = tab_mod > 0 ? tab_mod : 1; a.M = M; a.N = N; a.K = K; a.relu = relu; a.accumulate = accumulate;
   a.alpha = alpha; a.resid = resid; a.ldr = ldr;
-  fill_dropout(a, drop_p, drop_seed, drop_offset);
-  a.post_drop = drop_p > 0.f;
-  const bool avec = sak == 1 && sam % 4 == 0 && K % 16 == 0 && ((uintptr_t)A & 15) == 0;
-  const bool bvec = sbk == 1 && sbn % 4 == 0 && K % 16 == 0 && ((uintptr_t)B & 15) == 0;
-  launch_generic<0>(a, avec, bvec, st);
+  a.d_thresh = drop_p > 0.f ? (uint32_t)std::min<double>(4294967295.0, (double)drop_p * 4294967296.0) : 0u;
+  a.d_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  a.d_seed = drop_seed; a.d_offset = drop_offset;
+  // a [1, K] or [K, 1] operand has both strides "1": prefer the k-contiguous reading
+  const bool akm = sak != 1, bkm = sbk != 1;
+  const int avec = can_vec(A, akm ? sak : sam), bvec = can_vec(B, bkm ? sbk : sbn);
+  dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
+  if (akm && bkm) hipLaunchKernelGGL((hgemm_kernel<true, true>), grid, dim3(256), 0, st, a, avec, bvec);
+  else if (akm) hipLaunchKernelGGL((hgemm_kernel<true, false>), grid, dim3(256), 0, st, a, avec, bvec);
+  else if (bkm) hipLaunchKernelGGL((hgemm_kernel<false, true>), grid, dim3(256), 0, st, a, avec, bvec);
+  else hipLaunchKernelGGL((hgemm_kernel<false, false>), grid, dim3(256), 0, st, a, avec, bvec);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }
 
-// Backward of y = x W^T + b (x [M,K], W [N,K], dy [M,N] dense rows of stride ldy) in ONE launch:
-//   g  = pre(dy):  pre_mode 0 none | 1 ReLU mask (g = dy * [ymask > 0], ymask indexed like dy) |
-//                  2 dropout mask (g = dy * keep / (1 - p), element index m*ldy + n, as in the forward)
-//   dx = g . W (may be NULL);  dW (+)= g^T . x;  db (+)= colsum(g) (may be NULL)
-extern "C" int mvf_hlinear_bwd(const float* dy, long ldy, int pre_mode, const float* ymask, float drop_p,
-                               uint64_t drop_seed, uint64_t drop_offset, const float* x, long ldx, const float* W, long ldw,
-                               float* dx, long lddx, float* dW, long lddw, float* db, int M, int N, int K,
-                               int accumulate_params, hipStream_t st) {
-  MVF_CHECK_ARG(dy && x && W && dW && M > 0 && N > 0 && K > 0 && pre_mode >= 0 && pre_mode <= 2);
-  MVF_CHECK_ARG(pre_mode != 1 || ymask != nullptr);
-  MVF_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
+// Backward of y = x W^T + b (x [M,K] rows of stride ldx, W [N,K] rows of stride ldw, dy [M,N] rows of stride ldy,
+// all with unit inner stride) in ONE launch:  dx = dy . W (may be NULL);  dW (+)= dy^T . x;  db (+)= colsum(dy)
+// (may be NULL).  accumulate_params: add into dW / db (the flat gradient buffer) instead of overwriting them.
+extern "C" int mvf_hlinear_bwd(const float* dy, long ldy, const float* x, long ldx, const float* W, long ldw, float* dx,
+                               long lddx, float* dW, long lddw, float* db, int M, int N, int K, int accumulate_params,
+                               hipStream_t st) {
+  MVF_CHECK_ARG(dy && x && W && dW && M > 0 && N > 0 && K > 0);
   HGemmArgs gx{}, gw{};
-  // dX[m, k] = sum_n g[m, n] W[n, k]:   A = dy (rows m, k-index n), B(n, k) = W[n*ldw + k]
+  // dX[m, k] = sum_n dy[m, n] W[n, k]:   A = dy (rows m, k-index n contiguous), B(n, k) = W[n*ldw + k] (k-major)
   gx.A = dy; gx.sam = ldy; gx.sak = 1; gx.B = W; gx.sbk = ldw; gx.sbn = 1; gx.C = dx; gx.ldc = lddx;
-  gx.M = M; gx.N = K; gx.K = N; gx.alpha = 1.f; gx.tab_div = gx.tab_mod = 1;
-  gx.a_mode = pre_mode; gx.amask = ymask;
-  fill_dropout(gx, pre_mode == 2 ? drop_p : 0.f, drop_seed, drop_offset);
-  // dW[n, k] = sum_m g[m, n] x[m, k]:   A(n, m) = dy[m*ldy + n], B(m, k) = x[m*ldx + k]
+  gx.M = M; gx.N = K; gx.K = N; gx.alpha = 1.f; gx.tab_div = gx.tab_mod = 1; gx.d_scale = 1.f;
+  // dW[n, k] = sum_m dy[m, n] x[m, k]:   A(n, m) = dy[m*ldy + n], B(m, k) = x[m*ldx + k]  (both k-major)
   gw.A = dy; gw.sam = 1; gw.sak = ldy; gw.B = x; gw.sbk = ldx; gw.sbn = 1; gw.C = dW; gw.ldc = lddw;
-  gw.M = N; gw.N = K; gw.K = M; gw.alpha = 1.f; gw.tab_div = gw.tab_mod = 1; gw.accumulate = accumulate_params;
-  gw.a_mode = pre_mode; gw.amask = ymask; gw.rowsum = db; gw.rowsum_acc = accumulate_params;
-  fill_dropout(gw, pre_mode == 2 ? drop_p : 0.f, drop_seed, drop_offset);
+  gw.M = N; gw.N = K; gw.K = M; gw.alpha = 1.f; gw.tab_div = gw.tab_mod = 1; gw.d_scale = 1.f;
+  gw.accumulate = accumulate_params; gw.rowsum = db; gw.rowsum_acc = accumulate_params;
   const int dxn = ceil_div(K, 64), dxm = ceil_div(M, 64), dwn = ceil_div(K, 64), dwm = ceil_div(N, 64);
   const int nx = dx != nullptr ? dxn * dxm : 0, nw = dwn * dwm;
-  const bool dxvec = ldy % 4 == 0 && N % 16 == 0 && ((uintptr_t)dy & 15) == 0 &&
-                     (pre_mode != 1 || ((uintptr_t)ymask & 15) == 0);
-#define LAUNCH(VEC, MODE) \
-  hipLaunchKernelGGL((hlinear_bwd_kernel<VEC, MODE>), dim3(nx + nw), dim3(256), 0, st, gx, gw, nx, dxn, dwn)
-  if (pre_mode == 0) { if (dxvec) LAUNCH(true, 0); else LAUNCH(false, 0); }
-  else if (pre_mode == 1) { if (dxvec) LAUNCH(true, 1); else LAUNCH(false, 1); }
-  else { if (dxvec) LAUNCH(true, 2); else LAUNCH(false, 2); }
-#undef LAUNCH
+  hipLaunchKernelGGL(hlinear_bwd_kernel, dim3(nx + nw), dim3(256), 0, st, gx, gw, nx, dxn, dwn, (int)can_vec(dy, ldy),
+                     (int)can_vec(W, ldw), (int)can_vec(dy, ldy), (int)can_vec(x, ldx));
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

@@ -62,7 +62,7 @@ def grad_ready(*params):
 # ------------------------------------------------------------------------------------------------
 class _Linear(torch.autograd.Function):
     """fwd: one GEMM launch with bias / PE table / ReLU / dropout / residual in its epilogue.
-    bwd: ONE launch (mvf_hlinear_bwd) for dX, dW and db, with the ReLU or dropout backward applied to dy on load."""
+    bwd: ONE launch (mvf_hlinear_bwd) for dX, dW and db (after one elementwise pass for a ReLU / dropout mask)."""
 
     @staticmethod
     def forward(ctx, x, w, b, relu, table, tab_div, tab_mod, resid, drop, slots, owners):
@@ -104,13 +104,20 @@ class _Linear(torch.autograd.Function):
             dw = torch.empty(N, K, device=dev, dtype=torch.float32)
             db = torch.empty(N, device=dev, dtype=torch.float32) if has_bias else None
             gw, gb, acc = dw, db, 0
-        mode = 1 if relu else (2 if p > 0.0 else 0)
-        call('mvf_hlinear_bwd', dy.data_ptr(), N, mode, ptr(y), p, seed, off, x.data_ptr(), x.stride(0), w.data_ptr(),
-             w.stride(0), ptr(dx), K, gw.data_ptr(), gw.stride(0) if gw.dim() == 2 else K, ptr(gb) if has_bias else None,
-             M, N, K, acc, stream())
+        d_resid = dy if has_resid else None
+        if relu:                      # g = dy * [y > 0]
+            gm = torch.empty_like(dy)
+            call('mvf_relu_bwd', dy.data_ptr(), y.data_ptr(), gm.data_ptr(), M * N, stream())
+            dy = gm
+        elif p > 0.0:                 # g = dy * keep / (1 - p): the forward's counter-based mask
+            gm = torch.empty_like(dy)
+            call('mvf_dropout_add', dy.data_ptr(), None, gm.data_ptr(), M * N, p, seed, off, stream())
+            dy = gm
+        call('mvf_hlinear_bwd', dy.data_ptr(), N, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), ptr(dx), K,
+             gw.data_ptr(), gw.stride(0) if gw.dim() == 2 else K, ptr(gb) if has_bias else None, M, N, K, acc, stream())
         if slots is not None:
             grad_ready(*owners)
-        return dx, dw, db, None, None, None, None, (dy if has_resid else None), None, None, None
+        return dx, dw, db, None, None, None, None, d_resid, None, None, None
 
 
 def linear(x, w, b=None, relu=False, table=None, tab_div=1, tab_mod=1, resid=None, drop=None, fused=None):

@@ -35,11 +35,21 @@ struct AttnArgs {
 // ------------------------------------------------------------------------------------------------
 // bf16
 // ------------------------------------------------------------------------------------------------
-template <bool TR_READ>
-__global__ __launch_bounds__(256, 2) void vit_attn_bf16_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * KB * 128];
-  char* sk = smem;             // K block: [224][64] bf16, 128-B rows, 16-B chunks XOR-swizzled by (row & 7)
-  char* sv = smem + KB * 128;  // V block: [224][64] bf16, 128-B rows, linear
+// NT = key tiles (of 16) that are computed per key block.  NT == KT is the general form (any N, every tile masked against
+// the valid key count).  NT < KT is the specialisation for ONE key block whose last NT-th tile is the only padded one
+// (ViT-B/16 at 224 px: N = 197 -> NT = 13): all-padding tiles are not computed at all and only tile NT-1 is masked.
+// Compile-time loop bounds matter here: per-tile run-time branches serialise read -> MFMA -> max chains.
+template <bool TR_READ, int NT>
+__global__ __launch_bounds__(256, NT < KT ? 3 : 2) void vit_attn_bf16_kernel(AttnArgs a) {
+  // only the NT*16 keys that are computed are staged: at NT = 13 the block needs 52 KiB, so THREE workgroups (12 waves)
+  // share a CU instead of two -- the per-wave chain read -> MFMA -> softmax -> MFMA is serial, more waves hide it
+  constexpr int KROWS = NT * 16;
+  __shared__ __attribute__((aligned(16))) char smem[2 * KROWS * 128];
+  char* sk = smem;                // K block: [keys][64] bf16, 128-B rows, 16-B chunks XOR-swizzled by (row & 7)
+  char* sv = smem + KROWS * 128;  // V block: [keys][64] bf16, 128-B rows, 32-B chunks XOR-swizzled by ((row >> 1) & 3):
+                               // the transposing reads of one 32-lane half touch rows r, r+2, r+4, r+6 at the same
+                               // column -- 128-B rows put those on one set of banks (4-way conflict, measured 56 % of
+                               // all LDS cycles) unless the chunk index is rotated with the row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int f = blockIdx.x / a.H, h = blockIdx.x % a.H;
@@ -48,6 +58,8 @@ __global__ __launch_bounds__(256, 2) void vit_attn_bf16_kernel(AttnArgs a) {
   const bf16_t* qb = base + h * HD;
   const bf16_t* kbp = base + a.D + h * HD;
   const bf16_t* vbp = base + 2 * a.D + h * HD;
+  // row inside a 32-key step that this lane addresses in the transposing V read: 4g + (li >> 2) (+16)
+  const int vsw = ((2 * g + (li >> 3)) & 3) << 5;          // its chunk rotation, in bytes (same for row + 16)
 
   for (int rd = 0; rd < a.rounds; ++rd) {
     const int qt = (blockIdx.y * a.rounds + rd) * 4 + wave;  // query tile of this wave
@@ -58,17 +70,18 @@ __global__ __launch_bounds__(256, 2) void vit_attn_bf16_kernel(AttnArgs a) {
     for (int ks = 0; ks < 2; ++ks)
       qf[ks] = *reinterpret_cast<const bf16x8_t*>(qb + (size_t)qrow * ld + ks * 32 + g * 8);
 
-    float m_run = -1e30f, l_run = 0.f;
+    float m_run = -1e30f, l_run = 0.f;   // m_run in raw-score units (scores are scaled inside the exp2 argument)
     f32x4_t o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     for (int kb = 0; kb < a.nblk; ++kb) {
+      const int nkeys = min(a.N - kb * KB, KB);            // valid keys of this block
       if (a.nblk > 1 || rd == 0) {
         if (kb > 0 || rd > 0) __syncthreads();  // everyone done with the previous block
         // ---- stage K, V block: thread -> (row = tid/8 + 32*i, chunk = tid%8) ----
 #pragma unroll
-        for (int i = 0; i < KB / 32; ++i) {
+        for (int i = 0; i < (KROWS + 31) / 32; ++i) {
           const int r = (tid >> 3) + 32 * i, c = tid & 7;
           const int key = kb * KB + r;
           uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
@@ -76,8 +89,10 @@ __global__ __launch_bounds__(256, 2) void vit_attn_bf16_kernel(AttnArgs a) {
             kv = *reinterpret_cast<const uint4*>(kbp + (size_t)key * ld + c * 8);
             vv = *reinterpret_cast<const uint4*>(vbp + (size_t)key * ld + c * 8);
           }
-          *reinterpret_cast<uint4*>(sk + r * 128 + ((c ^ (r & 7)) << 4)) = kv;
-          *reinterpret_cast<uint4*>(sv + r * 128 + (c << 4)) = vv;
+          if (KROWS % 32 == 0 || r < KROWS) {
+            *reinterpret_cast<uint4*>(sk + r * 128 + ((c ^ (r & 7)) << 4)) = kv;
+            *reinterpret_cast<uint4*>(sv + r * 128 + ((c ^ (((r >> 1) & 3) << 1)) << 4)) = vv;
+          }
         }
         __syncthreads();
       }
@@ -86,73 +101,84 @@ __global__ __launch_bounds__(256, 2) void vit_attn_bf16_kernel(AttnArgs a) {
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         s[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (kt < NT) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int row = kt * 16 + li;
-          const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sk + row * 128 + (((ks * 4 + g) ^ (li & 7)) << 4));
-          s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+          for (int ks = 0; ks < 2; ++ks) {
+            const int row = kt * 16 + li;
+            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sk + row * 128 + (((ks * 4 + g) ^ (li & 7)) << 4));
+            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+          }
         }
       }
-      // ---- online softmax (log2 domain) ----
       float mx = -1e30f;
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
+      for (int kt = 0; kt < NT; ++kt) {
+        if (NT == KT || kt == NT - 1) {   // padded keys -> -inf (general form: every tile; specialised: the last one)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kb * KB + kt * 16 + 4 * g + r;
-          float v = s[kt][r] * a.scale_log2;
-          v = key < a.N ? v : -1e30f;
-          s[kt][r] = v;
-          mx = fmaxf(mx, v);
+          for (int r = 0; r < 4; ++r) s[kt][r] = kt * 16 + 4 * g + r < nkeys ? s[kt][r] : -1e30f;
         }
+        mx = fmaxf(fmaxf(mx, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+      }
+      // ---- online softmax: p = exp2(scale_log2 * (s - m)), the scale folded into one fma per score ----
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      const float nm = -m_new * a.scale_log2;
       float ls = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
+      for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], a.scale_log2, nm));
           s[kt][r] = p;
           ls += p;
         }
+      }
       ls += __shfl_xor(ls, 16, 64);
       ls += __shfl_xor(ls, 32, 64);
-      l_run = l_run * alpha + ls;
+      if (kb > 0) {            // a single key block (N <= 224, every ViT-B/16 config) never rescales
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * a.scale_log2);
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+      }
+      l_run += ls;
       m_run = m_new;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
       // ---- O^T += V^T P^T : k-step = 32 keys = score tiles (2s, 2s+1) ----
 #pragma unroll
-      for (int st = 0; st < KT / 2; ++st) {
-        union { bf16x8_t v; uint32_t u[4]; } pf;
-        pf.u[0] = pack_bf16x2(s[2 * st][0], s[2 * st][1]);
-        pf.u[1] = pack_bf16x2(s[2 * st][2], s[2 * st][3]);
-        pf.u[2] = pack_bf16x2(s[2 * st + 1][0], s[2 * st + 1][1]);
-        pf.u[3] = pack_bf16x2(s[2 * st + 1][2], s[2 * st + 1][3]);
+      for (int st = 0; st < (NT + 1) / 2; ++st) {
+        {
+          union { bf16x8_t v; uint32_t u[4]; } pf;
+          pf.u[0] = pack_bf16x2(s[2 * st][0], s[2 * st][1]);
+          pf.u[1] = pack_bf16x2(s[2 * st][2], s[2 * st][3]);
+          pf.u[2] = pack_bf16x2(s[2 * st + 1][0], s[2 * st + 1][1]);
+          pf.u[3] = pack_bf16x2(s[2 * st + 1][2], s[2 * st + 1][3]);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          union { bf16x8_t v; bf16x4_t h[2]; bf16_t e[8]; } vf;
-          if constexpr (TR_READ) {
-            // group of 16 lanes reads a 4-key x 16-d block transposed: lane supplies &V[key0+4g+(li>>2)][d0+4*(li&3)],
-            // receives V[key0+4g+0..3][d0+li]
-            const char* p0 = sv + (st * 32 + 4 * g + (li >> 2)) * 128 + (dt * 16 + 4 * (li & 3)) * 2;
-            vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) bf16x4_t*)(p0));
-            vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) bf16x4_t*)(p0 + 16 * 128));
-          } else {
+          for (int dt = 0; dt < 4; ++dt) {
+            union { bf16x8_t v; bf16x4_t h[2]; bf16_t e[8]; } vf;
+            if constexpr (TR_READ) {
+              // group of 16 lanes reads a 4-key x 16-d block transposed: lane supplies &V[key0+4g+(li>>2)][d0+4*(li&3)],
+              // receives V[key0+4g+0..3][d0+li]
+              const char* p0 = sv + (st * 32 + 4 * g + (li >> 2)) * 128 + (((dt * 32) ^ vsw) + 8 * (li & 3));
+              vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (__attribute__((address_space(3))) bf16x4_t*)(p0));
+              if (2 * st + 1 < NT)
+                vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) bf16x4_t*)(p0 + 16 * 128));
+              else
+                vf.h[1] = (bf16x4_t){0, 0, 0, 0};   // keys beyond the staged block: their probabilities are 0 too
+            } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const int key = st * 32 + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
-              vf.e[j] = *reinterpret_cast<const bf16_t*>(sv + key * 128 + (dt * 16 + li) * 2);
+              for (int j = 0; j < 8; ++j) {
+                const int key = st * 32 + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+                vf.e[j] = key < KROWS ? *reinterpret_cast<const bf16_t*>(sv + key * 128 + (((dt * 32) ^ (((key >> 1) & 3) << 5)) + li * 2))
+                                      : (bf16_t)0;
+              }
             }
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
           }
-          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
         }
       }
     }
@@ -303,8 +329,10 @@ int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H
   a.scale_log2 = LOG2E / 8.0f;  // 64^-0.5 * log2(e)
   dim3 grid(F * H, chunks);
   if (dtype == MVF_BF16) {
-    if (variant == 0) hipLaunchKernelGGL(vit_attn_bf16_kernel<true>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(vit_attn_bf16_kernel<false>, grid, dim3(256), 0, st, a);
+    const int ntile = ceil_div(N, 16);
+    if (variant != 0) hipLaunchKernelGGL((vit_attn_bf16_kernel<false, KT>), grid, dim3(256), 0, st, a);
+    else if (a.nblk == 1 && ntile == 13) hipLaunchKernelGGL((vit_attn_bf16_kernel<true, 13>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((vit_attn_bf16_kernel<true, KT>), grid, dim3(256), 0, st, a);
   } else if (dtype == MVF_F32) {
     static bool attr = false;
     if (!attr) {

@@ -53,10 +53,23 @@ __device__ __forceinline__ int lds_at(int k, int c) { return k * LDT + (c ^ (((k
 // Global -> registers for one [TK][64] operand tile.  X(r, k) = X[r*sr + k*sk], r = tile row (m or n), exactly one of
 // sr, sk is 1.  KMAJOR (sr == 1): thread -> (k = t/16 [+16], rows 4*(t%16)..+3), float4 along the rows.
 // else (sk == 1): thread -> (row = t/8 [+32], k = 4*(t%8)..+3), float4 along k.
-template <bool KMAJOR>
+// GUARD == false: the tile is known to be fully in range and 16-byte loadable (M, N multiples of 64, K of 32, aligned
+// strides) -- straight-line code, all loads of a k step issue back to back.  GUARD == true (ragged shapes such as the
+// 387-wide first FC layer, tiny query GEMMs) pays per-load range checks.
+template <bool KMAJOR, bool GUARD>
 __device__ __forceinline__ void tile_load(const float* X, long sr, long sk, int r0, int R, int k0, int K, bool vec,
                                           f32x4_t (&v)[2]) {
   const int t = threadIdx.x;
+  if constexpr (!GUARD) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if constexpr (KMAJOR)
+        v[h] = *reinterpret_cast<const f32x4_t*>(X + (long)(k0 + (t >> 4) + 16 * h) * sk + r0 + (t & 15) * 4);
+      else
+        v[h] = *reinterpret_cast<const f32x4_t*>(X + (long)(r0 + (t >> 3) + 32 * h) * sr + k0 + (t & 7) * 4);
+    }
+    return;
+  }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     f32x4_t x = {0.f, 0.f, 0.f, 0.f};
@@ -102,7 +115,7 @@ __device__ __forceinline__ void tile_store(float* T, const f32x4_t (&v)[2]) {
 }
 
 // one 64x64 output tile (bx, by) of the problem `a`; lds: 4 * TILE_F floats
-template <bool AKM, bool BKM>
+template <bool AKM, bool BKM, bool GUARD>
 __device__ __forceinline__ void hgemm_tile(const HGemmArgs& a, int bx, int by, float* lds, bool avec, bool bvec) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -118,8 +131,8 @@ __device__ __forceinline__ void hgemm_tile(const HGemmArgs& a, int bx, int by, f
 
   f32x4_t ra[2], rb[2];
   const int nt = (a.K + TK - 1) / TK;
-  tile_load<AKM>(a.A, a.sam, a.sak, m0, a.M, 0, a.K, avec, ra);
-  tile_load<BKM>(a.B, a.sbn, a.sbk, n0, a.N, 0, a.K, bvec, rb);
+  tile_load<AKM, GUARD>(a.A, a.sam, a.sak, m0, a.M, 0, a.K, avec, ra);
+  tile_load<BKM, GUARD>(a.B, a.sbn, a.sbk, n0, a.N, 0, a.K, bvec, rb);
   tile_store<AKM>(lds, ra);
   tile_store<BKM>(lds + TILE_F, rb);
   __syncthreads();
@@ -127,8 +140,9 @@ __device__ __forceinline__ void hgemm_tile(const HGemmArgs& a, int bx, int by, f
     const float* As = lds + (t & 1) * 2 * TILE_F;
     const float* Bs = As + TILE_F;
     if (t + 1 < nt) {   // request the next tile before this tile's MFMAs
-      tile_load<AKM>(a.A, a.sam, a.sak, m0, a.M, (t + 1) * TK, a.K, avec, ra);
-      tile_load<BKM>(a.B, a.sbn, a.sbk, n0, a.N, (t + 1) * TK, a.K, bvec, rb);
+      tile_load<AKM, GUARD>(a.A, a.sam, a.sak, m0, a.M, (t + 1) * TK, a.K, avec, ra);
+      tile_load<BKM, GUARD>(a.B, a.sbn, a.sbk, n0, a.N, (t + 1) * TK, a.K, bvec, rb);
+      __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the MFMAs (the scheduler would sink them)
     }
 #pragma unroll
     for (int q = 0; q < TK / 4; ++q) {
@@ -212,20 +226,21 @@ __device__ __forceinline__ void hgemm_tile(const HGemmArgs& a, int bx, int by, f
 }
 
 // operand forms: A k-major <=> sak != 1 (then sam == 1); B k-major <=> sbk != 1 (then sbn == 1)
-template <bool AKM, bool BKM>
+template <bool AKM, bool BKM, bool GUARD>
 __global__ __launch_bounds__(256) void hgemm_kernel(HGemmArgs a, int avec, int bvec) {
   __shared__ __attribute__((aligned(16))) float lds[4 * TILE_F];
-  hgemm_tile<AKM, BKM>(a, blockIdx.x, blockIdx.y, lds, avec != 0, bvec != 0);
+  hgemm_tile<AKM, BKM, GUARD>(a, blockIdx.x, blockIdx.y, lds, avec != 0, bvec != 0);
 }
 
 // Backward of y = x W^T + b in one launch: tiles [0, nx) compute dX = dy . W (A = dy k-contiguous, B = W k-major),
 // tiles [nx, nx + nw) compute dW (+)= dy^T . x (both k-major) and, in their first tile column, db (+)= colsum(dy).
+template <bool GUARD>
 __global__ __launch_bounds__(256) void hlinear_bwd_kernel(HGemmArgs dx, HGemmArgs dw, int nx, int dx_tiles_n, int dw_tiles_n,
                                                           int dx_avec, int dx_bvec, int dw_avec, int dw_bvec) {
   __shared__ __attribute__((aligned(16))) float lds[4 * TILE_F];
   const int b = blockIdx.x;
-  if (b < nx) hgemm_tile<false, true>(dx, b % dx_tiles_n, b / dx_tiles_n, lds, dx_avec != 0, dx_bvec != 0);
-  else hgemm_tile<true, true>(dw, (b - nx) % dw_tiles_n, (b - nx) / dw_tiles_n, lds, dw_avec != 0, dw_bvec != 0);
+  if (b < nx) hgemm_tile<false, true, GUARD>(dx, b % dx_tiles_n, b / dx_tiles_n, lds, dx_avec != 0, dx_bvec != 0);
+  else hgemm_tile<true, true, GUARD>(dw, (b - nx) % dw_tiles_n, (b - nx) / dw_tiles_n, lds, dw_avec != 0, dw_bvec != 0);
 }
 
 // out[c] (+)= sum_r x[r*ld + c]   -- bias gradients that are not attached to a weight-gradient GEMM
@@ -279,10 +294,17 @@ extern "C" int mvf_hgemm_ex(const float* A, long sam, long sak, const float* B, 
   const bool akm = sak != 1, bkm = sbk != 1;
   const int avec = can_vec(A, akm ? sak : sam), bvec = can_vec(B, bkm ? sbk : sbn);
   dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
-  if (akm && bkm) hipLaunchKernelGGL((hgemm_kernel<true, true>), grid, dim3(256), 0, st, a, avec, bvec);
-  else if (akm) hipLaunchKernelGGL((hgemm_kernel<true, false>), grid, dim3(256), 0, st, a, avec, bvec);
-  else if (bkm) hipLaunchKernelGGL((hgemm_kernel<false, true>), grid, dim3(256), 0, st, a, avec, bvec);
-  else hipLaunchKernelGGL((hgemm_kernel<false, false>), grid, dim3(256), 0, st, a, avec, bvec);
+  const bool full = avec && bvec && M % 64 == 0 && N % 64 == 0 && K % TK == 0;
+#define HG(AK, BK)                                                                                          \
+  do {                                                                                                      \
+    if (full) hipLaunchKernelGGL((hgemm_kernel<AK, BK, false>), grid, dim3(256), 0, st, a, avec, bvec);     \
+    else hipLaunchKernelGGL((hgemm_kernel<AK, BK, true>), grid, dim3(256), 0, st, a, avec, bvec);           \
+  } while (0)
+  if (akm && bkm) HG(true, true);
+  else if (akm) HG(true, false);
+  else if (bkm) HG(false, true);
+  else HG(false, false);
+#undef HG
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }
@@ -304,8 +326,12 @@ extern "C" int mvf_hlinear_bwd(const float* dy, long ldy, const float* x, long l
   gw.accumulate = accumulate_params; gw.rowsum = db; gw.rowsum_acc = accumulate_params;
   const int dxn = ceil_div(K, 64), dxm = ceil_div(M, 64), dwn = ceil_div(K, 64), dwm = ceil_div(N, 64);
   const int nx = dx != nullptr ? dxn * dxm : 0, nw = dwn * dwm;
-  hipLaunchKernelGGL(hlinear_bwd_kernel, dim3(nx + nw), dim3(256), 0, st, gx, gw, nx, dxn, dwn, (int)can_vec(dy, ldy),
-                     (int)can_vec(W, ldw), (int)can_vec(dy, ldy), (int)can_vec(x, ldx));
+  const bool full = can_vec(dy, ldy) && can_vec(W, ldw) && can_vec(x, ldx) && M % 64 == 0 && N % 64 == 0 && K % 64 == 0;
+  if (full)
+    hipLaunchKernelGGL(hlinear_bwd_kernel<false>, dim3(nx + nw), dim3(256), 0, st, gx, gw, nx, dxn, dwn, 1, 1, 1, 1);
+  else
+    hipLaunchKernelGGL(hlinear_bwd_kernel<true>, dim3(nx + nw), dim3(256), 0, st, gx, gw, nx, dxn, dwn,
+                       (int)can_vec(dy, ldy), (int)can_vec(W, ldw), (int)can_vec(dy, ldy), (int)can_vec(x, ldx));
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

@@ -81,6 +81,11 @@ int mvf_gemm_tc(int dtype, int epi, const void* A, int lda, const void* W, int l
  * persistent 256x256 8-phase kernel, else 128x128), 1 always 128x128, 2 only 256x256 (MVF_ERR_UNSUPPORTED where it
  * cannot run), 3 the 256x256 kernel with one workgroup per tile instead of one per CU */
 int mvf_gemm_tc_select(int variant);
+/* diagnostic: out[2b] = XCD id, out[2b+1] = HW_ID of workgroup b of a 1-D launch (placement study, never on the path) */
+int mvf_debug_xcc_map(int* out, int nblocks, int threads, int lds_bytes, hipStream_t stream);
+/* CUs available to the stream the GEMMs are launched on (CU-masked streams); 0 = all CUs of the device (default).
+ * The persistent 256x256 kernel launches one workgroup per available CU. */
+int mvf_gemm_tc_set_cus(int n);
 /* diagnostic build of the 256x256 kernel: per-block s_memtime stamps into buf[blocks][2][8] (NULL = off, the default) */
 int mvf_gemm_tc_debug_stamps(unsigned long long* buf);
 int mvf_patchify(int dtype, const float* frames, void* out, int F, int H, int W, int P, hipStream_t stream);

@@ -43,6 +43,7 @@ def S():
 
 # ------------------------------------------------------------------------------------------------ gemm_tc256
 @pytest.mark.parametrize('M,N,K,epi', [(256, 256, 128, 0), (2000, 768, 768, 0), (1576, 2304, 768, 1), (777, 384, 1536, 0),
+                                        (70000, 1024, 256, 1), (9000, 3072, 128, 0),
                                         (197 * 8, 768, 3072, 2), (196 * 6, 768, 768, 3)])
 def test_gemm_tc256_equals_tc128_bitwise(M, N, K, epi):
     """The 256x256 8-phase kernel accumulates every output in the same k order as the 128x128 kernel (64-wide K tiles,

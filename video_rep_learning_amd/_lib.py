@@ -23,6 +23,8 @@ SIGNATURES = {
     'mvf_gemm_tc': 'iipipippipipippiiiip',
     'mvf_gemm_tc_select': 'i',
     'mvf_gemm_tc_debug_stamps': 'p',
+    'mvf_gemm_tc_set_cus': 'i',
+    'mvf_debug_xcc_map': 'piiip',
     'mvf_patchify': 'ippiiiip',
     'mvf_layernorm_fwd': 'ipzpppziifp',
     'mvf_vit_attn_fwd': 'ippiiiiip',

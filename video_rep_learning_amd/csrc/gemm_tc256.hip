@@ -40,6 +40,8 @@
 //    the epilogue would make hipcc drain the next tile's DMAs).
 //  * operands swapped (W fragment as MFMA-A) so a lane owns 4 consecutive output columns; v_permlane16_swap pairs two
 //    tiles into 16-byte stores (gemm_tc_epi.h).
+//  * tried and rejected: N-grouping (each XCD serving only nbn/4 weight panels so that W stays L2-resident) -- no change
+//    at all on fc1 (315 us either way): W re-fetches are not what the loop waits for.
 //  * tried and rejected (PMC): rotating the K loop per A row-panel to shorten W's L2 re-use distance -- the L2 hits come
 //    from workgroups reading the SAME slices at the SAME time; rotation cut the hit rate from 74 % to 47 % (fc2).
 //  * XCD-aware static tile walk: workgroups b, b+8, ... share an XCD (round-robin dispatch, speed only); XCD x owns a

@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int TQ = 128;   // threads per workgroup = rows owned (queries or keys)
+constexpr int TQ = 128;   // threads per workgroup = rows owned (queries or keys); 64 measured no faster (dK/dV slower)
 constexpr int TK = 64;    // rows of the streamed operand per LDS tile
 constexpr float LOG2E = 1.4426950408889634f;
 

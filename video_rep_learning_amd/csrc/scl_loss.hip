@@ -90,6 +90,19 @@ __device__ __forceinline__ void load_rows(const SclArgs& a, float* dst, Meta* md
   }
 }
 
+// Columns that can interact with rows i0 .. i0+RB-1.  With 'single' in NEGATIVE_TYPE every pair outside the row's own
+// video has weight 0 and no label mass in BOTH directions (scl.py:74-77), so only the columns of the videos these rows
+// belong to are visited: 2T of M columns -- 4x less work at B = 4, 32x with 8 ranks' embeddings gathered.
+__device__ __forceinline__ void col_range(const SclArgs& a, int i0, int& kbeg, int& kend) {
+  kbeg = 0;
+  kend = a.M;
+  if (a.single) {
+    const int per = 2 * a.T;
+    kbeg = (min(i0, a.M - 1) / per) * per;
+    kend = (min(i0 + RB - 1, a.M - 1) / per + 1) * per;
+  }
+}
+
 __global__ __launch_bounds__(256) void scl_stats_kernel(SclArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Smem sm(smem_raw, a.E);
@@ -98,7 +111,9 @@ __global__ __launch_bounds__(256) void scl_stats_kernel(SclArgs a) {
   const int E1 = a.E + 1;
   load_rows(a, sm.er, sm.mr, i0, RB);
   float Ssum = 0.f, Rsum = 0.f;
-  for (int k0 = 0; k0 < a.M; k0 += CB) {
+  int kbeg, kend;
+  col_range(a, i0, kbeg, kend);
+  for (int k0 = kbeg; k0 < kend; k0 += CB) {
     __syncthreads();
     load_rows(a, sm.ec, sm.mc, k0, CB);
     __syncthreads();
@@ -175,7 +190,9 @@ __global__ __launch_bounds__(256) void scl_grad_kernel(SclArgs a) {
   float acc[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-  for (int k0 = 0; k0 < a.M; k0 += CB) {
+  int kbeg, kend;
+  col_range(a, i0, kbeg, kend);
+  for (int k0 = kbeg; k0 < kend; k0 += CB) {
     __syncthreads();
     load_rows(a, sm.ec, sm.mc, k0, CB);
     __syncthreads();

@@ -102,7 +102,34 @@ __global__ void cast_bf16_kernel(const float* __restrict__ in, bf16_t* __restric
   }
 }
 
+// diagnostic: which XCD (HW_REG_XCC_ID) and CU each workgroup of a 1-D launch lands on
+__global__ void xcc_map_kernel(int* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    unsigned xcc, hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    out[2 * blockIdx.x] = (int)(xcc & 0xf);
+    out[2 * blockIdx.x + 1] = (int)hwid;
+  }
+  // stay resident for a moment so that consecutive workgroups spread over CUs like a real kernel's do
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  while (__builtin_amdgcn_s_memtime() - t0 < 20000ull) {}
+}
+
 }  // namespace
+
+extern "C" int mvf_debug_xcc_map(int* out, int nblocks, int threads, int lds_bytes, hipStream_t st) {
+  MVF_CHECK_ARG(out && nblocks > 0 && threads > 0 && threads <= 1024 && lds_bytes >= 0 && lds_bytes <= 160 * 1024);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xcc_map_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(xcc_map_kernel, dim3(nblocks), dim3(threads), lds_bytes, st, out);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
 
 int mvf_im2col_impl(int dtype, const float* img, void* out, int F, int H, int W, int P, hipStream_t st) {
   MVF_CHECK_ARG(img && out && F > 0 && H % P == 0 && W % P == 0 && P % 4 == 0 && W % 4 == 0);

@@ -307,7 +307,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
 #undef STAMP
 }
 
+int g_cu_budget = 0;   // > 0: CUs the caller's stream may use (CU-masked streams), see mvf_gemm_tc_set_cus
+
 int num_cus() {
+  if (g_cu_budget > 0) return g_cu_budget;
   static int n = 0;
   if (n == 0) {
     int dev = 0;
@@ -336,6 +339,14 @@ int launch(const GemmTcArgs& a, bool persistent, hipStream_t st) {
 }
 
 }  // namespace
+
+// The persistent launch sizes its grid to one workgroup per CU.  On a CU-masked stream (hipExtStreamCreateWithCUMask) fewer
+// CUs are available than the device reports; the caller states how many (0 = what the device reports).
+extern "C" int mvf_gemm_tc_set_cus(int n) {
+  MVF_CHECK_ARG(n >= 0 && n <= 4096);
+  g_cu_budget = n;
+  return MVF_OK;
+}
 
 int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, bool persistent, hipStream_t st) {
   if (a.K % 128 != 0 || a.K < 128 || a.N % 32 != 0) return MVF_ERR_ARG;

@@ -77,7 +77,31 @@ __global__ __launch_bounds__(256, NT < KT ? 3 : 2) void vit_attn_bf16_kernel(Att
 
     for (int kb = 0; kb < a.nblk; ++kb) {
       const int nkeys = min(a.N - kb * KB, KB);            // valid keys of this block
-      if (a.nblk > 1 || rd == 0) {
+      if constexpr (NT < KT) {
+        // ---- one key block, staged once per workgroup by LDS-DMA (no VGPR round trip): K pieces first, then V; the
+        // S^T MFMAs and the softmax only need K, so V's HBM latency hides under them (ablation: the synchronous
+        // load -> ds_write staging cost 35 % of the kernel).  A piece = 8 rows x 128 B = one wave-instruction; lane ->
+        // (row 8p + lane/8, physical chunk lane%8); both swizzles are applied on the SOURCE chunk index.
+        if (rd == 0) {
+          constexpr int NP = KROWS / 8;
+          asm volatile("" : "+v"(qf[0]), "+v"(qf[1]));   // Q loads are waited for here, before any DMA is in flight
+          const int prow = lane >> 3, pc = lane & 7;
+          for (int p = wave; p < NP; p += 4) {
+            const int r = p * 8 + prow;
+            const bf16_t* src = kbp + (size_t)min(r, a.N - 1) * ld + ((pc ^ (r & 7)) << 3);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sk + p * 1024), 16, 0, 0);
+          }
+          for (int p = wave; p < NP; p += 4) {
+            const int r = p * 8 + prow;    // rows >= N repeat row N-1: finite values, their probabilities are 0
+            const bf16_t* src = vbp + (size_t)min(r, a.N - 1) * ld + ((pc ^ (((r >> 1) & 3) << 1)) << 3);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sv + p * 1024), 16, 0, 0);
+          }
+          // K landed <=> all but this wave's V pieces retired (waves < NP % 4 issued one piece more)
+          if (wave < (NP & 3)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NP + 3) / 4) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP / 4) : "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+      } else if (a.nblk > 1 || rd == 0) {
         if (kb > 0 || rd > 0) __syncthreads();  // everyone done with the previous block
         // ---- stage K, V block: thread -> (row = tid/8 + 32*i, chunk = tid%8) ----
 #pragma unroll
@@ -146,6 +170,12 @@ __global__ __launch_bounds__(256, NT < KT ? 3 : 2) void vit_attn_bf16_kernel(Att
       }
       l_run += ls;
       m_run = m_new;
+      if constexpr (NT < KT) {
+        if (rd == 0) {   // V landed (every wave waits for its own pieces, then the workgroup meets)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+      }
       // ---- O^T += V^T P^T : k-step = 32 keys = score tiles (2s, 2s+1) ----
 #pragma unroll
       for (int st = 0; st < (NT + 1) / 2; ++st) {

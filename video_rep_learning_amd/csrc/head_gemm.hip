@@ -15,11 +15,11 @@
 //   or re-loads the mask, 2.5x slower than one 5-us elementwise pass.)
 //
 // gfx950 design: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain), 64x64 output tile per workgroup (4 waves x 32x32),
-// 32-deep k steps.  Whatever the operand's layout -- k contiguous (x, W in the forward), or k strided with the tile
-// index contiguous (dy and x in dW = dy^T x, W in dX = dy W) -- its [32 k][64 rows] tile is fetched with coalesced
+// 64-deep k steps.  Whatever the operand's layout -- k contiguous (x, W in the forward), or k strided with the tile
+// index contiguous (dy and x in dW = dy^T x, W in dX = dy W) -- its [64 k][64 rows] tile is fetched with coalesced
 // 16-byte loads along the CONTIGUOUS direction and put into LDS k-major ([k][row]), from where
 // each lane reads the one element per MFMA the 16x16x4 layout wants (lane (r, g): row r, k = 4q + g): scalar LDS
-// reads, conflict-free (row stride 80 floats + an XOR swizzle of the 4-float column groups).  Two LDS buffers; the next tile's global loads are issued before the current tile's 32 MFMAs
+// reads, conflict-free (row stride 80 floats + an XOR swizzle of the 4-float column groups).  Two LDS buffers; the next tile's global loads are issued before the current tile's 64 MFMAs
 // and written to the other buffer after them: one barrier per k step, global latency hidden under the matrix pipe.
 // The matrices are a few MB and L2-resident and M is 768 rows, so this is latency- not bandwidth-bound work; operands
 // swapped in the MFMA so a lane owns 4 consecutive n (16-byte stores).
@@ -42,9 +42,10 @@ struct HGemmArgs {
   float* rowsum; int rowsum_acc;   // rowsum[m] (+)= sum_k A(m,k); written by the first column of tiles
 };
 
-constexpr int TK = 32;            // k step
+constexpr int TK = 64;            // k step: 64 MFMAs (2048 cycles) per wave and barrier -- covers the L2/MALL latency of the next tile's loads
 constexpr int LDT = 80;           // LDS row stride (floats): rows g, g+1 of a fragment read land 16 banks apart
 constexpr int TILE_F = TK * LDT;  // floats per operand tile
+constexpr int NPASS = TK / 16;    // 16-byte loads per thread and operand tile (256 threads x 4 floats = 16 k-rows of 64)
 // element (k, c) of a tile lives at k*LDT + (c ^ SW(k)): the XOR moves whole 4-float groups, so the 16-byte k-major
 // stores stay contiguous, fragment reads (16 consecutive c at fixed k) stay conflict-free, and the TRANSPOSING scalar
 // stores of a k-contiguous operand (8 lanes = 8 different k-quads, same c) spread over 8 banks instead of 1
@@ -58,20 +59,20 @@ __device__ __forceinline__ int lds_at(int k, int c) { return k * LDT + (c ^ (((k
 // 387-wide first FC layer, tiny query GEMMs) pays per-load range checks.
 template <bool KMAJOR, bool GUARD>
 __device__ __forceinline__ void tile_load(const float* X, long sr, long sk, int r0, int R, int k0, int K, bool vec,
-                                          f32x4_t (&v)[2]) {
+                                          f32x4_t (&v)[NPASS]) {
   const int t = threadIdx.x;
   if constexpr (!GUARD) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NPASS; ++h) {
       if constexpr (KMAJOR)
         v[h] = *reinterpret_cast<const f32x4_t*>(X + (long)(k0 + (t >> 4) + 16 * h) * sk + r0 + (t & 15) * 4);
       else
-        v[h] = *reinterpret_cast<const f32x4_t*>(X + (long)(r0 + (t >> 3) + 32 * h) * sr + k0 + (t & 7) * 4);
+        v[h] = *reinterpret_cast<const f32x4_t*>(X + (long)(r0 + (t >> 3) + 32 * (h & 1)) * sr + k0 + (t & 7) * 4 + 32 * (h >> 1));
     }
     return;
   }
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < NPASS; ++h) {
     f32x4_t x = {0.f, 0.f, 0.f, 0.f};
     if constexpr (KMAJOR) {
       const int k = k0 + (t >> 4) + 16 * h, r = r0 + (t & 15) * 4;
@@ -84,7 +85,7 @@ __device__ __forceinline__ void tile_load(const float* X, long sr, long sk, int 
         }
       }
     } else {
-      const int r = r0 + (t >> 3) + 32 * h, k = k0 + (t & 7) * 4;
+      const int r = r0 + (t >> 3) + 32 * (h & 1), k = k0 + (t & 7) * 4 + 32 * (h >> 1);
       if (r < R) {
         const float* p = X + (long)r * sr + k;
         if (vec && k + 3 < K) x = *reinterpret_cast<const f32x4_t*>(p);
@@ -100,14 +101,14 @@ __device__ __forceinline__ void tile_load(const float* X, long sr, long sk, int 
 
 // registers -> LDS tile [k][row]
 template <bool KMAJOR>
-__device__ __forceinline__ void tile_store(float* T, const f32x4_t (&v)[2]) {
+__device__ __forceinline__ void tile_store(float* T, const f32x4_t (&v)[NPASS]) {
   const int t = threadIdx.x;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < NPASS; ++h) {
     if constexpr (KMAJOR) {
       *reinterpret_cast<f32x4_t*>(T + lds_at((t >> 4) + 16 * h, (t & 15) * 4)) = v[h];
     } else {
-      const int r = (t >> 3) + 32 * h, k = (t & 7) * 4;
+      const int r = (t >> 3) + 32 * (h & 1), k = (t & 7) * 4 + 32 * (h >> 1);
 #pragma unroll
       for (int s = 0; s < 4; ++s) T[lds_at(k + s, r)] = v[h][s];
     }
@@ -129,7 +130,7 @@ __device__ __forceinline__ void hgemm_tile(const HGemmArgs& a, int bx, int by, f
   float rs[2] = {0.f, 0.f};
   const bool want_rs = a.rowsum != nullptr && bx == 0 && (wave & 1) == 0;
 
-  f32x4_t ra[2], rb[2];
+  f32x4_t ra[NPASS], rb[NPASS];
   const int nt = (a.K + TK - 1) / TK;
   tile_load<AKM, GUARD>(a.A, a.sam, a.sak, m0, a.M, 0, a.K, avec, ra);
   tile_load<BKM, GUARD>(a.B, a.sbn, a.sbk, n0, a.N, 0, a.K, bvec, rb);
@@ -228,7 +229,7 @@ __device__ __forceinline__ void hgemm_tile(const HGemmArgs& a, int bx, int by, f
 // operand forms: A k-major <=> sak != 1 (then sam == 1); B k-major <=> sbk != 1 (then sbn == 1)
 template <bool AKM, bool BKM, bool GUARD>
 __global__ __launch_bounds__(256) void hgemm_kernel(HGemmArgs a, int avec, int bvec) {
-  __shared__ __attribute__((aligned(16))) float lds[4 * TILE_F];
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // 4 * TILE_F floats (80 KiB)
   hgemm_tile<AKM, BKM, GUARD>(a, blockIdx.x, blockIdx.y, lds, avec != 0, bvec != 0);
 }
 
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256) void hgemm_kernel(HGemmArgs a, int avec, int b
 template <bool GUARD>
 __global__ __launch_bounds__(256) void hlinear_bwd_kernel(HGemmArgs dx, HGemmArgs dw, int nx, int dx_tiles_n, int dw_tiles_n,
                                                           int dx_avec, int dx_bvec, int dw_avec, int dw_bvec) {
-  __shared__ __attribute__((aligned(16))) float lds[4 * TILE_F];
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // 4 * TILE_F floats (80 KiB)
   const int b = blockIdx.x;
   if (b < nx) hgemm_tile<false, true, GUARD>(dx, b % dx_tiles_n, b / dx_tiles_n, lds, dx_avec != 0, dx_bvec != 0);
   else hgemm_tile<true, true, GUARD>(dw, (b - nx) % dw_tiles_n, (b - nx) / dw_tiles_n, lds, dw_avec != 0, dw_bvec != 0);
@@ -258,6 +259,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     out[c] = accumulate ? out[c] + s : s;
   }
+}
+
+constexpr int LDS_B = 4 * TILE_F * 4;   // dynamic LDS per workgroup (above the 64 KiB static limit)
+
+template <typename K>
+void allow_lds(K kern) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
 }
 
 // 16-byte loads along the contiguous direction are legal when base and the other stride keep 16-B alignment
@@ -297,8 +305,10 @@ extern "C" int mvf_hgemm_ex(const float* A, long sam, long sak, const float* B, 
   const bool full = avec && bvec && M % 64 == 0 && N % 64 == 0 && K % TK == 0;
 #define HG(AK, BK)                                                                                          \
   do {                                                                                                      \
-    if (full) hipLaunchKernelGGL((hgemm_kernel<AK, BK, false>), grid, dim3(256), 0, st, a, avec, bvec);     \
-    else hipLaunchKernelGGL((hgemm_kernel<AK, BK, true>), grid, dim3(256), 0, st, a, avec, bvec);           \
+    allow_lds(hgemm_kernel<AK, BK, false>);                                                                 \
+    allow_lds(hgemm_kernel<AK, BK, true>);                                                                  \
+    if (full) hipLaunchKernelGGL((hgemm_kernel<AK, BK, false>), grid, dim3(256), LDS_B, st, a, avec, bvec);     \
+    else hipLaunchKernelGGL((hgemm_kernel<AK, BK, true>), grid, dim3(256), LDS_B, st, a, avec, bvec);           \
   } while (0)
   if (akm && bkm) HG(true, true);
   else if (akm) HG(true, false);
@@ -327,10 +337,12 @@ extern "C" int mvf_hlinear_bwd(const float* dy, long ldy, const float* x, long l
   const int dxn = ceil_div(K, 64), dxm = ceil_div(M, 64), dwn = ceil_div(K, 64), dwm = ceil_div(N, 64);
   const int nx = dx != nullptr ? dxn * dxm : 0, nw = dwn * dwm;
   const bool full = can_vec(dy, ldy) && can_vec(W, ldw) && can_vec(x, ldx) && M % 64 == 0 && N % 64 == 0 && K % 64 == 0;
+  allow_lds(hlinear_bwd_kernel<false>);
+  allow_lds(hlinear_bwd_kernel<true>);
   if (full)
-    hipLaunchKernelGGL(hlinear_bwd_kernel<false>, dim3(nx + nw), dim3(256), 0, st, gx, gw, nx, dxn, dwn, 1, 1, 1, 1);
+    hipLaunchKernelGGL(hlinear_bwd_kernel<false>, dim3(nx + nw), dim3(256), LDS_B, st, gx, gw, nx, dxn, dwn, 1, 1, 1, 1);
   else
-    hipLaunchKernelGGL(hlinear_bwd_kernel<true>, dim3(nx + nw), dim3(256), 0, st, gx, gw, nx, dxn, dwn,
+    hipLaunchKernelGGL(hlinear_bwd_kernel<true>, dim3(nx + nw), dim3(256), LDS_B, st, gx, gw, nx, dxn, dwn,
                        (int)can_vec(dy, ldy), (int)can_vec(W, ldw), (int)can_vec(dy, ldy), (int)can_vec(x, ldx));
   MVF_LAUNCH_CHECK();
   return MVF_OK;

@@ -44,7 +44,8 @@ typedef struct MvfVitWeights {
   float ln_eps;                /* 1e-6 for timm ViT */
   const float* cls_token;      /* [dim]            */
   const float* pos_embed;      /* [1+P, dim]       */
-  const void* patch_w;         /* [dim, 3*p*p] dtype T (k = c*p*p + ky*p + kx) */
+  const void* patch_w;         /* [dim, Kp] dtype T, k = c*p*p + ky*p + kx, Kp = 3*p*p rounded up to a multiple of 128 with
+                                  zero columns (768 for patch 16, 192 -> 256 for patch 8, 588 -> 640 for patch 14) */
   const float* patch_b;        /* [dim]            */
   const float* norm_w;         /* final norm [dim] */
   const float* norm_b;

@@ -162,7 +162,9 @@ def _attn_ref(qkv, F, N, H):
     return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(F * N, D)
 
 
-@pytest.mark.parametrize('N', [197, 5, 785])
+# 197: ViT-B/16 @224 (13 key tiles, one block, DMA-staged specialisation); 193 / 208: the same specialisation at its edges;
+# 5: tiny; 257, 577: DINOv2 patch 14 @224 / @336 (two / three key blocks, online softmax); 785: ViT-B/8
+@pytest.mark.parametrize('N', [197, 193, 208, 5, 257, 577, 785])
 @pytest.mark.parametrize('dtype,variant', [('f32', 0), ('bf16', 0), ('bf16', 1)])
 def test_vit_attention(N, dtype, variant):
     code, tdt = ops._dt(dtype)

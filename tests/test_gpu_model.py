@@ -81,7 +81,9 @@ SMALL = dict(network='TIMM-vit_small_patch16_224.dino', num_frames=8, batch_size
              dropout=0.0)
 
 
-@pytest.mark.parametrize('variant', ['base', 'avg_enc_nst6', 'max_none', 'lin', 'dynamic', 'disjoint', 'batch_neg'])
+# fg99 / long64 / dinov2: the head and sequence shapes of BASELINE configs[2], [3] and [4] at a small image size
+@pytest.mark.parametrize('variant', ['base', 'avg_enc_nst6', 'max_none', 'lin', 'dynamic', 'disjoint', 'batch_neg', 'fg99',
+                                     'long64', 'dinov2'])
 def test_small_model_loss_and_grads(variant):
     kw = dict(SMALL)
     if variant == 'avg_enc_nst6':
@@ -94,6 +96,12 @@ def test_small_model_loss_and_grads(variant):
         kw.update(SMART_DYNAMIC_TOKENS=2, DYNAMIC_CTRL='average')
     elif variant == 'disjoint':
         kw.update(SMART_DISJOINT=True)
+    elif variant == 'fg99':      # configs_mvf/fg99_mvf.yml head: 6 entities, FC width 6 x 256, E = 256, late taps, avg
+        kw.update(SMART_TOKENS=6, CAPACITY_SCALAR=6, EMBEDDING_SIZE=256, SMART_FEATS='9,10,11', SMART_FINAL='avg')
+    elif variant == 'long64':    # 64-frame clips: temporal sequence S = 3 x 64 = 192
+        kw.update(num_frames=64, batch_size=1)
+    elif variant == 'dinov2':    # LayerScale + patch 14 backbone (DINOv2 family)
+        kw.update(network='TIMM-vit_small_patch14_dinov2.lvd142m', image_size=28)
     cfg, model = make(3, **kw)
     if variant == 'batch_neg':
         cfg.SCL.NEGATIVE_TYPE = 'batch_noself'
@@ -171,6 +179,31 @@ def test_small_model_loss_and_grads(variant):
     for k in p64:
         if 'running_' in k and not k.startswith('backbone'):
             assert relerr(sd[k], p64[k]) <= 1e-4, k
+
+
+def test_eval_embedding_extraction_variable_length():
+    """evaluate.get_embeddings (CARL_MVF/evaluate.py:27-81): a 21-frame video through a model trained at T = 8 with
+    EVAL.FRAMES_PER_BATCH = 10 -> 3 chunks of 7 frames, no mask, project=False, positional table interpolated to the
+    training length -- against the oracle chunk by chunk."""
+    from video_rep_learning_amd.evaluate import get_embeddings, get_embeddings_dataset
+    cfg, model = make(13, **SMALL)
+    cfg.EVAL.FRAMES_PER_BATCH = 10
+    vit_cfg, head_cfg, _ = oracle_cfgs(cfg)
+    g = torch.Generator().manual_seed(31)
+    L = 21
+    video = torch.randn(1, L, 3, cfg.IMAGE_SIZE, cfg.IMAGE_SIZE, generator=g)
+    model.eval()
+    emb = get_embeddings(cfg, model, video.to(DEV))
+    assert emb.shape == (L, cfg.MODEL.EMBEDDER_MODEL.EMBEDDING_SIZE)
+    params = cpu_params(model)
+    ref = torch.cat([OM.model_forward(video[:, i:i + 7], params, vit_cfg, head_cfg, None, project=False, training=False)[0]
+                     for i in range(0, L, 7)])
+    e = relerr(emb, ref)
+    assert e <= 1e-3, 'eval embeddings (3 chunks of 7, interpolated PE): %.3e' % e
+    labels = torch.arange(L).view(1, L)
+    labels[0, -2:] = -1
+    ds = get_embeddings_dataset(cfg, model, [(video, labels, torch.tensor([L]), torch.arange(L).view(1, L), None, ['v0'])], DEV)
+    assert ds['embs'][0].shape == (L - 2, emb.shape[1]) and ds['seq_lens'] == [L] and ds['names'] == ['v0']
 
 
 def test_full_size_vitb16_fp32_and_bf16():

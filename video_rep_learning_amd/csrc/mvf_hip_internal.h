@@ -9,7 +9,9 @@
 int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C,
                      int ldc, float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tpf, int M,
                      int N, int K, hipStream_t st);
-int mvf_im2col_impl(int dtype, const float* img, void* out, int F, int H, int W, int P, hipStream_t st);
+int mvf_im2col_impl(int dtype, const float* img, void* out, int F, int H, int W, int P, int ldk, hipStream_t st);
+// K of the patch-embed GEMM: 3*P*P rounded up to 128 elements (the granule of both GEMM kernels and dtypes)
+static inline int mvf_patch_k(int P) { return (3 * P * P + 127) / 128 * 128; }
 int mvf_cls_row_impl(float* x, const float* cls, const float* pos, int F, int tpf, int D, hipStream_t st);
 int mvf_layernorm_impl(int out_dtype, const float* x, size_t in_stride, const float* g, const float* b, void* y,
                        size_t out_stride, int rows, int D, float eps, hipStream_t st);

@@ -69,7 +69,7 @@ size_t carve(int dtype, int fc, int N, int D, int P, Ws* w, char* base) {
   char* x = take(Mc * D * 4);
   char* h = take(Mc * D * esz);
   char* qkv = take(Mc * 3 * D * esz);
-  const size_t patch_bytes = (size_t)fc * (N - 1) * 3 * P * P * esz;
+  const size_t patch_bytes = (size_t)fc * (N - 1) * mvf_patch_k(P) * esz;
   char* hid = take(std::max(Mc * 4 * D * esz, patch_bytes));
   if (w) { w->x = (float*)x; w->h = h; w->qkv = qkv; w->hid = hid; }
   return off;
@@ -93,7 +93,7 @@ extern "C" int mvf_vit_fwd(const MvfVitWeights* w, int dtype, const float* frame
   Ws ws;
   MVF_CHECK_ARG(carve(dtype, fc_max, N, D, P, &ws, (char*)workspace) <= ws_bytes);
   const size_t esz = dtype == MVF_BF16 ? 2 : 4;
-  const int kp = 3 * P * P;
+  const int kp = mvf_patch_k(P);   // patch_w is [dim, kp] (zero-padded beyond 3*P*P)
   int rc;
 #define RUN(call)               \
   do {                          \
@@ -105,7 +105,7 @@ extern "C" int mvf_vit_fwd(const MvfVitWeights* w, int dtype, const float* frame
     const int fc = std::min(fc_max, F - f0);
     const int Mc = fc * N;
     // ---- patch embed: gather patches, GEMM with bias + pos_embed fused, rows 1.. of every frame ----
-    RUN(mvf_im2col_impl(dtype, frames + (size_t)f0 * 3 * img * img, ws.hid, fc, img, img, P, st));
+    RUN(mvf_im2col_impl(dtype, frames + (size_t)f0 * 3 * img * img, ws.hid, fc, img, img, P, kp, st));
     RUN(timed_gemm(dtype, EPI_PATCH, ws.hid, kp, w->patch_w, kp, w->patch_b, nullptr, 0, ws.x, D, nullptr, 0,
                          w->pos_embed, nullptr, N, fc * np, D, kp, st));
     RUN(mvf_cls_row_impl(ws.x, w->cls_token, w->pos_embed, fc, N, D, st));
@@ -172,7 +172,7 @@ extern "C" int mvf_gemm_tc(int dtype, int epi, const void* A, int lda, const voi
   return mvf_gemm_tc_impl(dtype, epi, A, lda, W, ldw, bias, C, ldc, resid, ldr, tap, ldt, pos, ls, tpf, M, N, K, st);
 }
 extern "C" int mvf_patchify(int dtype, const float* frames, void* out, int F, int H, int W, int P, hipStream_t st) {
-  return mvf_im2col_impl(dtype, frames, out, F, H, W, P, st);
+  return mvf_im2col_impl(dtype, frames, out, F, H, W, P, 3 * P * P, st);
 }
 extern "C" int mvf_layernorm_fwd(int out_dtype, const float* x, size_t in_stride, const float* g, const float* b, void* y,
                                  size_t out_stride, int rows, int D, float eps, hipStream_t st) {

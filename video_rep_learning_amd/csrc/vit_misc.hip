@@ -6,33 +6,37 @@
 
 namespace {
 
-// frames [F,3,H,W] fp32 -> patch rows [F*gh*gw, 3*P*P] (T), k = c*P*P + ky*P + kx (Conv2d weight order).
-// One thread moves 4 consecutive kx (16 B read, coalesced along kx then px).
-template <typename T>
+// frames [F,3,H,W] fp32 -> patch rows [F*gh*gw, ldk] (T), k = c*P*P + ky*P + kx (Conv2d weight order); columns
+// 3*P*P .. ldk-1 are padding (ldk = 3*P*P rounded up to the GEMM's K granule; zero-filled by the caller's memset).
+// VEC: one thread moves 4 consecutive kx (16 B read, coalesced along kx then px) -- needs P % 4 == 0; otherwise (patch
+// 14 of the DINOv2 family) one element per thread.
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, T* __restrict__ out, int F, int H,
-                                                     int W, int P) {
+                                                     int W, int P, int ldk) {
   const int gh = H / P, gw = W / P;
-  const int kdim = 3 * P * P;
-  const int quads = P / 4;
-  const size_t total = (size_t)F * 3 * H * (W / 4);
+  constexpr int E = VEC ? 4 : 1;
+  const size_t total = (size_t)F * 3 * H * (W / E);
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    // idx walks the image in memory order (f, c, y, x/4) -> fully coalesced reads
-    const int xq = (int)(idx % (W / 4));
-    size_t r = idx / (W / 4);
+    // idx walks the image in memory order (f, c, y, x/E) -> fully coalesced reads
+    const int xq = (int)(idx % (W / E));
+    size_t r = idx / (W / E);
     const int y = (int)(r % H);
     r /= H;
     const int c = (int)(r % 3);
     const int f = (int)(r / 3);
-    const float4 v = *reinterpret_cast<const float4*>(img + idx * 4);
-    const int px = (xq * 4) / P, kx = (xq * 4) % P;
+    const int px = (xq * E) / P, kx = (xq * E) % P;
     const int py = y / P, ky = y % P;
     const size_t row = ((size_t)f * gh + py) * gw + px;
-    T* dst = out + row * kdim + (size_t)c * P * P + ky * P + kx;
-    (void)quads;
-    if constexpr (sizeof(T) == 4) {
-      *reinterpret_cast<float4*>(dst) = v;
+    T* dst = out + row * ldk + (size_t)c * P * P + ky * P + kx;
+    if constexpr (VEC) {
+      const float4 v = *reinterpret_cast<const float4*>(img + idx * 4);
+      if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(dst) = v;
+      } else {
+        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+      }
     } else {
-      *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+      Elem<T>::st(dst, img[idx]);
     }
   }
 }
@@ -131,14 +135,19 @@ extern "C" int mvf_debug_xcc_map(int* out, int nblocks, int threads, int lds_byt
   return MVF_OK;
 }
 
-int mvf_im2col_impl(int dtype, const float* img, void* out, int F, int H, int W, int P, hipStream_t st) {
-  MVF_CHECK_ARG(img && out && F > 0 && H % P == 0 && W % P == 0 && P % 4 == 0 && W % 4 == 0);
-  const size_t total = (size_t)F * 3 * H * (W / 4);
+int mvf_im2col_impl(int dtype, const float* img, void* out, int F, int H, int W, int P, int ldk, hipStream_t st) {
+  MVF_CHECK_ARG(img && out && F > 0 && H % P == 0 && W % P == 0 && ldk >= 3 * P * P);
+  const bool vec = P % 4 == 0 && W % 4 == 0 && ldk % 4 == 0;
+  if (ldk > 3 * P * P) {   // zero the padding columns (whole buffer: it is small and the memset is asynchronous)
+    const size_t bytes = (size_t)F * (H / P) * (W / P) * ldk * (dtype == MVF_BF16 ? 2 : 4);
+    if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) return MVF_ERR_ARG;
+  }
+  const size_t total = (size_t)F * 3 * H * (vec ? W / 4 : W);
   const int grid = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
-  if (dtype == MVF_BF16)
-    hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, img, (bf16_t*)out, F, H, W, P);
-  else
-    hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid), dim3(256), 0, st, img, (float*)out, F, H, W, P);
+#define IM2COL(TT, V) hipLaunchKernelGGL((im2col_kernel<TT, V>), dim3(grid), dim3(256), 0, st, img, (TT*)out, F, H, W, P, ldk)
+  if (dtype == MVF_BF16) { if (vec) IM2COL(bf16_t, true); else IM2COL(bf16_t, false); }
+  else { if (vec) IM2COL(float, true); else IM2COL(float, false); }
+#undef IM2COL
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

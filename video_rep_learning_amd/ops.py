@@ -631,7 +631,11 @@ class PackedViT:
         w.ln_eps = ln_eps
         w.cls_token = f32(sd['cls_token'].reshape(-1))
         w.pos_embed = f32(sd['pos_embed'].reshape(-1, dim))
-        w.patch_w = mat(sd['patch_embed.proj.weight'].reshape(dim, -1))
+        pw = sd['patch_embed.proj.weight'].detach().float().reshape(dim, -1)
+        kp = (pw.shape[1] + 127) // 128 * 128           # K granule of the GEMM kernels (mvf_hip.h: patch_w)
+        if kp != pw.shape[1]:
+            pw = torch.cat([pw, pw.new_zeros(dim, kp - pw.shape[1])], 1)
+        w.patch_w = mat(pw)
         w.patch_b = f32(sd['patch_embed.proj.bias'])
         w.norm_w, w.norm_b = f32(sd['norm.weight']), f32(sd['norm.bias'])
 

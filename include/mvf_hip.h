@@ -134,11 +134,14 @@ int mvf_ln_bwd(const float* dy, const float* x, const float* g, const float* mea
 
 /* BatchNorm1d (+fused ReLU)  (models/mvformer.py:78-79, resnet_c2d.py:118-119); SyncBN = caller merges the
  * (mean, var) / (s1, s2) vectors across ranks between the two halves (train.py:283) */
-int mvf_bn_stats(const float* x, int rows, int C, float* mean, float* var, hipStream_t stream);
+size_t mvf_bn_workspace_floats(int rows, int C);   /* scratch of mvf_bn_stats / mvf_bn_bwd_reduce (two-stage column sums) */
+int mvf_bn_stats(const float* x, int rows, int C, float* mean, float* var, float* running_mean, float* running_var,
+                 float momentum, float* ws, size_t ws_floats, hipStream_t stream);
 int mvf_bn_fwd(const float* x, const float* mean, const float* var, const float* g, const float* b, float* y, int rows,
                int C, float eps, int relu, hipStream_t stream);
 int mvf_bn_bwd_reduce(const float* dy, const float* x, const float* mean, const float* var, const float* g, const float* b,
-                      float* s1, float* s2, int rows, int C, float eps, int relu, hipStream_t stream);
+                      float* s1, float* s2, float* dgamma, float* dbeta, int accumulate_params, int rows, int C, float eps,
+                      int relu, float* ws, size_t ws_floats, hipStream_t stream);
 int mvf_bn_bwd_apply(const float* dy, const float* x, const float* mean, const float* var, const float* g, const float* b,
                      const float* s1, const float* s2, float* dx, int rows, int C, float eps, int relu, float count,
                      hipStream_t stream);

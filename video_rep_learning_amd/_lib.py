@@ -37,9 +37,10 @@ SIGNATURES = {
     'mvf_dropout_add': 'pppzfuup',
     'mvf_ln_fwd': 'ppppppiifp',
     'mvf_ln_bwd': 'ppppppppiiiip',
-    'mvf_bn_stats': 'piippp',
+    'mvf_bn_workspace_floats': 'ii',
+    'mvf_bn_stats': 'piippppfpzp',
     'mvf_bn_fwd': 'ppppppiifip',
-    'mvf_bn_bwd_reduce': 'ppppppppiifip',
+    'mvf_bn_bwd_reduce': 'ppppppppppiiifipzp',
     'mvf_bn_bwd_apply': 'pppppppppiififp',
     'mvf_concat_onehot': 'ppiiiip',
     'mvf_final_reduce_fwd': 'pppiiiiip',
@@ -90,7 +91,7 @@ def load():
     for name, sig in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.argtypes = [_KIND[k] for k in sig]
-        fn.restype = _Z if name == 'mvf_vit_workspace_bytes' else _I
+        fn.restype = _Z if name in ('mvf_vit_workspace_bytes', 'mvf_bn_workspace_floats') else _I
     _lib = lib
     return lib
 

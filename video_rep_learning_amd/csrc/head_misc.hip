@@ -88,30 +88,49 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 }
 
 // ---------------- BatchNorm1d ----------------
-// per-channel mean and biased variance over rows (two sweeps; data is L2 resident)
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int rows, int C, float* __restrict__ mean,
-                                                       float* __restrict__ var) {
-  __shared__ float red[4][64];
-  __shared__ float mu_s[64];
+// Column reductions over the rows of a [rows, C] matrix (BN statistics, BN backward sums) in two stages so that a
+// 768-row problem uses (C/64) x RS workgroups instead of C/64: stage 1 writes per-row-split partial sums to a caller
+// workspace ws[RS][2][C], stage 2 (one thread per channel) adds them in a fixed order -- deterministic, no atomics.
+// (The one-stage form with 8 workgroups took 47-53 us per call.)
+__host__ __device__ inline int bn_splits(int rows) { return rows >= 1024 ? 32 : (rows >= 64 ? rows / 32 : 1); }
+
+// stage 1 of the statistics: shifted sums  A = sum(x - p), B = sum((x - p)^2)  with the pivot p[c] = x[0, c]
+// (plain E[x^2] - E[x]^2 would cancel catastrophically in fp32 when |mean| >> std)
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, int rows, int C, int RS,
+                                                               float* __restrict__ ws) {
+  __shared__ float r1[4][64], r2[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  float s = 0.f;
-  if (c < C)
-    for (int r = rl; r < rows; r += 4) s += x[(size_t)r * C + c];
-  red[rl][cl] = s;
-  __syncthreads();
-  if (rl == 0) mu_s[cl] = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / rows;
-  __syncthreads();
-  const float mu = mu_s[cl];
-  s = 0.f;
-  if (c < C)
-    for (int r = rl; r < rows; r += 4) { const float d = x[(size_t)r * C + c] - mu; s += d * d; }
-  __syncthreads();
-  red[rl][cl] = s;
+  const int c = blockIdx.x * 64 + cl, rs = blockIdx.y;
+  const int chunk = (rows + RS - 1) / RS, rbeg = rs * chunk, rend = min(rows, rbeg + chunk);
+  float a = 0.f, b = 0.f;
+  if (c < C) {
+    const float p = x[c];
+    for (int r = rbeg + rl; r < rend; r += 4) { const float d = x[(size_t)r * C + c] - p; a += d; b += d * d; }
+  }
+  r1[rl][cl] = a; r2[rl][cl] = b;
   __syncthreads();
   if (rl == 0 && c < C) {
-    mean[c] = mu;
-    var[c] = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / rows;
+    ws[((size_t)rs * 2 + 0) * C + c] = r1[0][cl] + r1[1][cl] + r1[2][cl] + r1[3][cl];
+    ws[((size_t)rs * 2 + 1) * C + c] = r2[0][cl] + r2[1][cl] + r2[2][cl] + r2[3][cl];
+  }
+}
+
+// stage 2: mean, biased variance; optionally the running statistics (nn.BatchNorm1d: momentum, unbiased variance)
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ x, const float* __restrict__ ws, int rows,
+                                                             int C, int RS, float* __restrict__ mean, float* __restrict__ var,
+                                                             float* __restrict__ rmean, float* __restrict__ rvar,
+                                                             float momentum) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int rs = 0; rs < RS; ++rs) { a += ws[((size_t)rs * 2 + 0) * C + c]; b += ws[((size_t)rs * 2 + 1) * C + c]; }
+  const float inv = 1.f / rows, d = a * inv;
+  const float mu = x[c] + d, v = fmaxf(b * inv - d * d, 0.f);
+  mean[c] = mu;
+  var[c] = v;
+  if (rmean != nullptr) {
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * v * ((float)rows / fmaxf((float)rows - 1.f, 1.f));
   }
 }
 
@@ -126,20 +145,21 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ x
   }
 }
 
-// s1[c] = sum_r dy_eff ; s2[c] = sum_r dy_eff * xhat     (dy_eff = dy * [bn(x) > 0] when relu)
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                            const float* __restrict__ mean, const float* __restrict__ var,
-                                                            const float* __restrict__ g, const float* __restrict__ b,
-                                                            float* __restrict__ s1, float* __restrict__ s2, int rows, int C,
-                                                            float eps, int relu) {
+// s1[c] = sum_r dy_eff ; s2[c] = sum_r dy_eff * xhat     (dy_eff = dy * [bn(x) > 0] when relu); stage 1: partial sums
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ mean, const float* __restrict__ var,
+                                                             const float* __restrict__ g, const float* __restrict__ b,
+                                                             float* __restrict__ ws, int rows, int C, int RS, float eps,
+                                                             int relu) {
   __shared__ float r1[4][64], r2[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  const int c = blockIdx.x * 64 + cl, rs = blockIdx.y;
+  const int chunk = (rows + RS - 1) / RS, rbeg = rs * chunk, rend = min(rows, rbeg + chunk);
   float a = 0.f, bb = 0.f;
   if (c < C) {
-    const float mu = mean[c], rs = rsqrtf(var[c] + eps), gg = g[c], be = b[c];
-    for (int r = rl; r < rows; r += 4) {
-      const float xh = (x[(size_t)r * C + c] - mu) * rs;
+    const float mu = mean[c], rsd = rsqrtf(var[c] + eps), gg = g[c], be = b[c];
+    for (int r = rbeg + rl; r < rend; r += 4) {
+      const float xh = (x[(size_t)r * C + c] - mu) * rsd;
       float d = dy[(size_t)r * C + c];
       if (relu && !(xh * gg + be > 0.f)) d = 0.f;
       a += d;
@@ -149,8 +169,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   r1[rl][cl] = a; r2[rl][cl] = bb;
   __syncthreads();
   if (rl == 0 && c < C) {
-    s1[c] = r1[0][cl] + r1[1][cl] + r1[2][cl] + r1[3][cl];
-    s2[c] = r2[0][cl] + r2[1][cl] + r2[2][cl] + r2[3][cl];
+    ws[((size_t)rs * 2 + 0) * C + c] = r1[0][cl] + r1[1][cl] + r1[2][cl] + r1[3][cl];
+    ws[((size_t)rs * 2 + 1) * C + c] = r2[0][cl] + r2[1][cl] + r2[2][cl] + r2[3][cl];
+  }
+}
+
+// stage 2: s1, s2 and (optionally) the parameter gradients dbeta (+)= s1, dgamma (+)= s2 of THIS rank's rows
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ ws, int C, int RS, float* __restrict__ s1,
+                                                           float* __restrict__ s2, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int rs = 0; rs < RS; ++rs) { a += ws[((size_t)rs * 2 + 0) * C + c]; b += ws[((size_t)rs * 2 + 1) * C + c]; }
+  s1[c] = a;
+  s2[c] = b;
+  if (dgamma != nullptr) {
+    dgamma[c] = accumulate ? dgamma[c] + b : b;
+    dbeta[c] = accumulate ? dbeta[c] + a : a;
   }
 }
 
@@ -303,9 +339,18 @@ extern "C" int mvf_ln_bwd(const float* dy, const float* x, const float* g, const
   return MVF_OK;
 }
 
-extern "C" int mvf_bn_stats(const float* x, int rows, int C, float* mean, float* var, hipStream_t st) {
-  MVF_CHECK_ARG(x && mean && var && rows > 0 && C > 0);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, x, rows, C, mean, var);
+extern "C" size_t mvf_bn_workspace_floats(int rows, int C) { return (size_t)bn_splits(rows) * 2 * C; }
+
+// mean / biased variance of x over its rows; running_mean / running_var (may be NULL) are updated like nn.BatchNorm1d
+// does in training (skip them under SyncBN: the caller updates them from the merged statistics)
+extern "C" int mvf_bn_stats(const float* x, int rows, int C, float* mean, float* var, float* running_mean,
+                            float* running_var, float momentum, float* ws, size_t ws_floats, hipStream_t st) {
+  MVF_CHECK_ARG(x && mean && var && ws && rows > 0 && C > 0 && ((running_mean == nullptr) == (running_var == nullptr)));
+  const int RS = bn_splits(rows);
+  MVF_CHECK_ARG(ws_floats >= (size_t)RS * 2 * C);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(ceil_div(C, 64), RS), dim3(256), 0, st, x, rows, C, RS, ws);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, x, ws, rows, C, RS, mean, var,
+                     running_mean, running_var, momentum);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }
@@ -319,12 +364,19 @@ extern "C" int mvf_bn_fwd(const float* x, const float* mean, const float* var, c
   return MVF_OK;
 }
 
+// s1 = sum_r dy_eff, s2 = sum_r dy_eff * xhat; dgamma / dbeta (may be NULL): this rank's parameter gradients
+// (= s2 / s1 before any cross-rank reduction), added in place when accumulate_params != 0 (flat gradient buffer)
 extern "C" int mvf_bn_bwd_reduce(const float* dy, const float* x, const float* mean, const float* var, const float* g,
-                                 const float* b, float* s1, float* s2, int rows, int C, float eps, int relu,
-                                 hipStream_t st) {
-  MVF_CHECK_ARG(dy && x && mean && var && g && b && s1 && s2 && rows > 0 && C > 0);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, dy, x, mean, var, g, b, s1, s2, rows,
-                     C, eps, relu);
+                                 const float* b, float* s1, float* s2, float* dgamma, float* dbeta, int accumulate_params,
+                                 int rows, int C, float eps, int relu, float* ws, size_t ws_floats, hipStream_t st) {
+  MVF_CHECK_ARG(dy && x && mean && var && g && b && s1 && s2 && ws && rows > 0 && C > 0);
+  MVF_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr));
+  const int RS = bn_splits(rows);
+  MVF_CHECK_ARG(ws_floats >= (size_t)RS * 2 * C);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(ceil_div(C, 64), RS), dim3(256), 0, st, dy, x, mean, var, g, b, ws, rows, C,
+                     RS, eps, relu);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, ws, C, RS, s1, s2, dgamma, dbeta,
+                     accumulate_params);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

@@ -239,6 +239,10 @@ def sync_bn_stats(mean, var, count, group=None):
     return gm.contiguous(), gv.contiguous(), total
 
 
+def _bn_ws(R, C, dev):
+    return torch.empty(_lib.load().mvf_bn_workspace_floats(R, C), device=dev, dtype=torch.float32)
+
+
 class _BatchNormTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, g, b, running_mean, running_var, momentum, eps, relu, sync, group):
@@ -246,31 +250,43 @@ class _BatchNormTrain(torch.autograd.Function):
         R, C = x.shape
         mean = torch.empty(C, device=x.device, dtype=torch.float32)
         var = torch.empty_like(mean)
-        call('mvf_bn_stats', ptr(x), R, C, ptr(mean), ptr(var), stream())
         count = float(R)
         world = _world(group) if sync else 1
+        ws = _bn_ws(R, C, x.device)
+        local_running = world == 1       # the statistics kernel updates the running buffers itself
+        call('mvf_bn_stats', ptr(x), R, C, ptr(mean), ptr(var), ptr(running_mean) if local_running else None,
+             ptr(running_var) if local_running else None, float(momentum), ptr(ws), ws.numel(), stream())
         if world > 1:
             # exchange (mean, biased var, count) and merge (Chan); 2C+1 floats per rank -- collective C2 of SURVEY.md
             mean, var, count = sync_bn_stats(mean, var, count, group)
-        with torch.no_grad():
-            running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-            running_var.mul_(1 - momentum).add_(var, alpha=momentum * count / max(count - 1.0, 1.0))
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                running_var.mul_(1 - momentum).add_(var, alpha=momentum * count / max(count - 1.0, 1.0))
         y = torch.empty_like(x)
         call('mvf_bn_fwd', ptr(x), ptr(mean), ptr(var), ptr(g), ptr(b), ptr(y), R, C, eps, int(relu), stream())
         ctx.save_for_backward(x, g, b, mean, var)
-        ctx.cfg = (eps, relu, count, world, group)
+        use = x.requires_grad and grad_slot(g) is not None and grad_slot(b) is not None
+        ctx.cfg = (eps, relu, count, world, group, (grad_slot(g), grad_slot(b)) if use else None, (g, b) if use else ())
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, g, b, mean, var = ctx.saved_tensors
-        eps, relu, count, world, group = ctx.cfg
+        eps, relu, count, world, group, slots, owners = ctx.cfg
         dy = dy.contiguous()
         R, C = x.shape
         s = torch.empty(2, C, device=x.device, dtype=torch.float32)
-        call('mvf_bn_bwd_reduce', ptr(dy), ptr(x), ptr(mean), ptr(var), ptr(g), ptr(b), s[0].data_ptr(),
-             s[1].data_ptr(), R, C, eps, int(relu), stream())
-        dgamma, dbeta = s[1].clone(), s[0].clone()   # local sums, like torch SyncBatchNorm
+        ws = _bn_ws(R, C, x.device)
+        if slots is not None:            # local dgamma / dbeta straight into the flat gradient buffer
+            dgamma = dbeta = None
+            gp, bp, acc = slots[0].data_ptr(), slots[1].data_ptr(), 1
+        else:
+            dgamma, dbeta = torch.empty_like(g), torch.empty_like(b)
+            gp, bp, acc = dgamma.data_ptr(), dbeta.data_ptr(), 0
+        call('mvf_bn_bwd_reduce', ptr(dy), ptr(x), ptr(mean), ptr(var), ptr(g), ptr(b), s[0].data_ptr(), s[1].data_ptr(),
+             gp, bp, acc, R, C, eps, int(relu), ptr(ws), ws.numel(), stream())
+        if slots is not None:
+            grad_ready(*owners)
         if world > 1:
             dist.all_reduce(s, group=group)          # collective C3 of SURVEY.md
         dx = torch.empty_like(x)
@@ -297,8 +313,9 @@ class _BatchNormEval(torch.autograd.Function):
         dy = dy.contiguous()
         R, C = x.shape
         s = torch.empty(2, C, device=x.device, dtype=torch.float32)
-        call('mvf_bn_bwd_reduce', ptr(dy), ptr(x), ptr(mean), ptr(var), ptr(g), ptr(b), s[0].data_ptr(),
-             s[1].data_ptr(), R, C, eps, int(relu), stream())
+        ws = _bn_ws(R, C, x.device)
+        call('mvf_bn_bwd_reduce', ptr(dy), ptr(x), ptr(mean), ptr(var), ptr(g), ptr(b), s[0].data_ptr(), s[1].data_ptr(),
+             None, None, 0, R, C, eps, int(relu), ptr(ws), ws.numel(), stream())
         dx = torch.empty_like(x)
         call('mvf_bn_bwd_apply', ptr(dy), ptr(x), ptr(mean), ptr(var), ptr(g), ptr(b), s[0].data_ptr(),
              s[1].data_ptr(), ptr(dx), R, C, eps, int(relu), 0.0, stream())

@@ -156,6 +156,8 @@ int mvf_l2norm_bwd(const float* dy, const float* y, const float* nrm, float* dx,
                    hipStream_t stream);
 
 /* temporal multi-head self-attention (models/utils.py:11-44,88-104); qkv [B*S, 3*Dm], mask [B,S] or NULL */
+/* 1 = scalar-FMA kernels only (cross-check, A/B), 0 = fp32 matrix-core kernels when dk is 16, 32 or 64 (default) */
+int mvf_tattn_select(int scalar_only);
 int mvf_tattn_fwd(const float* qkv, const float* mask, float* o, float* lse, int B, int S, int H, int Dm,
                   hipStream_t stream);
 int mvf_tattn_bwd(const float* qkv, const float* mask, const float* o, const float* lse, const float* d_o, float* dqkv,

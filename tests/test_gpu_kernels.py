@@ -351,8 +351,12 @@ def test_batch_norm_fwd_bwd(training, relu):
         check(rv, pr['bn.running_var'], 1e-5, 'running_var')
 
 
-@pytest.mark.parametrize('B,S,H,Dm,pad', [(3, 96, 8, 256, 7), (2, 24, 4, 32, 0), (2, 200, 8, 256, 33), (1, 130, 2, 128, 1)])
-def test_temporal_attention_fwd_bwd(B, S, H, Dm, pad):
+# dk = 32 / 8 / 32 / 64 / 16: the matrix-core kernels serve dk in {16, 32, 64}, the scalar ones the rest; `scalar` forces the
+# scalar kernels so both implementations are checked on the same cases
+@pytest.mark.parametrize('scalar', [0, 1])
+@pytest.mark.parametrize('B,S,H,Dm,pad', [(3, 96, 8, 256, 7), (2, 24, 4, 32, 0), (2, 200, 8, 256, 33), (1, 130, 2, 128, 1),
+                                           (8, 192, 8, 256, 40), (2, 70, 4, 64, 69)])
+def test_temporal_attention_fwd_bwd(B, S, H, Dm, pad, scalar):
     g = gen(24)
     qkv = torch.randn(B * S, 3 * Dm, generator=g)
     mask = torch.ones(B, S)
@@ -366,8 +370,12 @@ def test_temporal_attention_fwd_bwd(B, S, H, Dm, pad):
     o = o.transpose(1, 2).reshape(B * S, Dm)
     (o * go.double()).sum().backward()
     qd = _leaf(qkv)
-    od = ops.temporal_attention(qd, mask.to(DEV), B, S, H)
-    (od * go.to(DEV)).sum().backward()
+    _lib.call('mvf_tattn_select', scalar)
+    try:
+        od = ops.temporal_attention(qd, mask.to(DEV), B, S, H)
+        (od * go.to(DEV)).sum().backward()
+    finally:
+        _lib.call('mvf_tattn_select', 0)
     check(od, o, 2e-5, 'tattn o')
     check(qd.grad, qr.grad, 1e-4, 'tattn dqkv')
 

@@ -47,6 +47,7 @@ SIGNATURES = {
     'mvf_final_reduce_bwd': 'pppiiiiip',
     'mvf_l2norm_fwd': 'pppiifp',
     'mvf_l2norm_bwd': 'ppppiifp',
+    'mvf_tattn_select': 'i',
     'mvf_tattn_fwd': 'ppppiiiip',
     'mvf_tattn_bwd': 'ppppppiiiip',
     'mvf_lstp_scores': 'piiiiiiipipp',

@@ -264,10 +264,21 @@ int dispatch(int which, int dk, const TAttnArgs& a, hipStream_t st) {
 
 }  // namespace
 
+int g_tattn_scalar = 0;
+// 1 = always the scalar-FMA kernels of this file (cross-check / A-B measurements), 0 = matrix-core kernels when dk % 16 == 0
+extern "C" int mvf_tattn_select(int scalar_only) {
+  g_tattn_scalar = scalar_only != 0;
+  return MVF_OK;
+}
+
 extern "C" int mvf_tattn_fwd(const float* qkv, const float* mask, float* o, float* lse, int B, int S, int H, int Dm,
                              hipStream_t st) {
   MVF_CHECK_ARG(qkv && o && lse && B > 0 && S > 0 && H > 0 && Dm % H == 0 && Dm % 4 == 0);
   MVF_CHECK_ARG(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 15) == 0);
+  if ((Dm / H) % 16 == 0 && g_tattn_scalar == 0) {   // matrix-core path (head_attn_mfma.hip)
+    const int rc = mvf_tattn_mfma(0, qkv, mask, o, lse, nullptr, nullptr, B, S, H, Dm, st);
+    if (rc != MVF_ERR_UNSUPPORTED) return rc;
+  }
   TAttnArgs a{};
   a.qkv = qkv; a.mask = mask; a.o = o; a.lse = lse; a.B = B; a.S = S; a.H = H; a.Dm = Dm;
   const int dk = Dm / H;
@@ -280,6 +291,10 @@ extern "C" int mvf_tattn_bwd(const float* qkv, const float* mask, const float* o
                              float* dqkv, int B, int S, int H, int Dm, hipStream_t st) {
   MVF_CHECK_ARG(qkv && o && lse && d_o && dqkv && B > 0 && S > 0 && H > 0 && Dm % H == 0 && Dm % 4 == 0);
   MVF_CHECK_ARG(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)dqkv & 15) == 0 && ((uintptr_t)d_o & 15) == 0);
+  if ((Dm / H) % 16 == 0 && g_tattn_scalar == 0) {
+    const int rc = mvf_tattn_mfma(1, qkv, mask, const_cast<float*>(o), const_cast<float*>(lse), d_o, dqkv, B, S, H, Dm, st);
+    if (rc != MVF_ERR_UNSUPPORTED) return rc;
+  }
   TAttnArgs a{};
   a.qkv = qkv; a.mask = mask; a.o = const_cast<float*>(o); a.lse = const_cast<float*>(lse); a.d_o = d_o; a.dqkv = dqkv;
   a.B = B; a.S = S; a.H = H; a.Dm = Dm;

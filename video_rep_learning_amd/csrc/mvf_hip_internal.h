@@ -17,3 +17,8 @@ int mvf_layernorm_impl(int out_dtype, const float* x, size_t in_stride, const fl
                        size_t out_stride, int rows, int D, float eps, hipStream_t st);
 int mvf_cast_bf16_impl(const float* in, void* out, size_t n, hipStream_t st);
 int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t st);
+
+// ---- head ----
+// MFMA temporal attention (head_attn_mfma.hip); which: 0 forward, 1 backward; MVF_ERR_UNSUPPORTED unless dk in {16,32,64}
+int mvf_tattn_mfma(int which, const float* qkv, const float* mask, float* o, float* lse, const float* d_o, float* dqkv,
+                   int B, int S, int H, int Dm, hipStream_t st);

@@ -120,8 +120,9 @@ def main():
 
     def step():
         # one-batch lookahead as in train.train(): the frozen-backbone forward of the NEXT batch is started on the side
-        # stream before this batch's head work is enqueued (every step still runs exactly one backbone forward and one
-        # head forward/backward/update; the resident synthetic batch is the same tensor each step)
+        # stream before this batch's head work is enqueued; the head consumes the forward launched one step EARLIER (the
+        # stash is FIFO and was primed below).  Every step still launches exactly one backbone forward and runs one
+        # head forward/backward/update; the resident synthetic batch is the same tensor each step.
         if not a.no_lookahead:
             wrapped.prefetch(videos)
         opt.zero_grad()
@@ -136,6 +137,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if not a.no_lookahead:
+        wrapped.prefetch(videos)     # prime the pipeline: step k's head reads the forward launched in step k-1
     for _ in range(a.warmup):
         step()
     fence()

@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libmvf_hip.so')
+LIB_PATH = os.environ.get('MVF_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libmvf_hip.so')
 
 F32, BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_PATCH = 0, 1, 2, 3

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, 'libmvf_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result',
-         '-I' + HERE, '-I' + os.path.join(HERE, '..', '..', 'include')]
+         '-I' + HERE, '-I' + os.path.join(HERE, '..', '..', 'include')] + os.environ.get('MVF_EXTRA_FLAGS', '').split()
 
 
 def sources():

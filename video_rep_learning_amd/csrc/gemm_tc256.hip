@@ -263,15 +263,56 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     for (int j = 0; j < 4; ++j)
       bj[j] = a.bias != nullptr ? *reinterpret_cast<const float4*>(sbias + (j * 16 + fgrp * 4) * 4)
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr bool kReadModify = EPI == EPI_RESID || EPI == EPI_PATCH;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gj[4] = {z4, z4, z4, z4};
+    if constexpr (EPI == EPI_RESID) {
+      if (a.ls != nullptr) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + frow;
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0 + wc * 64 + j * 16 + fgrp * 4;
+          if (n < a.N) gj[j] = *reinterpret_cast<const float4*>(a.ls + n);
+        }
+      }
+    }
+    // read-modify epilogues: the addends of EB accumulator rows (4*EB 16-byte loads per lane) are in flight together,
+    // and batch b+1 is requested before batch b is stored (so the wait for b+1 overlaps b's stores)
+#ifndef MVF_EPI_EB
+#define MVF_EPI_EB 2
+#endif
+#ifndef MVF_EPI_PIPE
+#define MVF_EPI_PIPE 0
+#endif
+    constexpr int EB = MVF_EPI_EB, NB = 8 / EB;
+    float4 add[2][EB][4];
+    auto prefetch = [&](int b) {
+      if constexpr (kReadModify) {
 #pragma unroll
-      for (int jp = 0; jp < 2; ++jp) {
-        const int nb = n0 + wc * 64 + jp * 32;
-        // N % 32 == 0: a tile pair is in range or out as a whole
-        epilogue_pair_bf16<EPI>(a, m, m < a.M && nb < a.N, nb, fgrp, acc[i][2 * jp], acc[i][2 * jp + 1], bj[2 * jp],
-                                bj[2 * jp + 1]);
+        for (int ii = 0; ii < EB; ++ii) {
+          const int i = b * EB + ii;
+          const int m = m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + frow;
+          epilogue_prefetch<EPI>(a, m, m < a.M, n0 + wc * 64, fgrp, add[MVF_EPI_PIPE ? (b & 1) : 0][ii]);
+        }
+      }
+    };
+    if (MVF_EPI_PIPE) prefetch(0);
+#pragma unroll
+    for (int ih = 0; ih < NB; ++ih) {
+      if (!MVF_EPI_PIPE) prefetch(ih);
+      else if (ih + 1 < NB) prefetch(ih + 1);
+      const float4(&addb)[EB][4] = add[MVF_EPI_PIPE ? (ih & 1) : 0];
+#pragma unroll
+      for (int ii = 0; ii < EB; ++ii) {
+        const int i = ih * EB + ii;
+        const int m = m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + frow;
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          const int nb = n0 + wc * 64 + jp * 32;
+          // N % 32 == 0: a tile pair is in range or out as a whole
+          epilogue_pair_bf16<EPI>(a, m, m < a.M && nb < a.N, nb, fgrp, acc[i][2 * jp], acc[i][2 * jp + 1], bj[2 * jp],
+                                  bj[2 * jp + 1], kReadModify ? addb[ii][2 * jp] : z4,
+                                  kReadModify ? addb[ii][2 * jp + 1] : z4, gj[2 * jp], gj[2 * jp + 1]);
+        }
       }
     }
     STAMP();

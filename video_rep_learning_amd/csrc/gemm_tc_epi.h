@@ -109,10 +109,34 @@ __device__ __forceinline__ void swap_store_bf16x8(char* base, size_t row_elem_of
   }
 }
 
+// Prefetch for the read-modify epilogues: the fp32 addend (residual stream row for EPI_RESID, pos_embed row for
+// EPI_PATCH) of the 4 accumulator tiles of row m.  The kernel issues a batch of these before consuming any, so the
+// HBM/L2 round trip is paid once per batch instead of once per tile pair.
+template <int EPI>
+__device__ __forceinline__ void epilogue_prefetch(const GemmTcArgs& a, int m, bool ok, int nw, int fgrp,
+                                                  float4 (&add)[4]) {
+  const float* src = nullptr;
+  if (ok) {
+    if constexpr (EPI == EPI_RESID) {
+      src = a.resid + (size_t)m * a.ldr;
+    } else {
+      const int np = a.tpf - 1;
+      src = a.pos + (size_t)(1 + (m - (m / np) * np)) * a.N;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = nw + j * 16 + fgrp * 4;
+    add[j] = (ok && n < a.N) ? *reinterpret_cast<const float4*>(src + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// add0/add1: the prefetched addends of the two tiles (EPI_RESID / EPI_PATCH), g0/g1: LayerScale (EPI_RESID with a.ls).
 template <int EPI>
 __device__ __forceinline__ void epilogue_pair_bf16(const GemmTcArgs& a, int m, bool ok, int nb, int fgrp,
                                                    const f32x4_t& acc0, const f32x4_t& acc1, const float4& b0,
-                                                   const float4& b1) {
+                                                   const float4& b1, const float4& add0, const float4& add1,
+                                                   const float4& g0, const float4& g1) {
   float v0[4] = {acc0[0] + b0.x, acc0[1] + b0.y, acc0[2] + b0.z, acc0[3] + b0.w};
   float v1[4] = {acc1[0] + b1.x, acc1[1] + b1.y, acc1[2] + b1.z, acc1[3] + b1.w};
   const int n0 = nb + fgrp * 4, n1 = nb + 16 + fgrp * 4;   // this lane's own columns in the two tiles
@@ -125,16 +149,14 @@ __device__ __forceinline__ void epilogue_pair_bf16(const GemmTcArgs& a, int m, b
   } else if constexpr (EPI == EPI_RESID) {
     bool tap_ok = false;
     size_t tap_off = 0;
+    if (a.ls != nullptr) {
+      v0[0] *= g0.x; v0[1] *= g0.y; v0[2] *= g0.z; v0[3] *= g0.w;
+      v1[0] *= g1.x; v1[1] *= g1.y; v1[2] *= g1.z; v1[3] *= g1.w;
+    }
+    v0[0] += add0.x; v0[1] += add0.y; v0[2] += add0.z; v0[3] += add0.w;
+    v1[0] += add1.x; v1[1] += add1.y; v1[2] += add1.z; v1[3] += add1.w;
     if (ok) {
       float* rp = a.resid + (size_t)m * a.ldr;
-      if (a.ls != nullptr) {
-        const float4 g0 = *reinterpret_cast<const float4*>(a.ls + n0), g1 = *reinterpret_cast<const float4*>(a.ls + n1);
-        v0[0] *= g0.x; v0[1] *= g0.y; v0[2] *= g0.z; v0[3] *= g0.w;
-        v1[0] *= g1.x; v1[1] *= g1.y; v1[2] *= g1.z; v1[3] *= g1.w;
-      }
-      const float4 o0 = *reinterpret_cast<const float4*>(rp + n0), o1 = *reinterpret_cast<const float4*>(rp + n1);
-      v0[0] += o0.x; v0[1] += o0.y; v0[2] += o0.z; v0[3] += o0.w;
-      v1[0] += o1.x; v1[1] += o1.y; v1[2] += o1.z; v1[3] += o1.w;
       *reinterpret_cast<float4*>(rp + n0) = make_float4(v0[0], v0[1], v0[2], v0[3]);
       *reinterpret_cast<float4*>(rp + n1) = make_float4(v1[0], v1[1], v1[2], v1[3]);
       if (a.tap != nullptr) {  // tapped block output, CLS row dropped
@@ -148,11 +170,9 @@ __device__ __forceinline__ void epilogue_pair_bf16(const GemmTcArgs& a, int m, b
     if (ok) {
       const int np = a.tpf - 1;
       const int f = m / np, p = m - f * np;
-      const float* pr = a.pos + (size_t)(1 + p) * a.N;
       float* rp = a.resid + ((size_t)f * a.tpf + 1 + p) * a.ldr;
-      const float4 p0 = *reinterpret_cast<const float4*>(pr + n0), p1 = *reinterpret_cast<const float4*>(pr + n1);
-      *reinterpret_cast<float4*>(rp + n0) = make_float4(v0[0] + p0.x, v0[1] + p0.y, v0[2] + p0.z, v0[3] + p0.w);
-      *reinterpret_cast<float4*>(rp + n1) = make_float4(v1[0] + p1.x, v1[1] + p1.y, v1[2] + p1.z, v1[3] + p1.w);
+      *reinterpret_cast<float4*>(rp + n0) = make_float4(v0[0] + add0.x, v0[1] + add0.y, v0[2] + add0.z, v0[3] + add0.w);
+      *reinterpret_cast<float4*>(rp + n1) = make_float4(v1[0] + add1.x, v1[1] + add1.y, v1[2] + add1.z, v1[3] + add1.w);
     }
   }
 }

@@ -118,12 +118,12 @@ def main():
     model.train()
     clip = cfg.OPTIMIZER.GRAD_CLIP
 
-    def step():
+    def step(lookahead=not a.no_lookahead):
         # one-batch lookahead as in train.train(): the frozen-backbone forward of the NEXT batch is started on the side
         # stream before this batch's head work is enqueued; the head consumes the forward launched one step EARLIER (the
         # stash is FIFO and was primed below).  Every step still launches exactly one backbone forward and runs one
         # head forward/backward/update; the resident synthetic batch is the same tensor each step.
-        if not a.no_lookahead:
+        if lookahead:
             wrapped.prefetch(videos)
         opt.zero_grad()
         loss = algo.compute_loss(wrapped, videos, seq_lens, steps, masks)['loss']
@@ -156,11 +156,19 @@ def main():
     # ---- roofline of the dominant kernel: per-launch HIP-event timing during extra (untimed) steps ----
     roof = None
     if rank == 0:
+        # Kernel timing wants the kernels one at a time: the timed region above keeps two backbone lanes and the head in
+        # flight together (a launch's event-to-event time would then include the other streams' kernels), so these
+        # extra steps run the backbone as one lane, without lookahead -- the same serial order rocprofv3 records.
+        from video_rep_learning_amd import ops
+        lane_rows, ops.VIT_LANE_MIN_ROWS = ops.VIT_LANE_MIN_ROWS, 1 << 62
+        step(lookahead=False)                  # drains the primed forward
+        torch.cuda.synchronize()
         _lib.call('mvf_prof_enable', 1)
         for _ in range(max(a.profile_steps, 1)):
-            step()
+            step(lookahead=False)
         torch.cuda.synchronize()
         _lib.call('mvf_prof_enable', 0)
+        ops.VIT_LANE_MIN_ROWS = lane_rows
         G = 16
         ms, fl = (ctypes.c_double * G)(), (ctypes.c_double * G)()
         cnt, epi, nn, kk = (ctypes.c_int * G)(), (ctypes.c_int * G)(), (ctypes.c_int * G)(), (ctypes.c_int * G)()
@@ -179,6 +187,7 @@ def main():
         kern = ('gemm_tc256_kernel' if a.dtype == 'bf16' else 'gemm_tc_kernel<float>') + ' / ' + dom['name']
         roof = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                 'traffic': pmc_traffic(dom['name']), 'kernel': kern, 'launches': dom['launches'],
+                'timing': 'HIP events around each launch on its stream, kernels serialized (1 backbone lane, no lookahead)',
                 'avg_launch_us': dom['avg_us'], 'flop_per_launch': dom['flop'] / max(dom['launches'], 1),
                 'all_gemm': {'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 1), 'frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4),
                              'ms_per_step': round(tot_ms / max(a.profile_steps, 1), 3)},

@@ -669,34 +669,82 @@ class PackedViT:
         if 'blocks.0.ls1.gamma' in sd:
             w.ls1, w.ls2 = table('blocks.%d.ls1.gamma', f32), table('blocks.%d.ls2.gamma', f32)
         self.struct = w
-        self.ws = None
+        self.ws = {}
         self.ws_key = None
 
-    def workspace(self, fc, device):
+    def workspace(self, fc, device, slot=0):
+        """One activation workspace per concurrent forward (`slot`), reused call after call on that slot's stream."""
         tokens = (self.img // self.patch) ** 2 + 1
         key = (fc, tokens)
         if self.ws_key != key:
+            self.ws, self.ws_key = {}, key
+        if slot not in self.ws:
             nbytes = _lib.load().mvf_vit_workspace_bytes(self.code, fc, tokens, self.dim, self.patch)
-            self.ws = torch.empty(nbytes, device=device, dtype=torch.uint8)
-            self.ws_key = key
-        return self.ws
+            self.ws[slot] = torch.empty(nbytes, device=device, dtype=torch.uint8)
+        return self.ws[slot]
+
+    def lane_stream(self, slot, device):
+        """Extra HIP stream of concurrent-forward lane `slot` >= 1 (lane 0 is the caller's stream)."""
+        if not hasattr(self, '_lanes'):
+            self._lanes = {}
+        if slot not in self._lanes:
+            self._lanes[slot] = torch.cuda.Stream(device=device)
+        return self._lanes[slot]
 
 
-def vit_forward(frames, packed, frames_per_chunk=0, want_cls=True, attn_variant=0):
-    """frames [F,3,H,W] fp32 -> (taps: list of [F*(N-1), dim] tensors in packed.tdtype, cls [F, dim] fp32 | None)."""
+# Rows (frames x tokens) per lane from which a forward is split into concurrent lanes: every GEMM of a lane must still
+# cover the chip (> 256 tiles of 256 x 256 for N = 768) for the split to pay.
+VIT_LANE_MIN_ROWS = 22000
+
+
+def vit_forward(frames, packed, frames_per_chunk=0, want_cls=True, attn_variant=0, lanes=None):
+    """frames [F,3,H,W] fp32 -> (taps: list of [F*(N-1), dim] tensors in packed.tdtype, cls [F, dim] fp32 | None).
+
+    `lanes`: the F frames are forwarded as `lanes` independent slices on as many HIP streams (lane 0 = the caller's
+    stream), each with its own workspace and writing its slice of the outputs.  The persistent GEMM leaves most CUs idle
+    in the last, partially filled round of 256 x 256 tiles (N = 768: 591 tiles on 256 CUs); with two forwards in flight
+    the other lane's kernels fill those CUs (ViT-B/16, 256 frames: 12.09 -> 11.31 ms, outputs bitwise identical).
+    None = 2 lanes when each still fills the chip, else 1."""
     if not frames.is_cuda:
         raise _lib.MvfError('vit_forward received a %s tensor (no CPU fallback)' % frames.device)
     frames = frames.contiguous().float()
     F = frames.shape[0]
     assert frames.shape[1:] == (3, packed.img, packed.img), frames.shape
     np_ = (packed.img // packed.patch) ** 2
-    fc = F if frames_per_chunk <= 0 else min(frames_per_chunk, F)
-    ws = packed.workspace(fc, frames.device)
-    taps = [torch.empty(F * np_, packed.dim, device=frames.device, dtype=packed.tdtype) for _ in packed.taps]
-    cls = torch.empty(F, packed.dim, device=frames.device, dtype=torch.float32) if want_cls else None
-    tab = (ctypes.c_void_p * max(len(taps), 1))(*[t.data_ptr() for t in taps])
-    call('mvf_vit_fwd', ctypes.byref(packed.struct), packed.code, ptr(frames), F, tab, ptr(cls), ptr(ws), ws.numel(),
-         fc, attn_variant, stream())
+    if lanes is None:
+        lanes = 2 if (F % 2 == 0 and (F // 2) * (np_ + 1) >= VIT_LANE_MIN_ROWS) else 1
+    if lanes < 1 or F % lanes != 0:
+        raise _lib.MvfError('vit_forward: %d frames do not split into %d lanes' % (F, lanes))
+    fl = F // lanes
+    fc = fl if frames_per_chunk <= 0 else min(frames_per_chunk, fl)
+    dev = frames.device
+    taps = [torch.empty(F * np_, packed.dim, device=dev, dtype=packed.tdtype) for _ in packed.taps]
+    cls = torch.empty(F, packed.dim, device=dev, dtype=torch.float32) if want_cls else None
+    esz = taps[0].element_size() if taps else 0
+    cur = torch.cuda.current_stream(dev)
+    ready = None
+    if lanes > 1:
+        ready = torch.cuda.Event()
+        ready.record(cur)                      # inputs written / outputs allocated in caller-stream order
+    joins = []
+    for s in range(lanes):
+        st = cur if s == 0 else packed.lane_stream(s, dev)
+        if s > 0:
+            st.wait_event(ready)
+        ws = packed.workspace(fc, dev, s)
+        tab = (ctypes.c_void_p * max(len(taps), 1))(*[t.data_ptr() + s * fl * np_ * packed.dim * esz for t in taps])
+        call('mvf_vit_fwd', ctypes.byref(packed.struct), packed.code,
+             frames.data_ptr() + s * fl * 3 * packed.img * packed.img * 4, fl, tab,
+             None if cls is None else cls.data_ptr() + s * fl * packed.dim * 4, ptr(ws), ws.numel(), fc, attn_variant,
+             ctypes.c_void_p(st.cuda_stream))
+        if s > 0:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            joins.append(ev)
+            for t in taps + [frames] + ([cls] if cls is not None else []):
+                t.record_stream(st)
+    for ev in joins:
+        cur.wait_event(ev)
     return taps, cls
 
 

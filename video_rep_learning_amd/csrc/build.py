@@ -9,7 +9,10 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, 'libmvf_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+# atomic optimizer off: it rewrites a one-lane ticket atomic (gemm_tc256) into a wave-aggregated one whose result is
+# read back at once (s_waitcnt vmcnt(0) right behind the atomic)
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result',
+         '-mllvm', '-amdgpu-atomic-optimizer-strategy=None',
          '-I' + HERE, '-I' + os.path.join(HERE, '..', '..', 'include')] + os.environ.get('MVF_EXTRA_FLAGS', '').split()
 
 

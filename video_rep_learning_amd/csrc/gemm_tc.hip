@@ -181,6 +181,7 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
   a.A = (const char*)A; a.W = (const char*)W; a.bias = bias; a.C = (char*)C; a.resid = resid; a.tap = (char*)tap;
   a.pos = pos; a.ls = ls; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.ldt = ldt; a.M = M; a.N = N; a.K = K; a.tpf = tpf;
   a.dbg = g_dbg;
+  a.sched = nullptr;   // set by the persistent gemm_tc256 launch
   // bf16 with K a multiple of 128: the 256x256 8-phase kernel (gemm_tc256.hip); g_variant 1 pins the 128x128 kernel
   if (dtype == MVF_BF16 && g_variant != 1 && K % 128 == 0 && N % 32 == 0)
     return mvf_gemm_tc256_launch(epi, a, /*persistent=*/g_variant != 3, st);

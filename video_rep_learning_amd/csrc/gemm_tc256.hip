@@ -44,11 +44,22 @@
 //    at all on fc1 (315 us either way): W re-fetches are not what the loop waits for.
 //  * tried and rejected (PMC): rotating the K loop per A row-panel to shorten W's L2 re-use distance -- the L2 hits come
 //    from workgroups reading the SAME slices at the SAME time; rotation cut the hit rate from 74 % to 47 % (fc2).
-//  * XCD-aware static tile walk: workgroups b, b+8, ... share an XCD (round-robin dispatch, speed only); XCD x owns a
-//    contiguous chunk of the tile list (tiles of one A row-panel are neighbours) and its workgroups walk it in step.
+//  * XCD-aware tile walk: workgroups b, b+8, ... share an XCD (round-robin dispatch, speed only); group x = b & 7 owns a
+//    contiguous chunk of the tile list (tiles of one A row-panel are neighbours).  A workgroup's FIRST tile is static
+//    (chunk start + b/8); every further tile is a ticket from the group's counter (a.sched, agent-scope atomic), so a
+//    workgroup that starts late -- its CU was still running another stream's kernel: the head of the previous batch
+//    and the other backbone lane run concurrently -- simply takes fewer tiles instead of stretching the launch by its
+//    delay.  Wave 0 requests the ticket for tile i+2 in K tile nk-2 of tile i (the second tile's before the cold
+//    prologue), publishes it through a 4-byte LDS slot at the start of tile i's epilogue (a K tile later: no wait), and
+//    all waves read it in K tile 1 of tile i+1, whose K tile nk-2 starts staging it.  The counters clean themselves: the last workgroup of a group to
+//    leave resets them.
 #include "common.h"
 #include "mvf_hip_internal.h"
 #include "gemm_tc_epi.h"
+
+#include <atomic>
+#include <cstdlib>
+#include <mutex>
 
 namespace {
 using namespace gemm_tc;
@@ -57,7 +68,8 @@ constexpr int BM = 256, BN = 256, ROWB = 128;
 constexpr int HALF_BYTES = 128 * ROWB;          // 16 KiB: 128 rows x 64 bf16
 constexpr int BUF_BYTES = 4 * HALF_BYTES;       // A0 A1 B0 B1
 constexpr int BIAS_OFF = 2 * BUF_BYTES;         // 8 waves x 64 floats behind the two K-tile buffers
-constexpr int LDS_BYTES = BIAS_OFF + 8 * 256;   // 130 KiB -> one workgroup per CU
+constexpr int SLOT_OFF = BIAS_OFF + 8 * 256;    // 4 B: the next tile's ticket, wave 0 -> all waves
+constexpr int LDS_BYTES = SLOT_OFF + 16;        // 130 KiB -> one workgroup per CU
 constexpr int OFF_A0 = 0, OFF_A1 = HALF_BYTES, OFF_B0 = 2 * HALF_BYTES, OFF_B1 = 3 * HALF_BYTES;
 
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -106,14 +118,30 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   int lid = start + slot;                          // tile being computed
   if (lid >= end) return;                          // whole workgroup (only when tiles are unevenly spread over XCDs)
   const int nk = a.K >> 6;                         // K tiles of 64 (even: K % 128 == 0)
+  // dynamic tickets only when this group has more tiles than workgroups (then no workgroup of it returned above)
+  const bool dyn = a.sched != nullptr && nk >= 4 && start + bpx < end;
+  unsigned* const cnt = a.sched + xcd;
+  // The ticket is a compiler-visible atomic (hipcc counts the VMEM operations issued after it and waits with an exact
+  // vmcnt(N) before the value is used); an inline-asm atomic would leave a register the compiler believes ready while
+  // the hardware has yet to write it.  It is requested where a whole epilogue (or the cold prologue) passes before its use.
+  unsigned ticket;   // only ever read by the lane that wrote it
+  auto fetch_ticket = [&]() {
+    if (wave == 0 && lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto publish_ticket = [&]() {   // before a workgroup barrier that precedes K tile 1 of the tile that needs it
+    if (wave == 0 && lane == 0) *(volatile __attribute__((address_space(3))) unsigned*)LDS_PTR(smem + SLOT_OFF) = ticket;
+    WAIT_LGKM(0);
+  };
 
   // ---- LDS-DMA source pointers of the tile being STAGED (runs up to two K tiles ahead of the compute side) ----
   // per half-tile every wave issues 2 pieces of 1 KiB = 8 rows x 128 B: piece p = i*8 + wave covers half-tile rows
   // p*8 .. p*8+7; lane -> (row = p*8 + lane/8, physical chunk = lane%8)
   const int prow = lane >> 3;
   const int lchunk = (lane & 7) ^ prow;  // logical 16-B chunk fetched into physical chunk lane%8 (row & 7 == prow)
-  const char* asrc[2][2];                // [half][piece]
-  const char* wsrc[2][2];
+  // 32-bit byte offsets from a.A / a.W (the launch refuses operands of 4 GiB or more): the DMA then takes the uniform
+  // base in SGPRs plus one VGPR per piece -- half the address registers of full pointers
+  unsigned asrc[2][2];                   // [half][piece]
+  unsigned wsrc[2][2];
   auto set_sources = [&](int tile) {
     const int tm0 = (tile / nbn) * BM, tn0 = (tile % nbn) * BN;
 #pragma unroll
@@ -125,17 +153,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
         const int wn = (r >> 5) * 64 + h * 32 + (r & 31);        // W: wave column r>>5, n-quadrant h
         const int gm = min(tm0 + am, a.M - 1);
         const int gn = min(tn0 + wn, a.N - 1);
-        asrc[h][i] = a.A + (size_t)gm * a.lda * 2 + lchunk * 16;
-        wsrc[h][i] = a.W + (size_t)gn * a.ldw * 2 + lchunk * 16;
+        // 24-bit multiply (rows and row bytes < 2^24, checked by the launch): one v_mad_u32_u24 -- a full 32-bit
+        // product goes through v_mad_u64_u32, whose don't-care high addend register hipcc shares with the ticket's
+        asrc[h][i] = __umul24((unsigned)gm, (unsigned)a.lda * 2u) + lchunk * 16;
+        wsrc[h][i] = __umul24((unsigned)gn, (unsigned)a.ldw * 2u) + lchunk * 16;
       }
   };
   set_sources(lid);
   const int piece0 = wave * 1024, piece1 = (8 + wave) * 1024;
-  auto stage = [&](int buf, int off, const char* const (&src)[2], int kt) {
+  auto stage = [&](int buf, int off, const char* gbase, const unsigned (&src)[2], int kt) {
     char* dst = smem + buf * BUF_BYTES + off;
-    const size_t koff = (size_t)kt * ROWB;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src[0] + koff), LDS_PTR(dst + piece0), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src[1] + koff), LDS_PTR(dst + piece1), 16, 0, 0);
+    const unsigned koff = (unsigned)kt * ROWB;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(gbase + (size_t)(src[0] + koff)), LDS_PTR(dst + piece0), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(gbase + (size_t)(src[1] + koff)), LDS_PTR(dst + piece1), 16, 0, 0);
   };
   // this wave's 64 bias values -> its private 256 B of LDS, one LDS-DMA (4 B per lane)
   char* sbias = smem + BIAS_OFF + wave * 256;
@@ -159,15 +189,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   // ---- cold prologue (first tile of the workgroup only): K tile 0 complete, K tile 1 except A1 ----
+  if (dyn) fetch_ticket();
   stage_bias(lid);
-  stage(0, OFF_B0, wsrc[0], 0);
-  stage(0, OFF_A0, asrc[0], 0);
-  stage(0, OFF_B1, wsrc[1], 0);
-  stage(0, OFF_A1, asrc[1], 0);
-  stage(1, OFF_B0, wsrc[0], 1);
-  stage(1, OFF_A0, asrc[0], 1);
-  stage(1, OFF_B1, wsrc[1], 1);
+  stage(0, OFF_B0, a.W, wsrc[0], 0);
+  stage(0, OFF_A0, a.A, asrc[0], 0);
+  stage(0, OFF_B1, a.W, wsrc[1], 0);
+  stage(0, OFF_A1, a.A, asrc[1], 0);
+  stage(1, OFF_B0, a.W, wsrc[0], 1);
+  stage(1, OFF_A0, a.A, asrc[0], 1);
+  stage(1, OFF_B1, a.W, wsrc[1], 1);
   WAIT_VMCNT(6);
+  if (dyn) publish_ticket();   // the second tile of this workgroup
   WG_BARRIER();
   STAMP();
 
@@ -203,11 +235,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     LOAD_B(bf0, OFF_B0);                                                                                     \
     SCHED_FENCE();                                                                                           \
     LOAD_A(OFF_A0);                                                                                          \
-    if (CAN_ISSUE(1)) stage((BUF) ^ 1, OFF_A1, asrc[1], t + 1 + kwrap);                                      \
+    if (CAN_ISSUE(1)) stage((BUF) ^ 1, OFF_A1, a.A, asrc[1], t + 1 + kwrap);                                      \
     SCHED_FENCE();                                                                                           \
     WAIT_LGKM(8);                                                                                            \
     WG_BARRIER();                                                                                            \
+    unsigned tkv = 0;                                                                                        \
+    if (dyn && t == 1) tkv = *(volatile __attribute__((address_space(3))) unsigned*)LDS_PTR(smem + SLOT_OFF); \
     WAIT_LGKM(0);                                                                                            \
+    if (dyn && t == 1) {                                                                                     \
+      lid_next = start + bpx + (int)__builtin_amdgcn_readfirstlane(tkv);                                     \
+      have_next = lid_next < end;                                                                            \
+    }                                                                                                        \
     SCHED_FENCE();                                                                                           \
     MFMA_QUAD(0, 0, bf0);                                                                                    \
     WG_BARRIER();                                                                                            \
@@ -217,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     }                                                                                                        \
     /* P1 */                                                                                                 \
     LOAD_B(bf1, OFF_B1);                                                                                     \
-    if (CAN_ISSUE(2)) stage((BUF), OFF_B0, wsrc[0], t + 2 + kwrap);                                          \
+    if (CAN_ISSUE(2)) stage((BUF), OFF_B0, a.W, wsrc[0], t + 2 + kwrap);                                          \
     WG_BARRIER();                                                                                            \
     WAIT_LGKM(0);                                                                                            \
     SCHED_FENCE();                                                                                           \
@@ -225,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     WG_BARRIER();                                                                                            \
     /* P2 */                                                                                                 \
     LOAD_A(OFF_A1);                                                                                          \
-    if (CAN_ISSUE(2)) stage((BUF), OFF_A0, asrc[0], t + 2 + kwrap);                                          \
+    if (CAN_ISSUE(2)) stage((BUF), OFF_A0, a.A, asrc[0], t + 2 + kwrap);                                          \
     WG_BARRIER();                                                                                            \
     WAIT_LGKM(0);                                                                                            \
     SCHED_FENCE();                                                                                           \
@@ -233,19 +271,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     WG_BARRIER();                                                                                            \
     /* P3 */                                                                                                 \
     if (CAN_ISSUE(2)) {                                                                                      \
-      stage((BUF), OFF_B1, wsrc[1], t + 2 + kwrap);                                                          \
+      stage((BUF), OFF_B1, a.W, wsrc[1], t + 2 + kwrap);                                                          \
       WAIT_VMCNT(6);                                                                                         \
     } else {                                                                                                 \
       WAIT_VMCNT(0);                                                                                         \
     }                                                                                                        \
+    if (dyn && (BUF) == 0 && t == nk - 2 && have_next) fetch_ticket(); /* tile after next, see epilogue */   \
     WG_BARRIER();                                                                                            \
     MFMA_QUAD(1, 0, bf0);                                                                                    \
     WG_BARRIER();                                                                                            \
   }
 
   for (;;) {
-    const int lid_next = lid + bpx;
-    const bool have_next = lid_next < end;
+    int lid_next = dyn ? 0x7fffffff : lid + bpx;   // dyn: known from K tile 1 on (see K_TILE)
+    bool have_next = lid_next < end;
     const int m0 = (lid / nbn) * BM, n0 = (lid % nbn) * BN;   // compute-side tile
     int kwrap = 0;
     if (wr == 1) WG_BARRIER();  // stagger: wave row 1 runs one barrier behind wave row 0
@@ -263,6 +302,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     for (int j = 0; j < 4; ++j)
       bj[j] = a.bias != nullptr ? *reinterpret_cast<const float4*>(sbias + (j * 16 + fgrp * 4) * 4)
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    // the ticket requested in K tile nk-2 has had a K tile's time; hipcc's vmcnt(0) in front of the bias reads (or in
+    // front of this write) finds it done.  Every wave is past its K tile 1 read of the slot.
+    if (dyn && have_next) publish_ticket();
     constexpr bool kReadModify = EPI == EPI_RESID || EPI == EPI_PATCH;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 gj[4] = {z4, z4, z4, z4};
@@ -325,6 +367,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     WAIT_LGKM(0);        // this wave's bias reads are done before its bias slot is re-staged
     stage_bias(lid);     // older than every DMA the coming vmcnt(6) waits leave in flight
   }
+  // every workgroup of a dynamic group ends on one refused ticket, which it has seen: all of the group's ticket
+  // requests are complete once all have counted themselves out, and the last one zeroes the pair for the next launch
+  if (dyn && wave == 0 && lane == 0) {
+    unsigned* const gone = a.sched + 8 + xcd;
+    const unsigned old = __hip_atomic_fetch_add(gone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (unsigned)bpx - 1) {
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(gone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 
 #undef K_TILE
 #undef CAN_ISSUE
@@ -362,8 +414,25 @@ int num_cus() {
   return n;
 }
 
+// Scheduler counters: a ring of 1024 x 16 zeroed words, one slot per persistent launch (a launch leaves its slot zeroed;
+// two launches could only share a slot if 1024 later launches were enqueued while the first was still running).
+unsigned* sched_slot() {
+  static unsigned* ring = nullptr;
+  static std::atomic<unsigned> next{0};
+  static std::once_flag once;
+  std::call_once(once, [] {
+    unsigned* p = nullptr;
+    if (hipMalloc(&p, 1024 * 16 * sizeof(unsigned)) == hipSuccess && hipMemset(p, 0, 1024 * 16 * sizeof(unsigned)) == hipSuccess)
+      ring = p;
+  });
+  return ring == nullptr ? nullptr : ring + (size_t)(next.fetch_add(1) & 1023u) * 16;
+}
+
 template <int EPI, bool DBG = false>
-int launch(const GemmTcArgs& a, bool persistent, hipStream_t st) {
+int launch(const GemmTcArgs& a0, bool persistent, hipStream_t st) {
+  GemmTcArgs a = a0;
+  static const bool force_static = getenv("MVF_GEMM_STATIC") != nullptr;   // A/B measurements only
+  a.sched = persistent && !force_static ? sched_slot() : nullptr;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tc256_kernel<EPI, DBG>),
@@ -391,6 +460,10 @@ extern "C" int mvf_gemm_tc_set_cus(int n) {
 
 int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, bool persistent, hipStream_t st) {
   if (a.K % 128 != 0 || a.K < 128 || a.N % 32 != 0) return MVF_ERR_ARG;
+  // 32-bit operand offsets inside the kernel
+  if ((size_t)a.M * a.lda * 2 >= (1ull << 32) || (size_t)a.N * a.ldw * 2 >= (1ull << 32) || a.M >= (1 << 24) ||
+      a.N >= (1 << 24) || a.lda >= (1 << 23) || a.ldw >= (1 << 23))
+    return MVF_ERR_UNSUPPORTED;
   if (a.dbg != nullptr) return epi == EPI_STORE ? launch<EPI_STORE, true>(a, persistent, st) : MVF_ERR_UNSUPPORTED;
   switch (epi) {
     case EPI_STORE: return launch<EPI_STORE>(a, persistent, st);

@@ -20,6 +20,7 @@ struct GemmTcArgs {
   int M, N, K;
   int tpf;  // tokens per frame (1 + patches)
   unsigned long long* dbg;  // diagnostic stamps (gemm_tc256 DBG build only), normally null
+  unsigned* sched;          // gemm_tc256 persistent launch: 16 zeroed counters of this launch's tile scheduler (or null)
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -102,7 +102,7 @@ class TransformerModel(nn.Module):
         bc, t, c, h, w = x.shape
         cur = torch.cuda.current_stream(x.device)
         if getattr(self, '_side', None) is None or self._side.device != x.device:
-            self._side = torch.cuda.Stream(device=x.device)
+            self._side = torch.cuda.Stream(device=x.device, priority=ops.BACKBONE_STREAM_PRIORITY)
         if ready_event is None:            # "x is ready": everything enqueued on the caller's stream so far
             ready_event = torch.cuda.Event()
             ready_event.record(cur)

@@ -5,6 +5,7 @@ allocator) and provides the stream; no arithmetic of the path is done by ATen he
 Every op fails loudly on non-CUDA tensors or a missing library (see _lib.py) -- there is no CPU fallback.
 """
 import math
+import os
 import ctypes
 
 import torch
@@ -688,13 +689,18 @@ class PackedViT:
         if not hasattr(self, '_lanes'):
             self._lanes = {}
         if slot not in self._lanes:
-            self._lanes[slot] = torch.cuda.Stream(device=device)
+            self._lanes[slot] = torch.cuda.Stream(device=device, priority=BACKBONE_STREAM_PRIORITY)
         return self._lanes[slot]
 
 
 # Rows (frames x tokens) per lane from which a forward is split into concurrent lanes: every GEMM of a lane must still
 # cover the chip (> 256 tiles of 256 x 256 for N = 768) for the split to pay.
 VIT_LANE_MIN_ROWS = 22000
+# HIP priority of the streams the frozen backbone runs on (lane streams here, the lookahead stream of the model) and the
+# lane count of a split forward.  Measured in the full step (B = 4, 32 frames): priority -1 = priority 0 (12.14 vs 12.13 ms),
+# 4 lanes 12.75 ms, 2 lanes 12.13 ms, 1 lane 12.48 ms.
+BACKBONE_STREAM_PRIORITY = 0
+VIT_LANES = 2
 
 
 def vit_forward(frames, packed, frames_per_chunk=0, want_cls=True, attn_variant=0, lanes=None):
@@ -712,7 +718,7 @@ def vit_forward(frames, packed, frames_per_chunk=0, want_cls=True, attn_variant=
     assert frames.shape[1:] == (3, packed.img, packed.img), frames.shape
     np_ = (packed.img // packed.patch) ** 2
     if lanes is None:
-        lanes = 2 if (F % 2 == 0 and (F // 2) * (np_ + 1) >= VIT_LANE_MIN_ROWS) else 1
+        lanes = VIT_LANES if (F % VIT_LANES == 0 and (F // VIT_LANES) * (np_ + 1) >= VIT_LANE_MIN_ROWS) else 1
     if lanes < 1 or F % lanes != 0:
         raise _lib.MvfError('vit_forward: %d frames do not split into %d lanes' % (F, lanes))
     fl = F // lanes

@@ -165,7 +165,8 @@ def _attn_ref(qkv, F, N, H):
 # 197: ViT-B/16 @224 (13 key tiles, one block, DMA-staged specialisation); 193 / 208: the same specialisation at its edges;
 # 5: tiny; 257, 577: DINOv2 patch 14 @224 / @336 (two / three key blocks, online softmax); 785: ViT-B/8
 @pytest.mark.parametrize('N', [197, 193, 208, 5, 257, 577, 785])
-@pytest.mark.parametrize('dtype,variant', [('f32', 0), ('bf16', 0), ('bf16', 1)])
+# variants: 0 default (two query tiles per wave at N = 193..208), 1 gather reads, 2 one tile per wave, 3 = 0 at 2 waves/SIMD
+@pytest.mark.parametrize('dtype,variant', [('f32', 0), ('bf16', 0), ('bf16', 1), ('bf16', 2), ('bf16', 3)])
 def test_vit_attention(N, dtype, variant):
     code, tdt = ops._dt(dtype)
     F, H, D = 2, 3, 192

@@ -63,6 +63,9 @@ __global__ __launch_bounds__(256, NT < KT ? 3 : 2) void vit_attn_bf16_kernel(Att
 
   for (int rd = 0; rd < a.rounds; ++rd) {
     const int qt = (blockIdx.y * a.rounds + rd) * 4 + wave;  // query tile of this wave
+    // rounds > 1 only with a single key block, staged (with its barriers) in round 0: a wave without a query tile in
+    // a later round is done (N = 197: 13 tiles on 4 waves, three of them would compute a discarded 4th tile)
+    if (rd > 0 && qt * 16 >= a.N) break;
     const int qrow = min(qt * 16 + li, a.N - 1);
     // Q fragments (MFMA B operand): lane (query li, k-group g) holds Q[q][ks*32 + 8g .. +8]
     bf16x8_t qf[2];
@@ -226,6 +229,174 @@ __global__ __launch_bounds__(256, NT < KT ? 3 : 2) void vit_attn_bf16_kernel(Att
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16, one key block, TWO query tiles per wave at a time (the ViT-B/16 @ 224 px kernel: N = 197, NT = 13)
+// ------------------------------------------------------------------------------------------------
+// Same data flow as vit_attn_bf16_kernel<true, NT> (LDS-DMA staging, transposed scores, accumulator-as-B-operand), but a
+// wave walks its query tiles {w, w+4, w+8, w+12} two at a time: every K fragment (ds_read_b128) and every V fragment
+// (2 x ds_read_b64_tr_b16) feeds two MFMAs -- half the LDS reads per query -- and the two tiles' max / exp2 / sum chains
+// are independent, so one wave keeps the matrix pipe and the VALU busy together.  13 tiles split 4+3+3+3 over the waves
+// (pair+pair, pair+single): no discarded 4th tile.
+template <int NT, int NQ>
+__device__ __forceinline__ void attn_tiles(const AttnArgs& a, const char* sk, const char* sv, bf16_t* obase,
+                                           const bf16x8_t (&qf)[2][2], const int (&qt)[2], int li, int g, int vsw,
+                                           bool wait_v) {
+  f32x4_t s[NQ][NT];
+  // ---- S^T tiles: s[i][kt] = K_tile(kt) . Q_i^T -> lane holds S[query li][key kt*16 + 4g + r] ----
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) s[i][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int row = kt * 16 + li;
+      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sk + row * 128 + (((ks * 4 + g) ^ (li & 7)) << 4));
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) s[i][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[i][ks], s[i][kt], 0, 0, 0);
+    }
+  }
+  float inv[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[i][NT - 1][r] = (NT - 1) * 16 + 4 * g + r < a.N ? s[i][NT - 1][r] : -1e30f;
+    float mx = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(s[i][kt][0], s[i][kt][1])), fmaxf(s[i][kt][2], s[i][kt][3]));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float nm = -mx * a.scale_log2;
+    float ls = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[i][kt][r], a.scale_log2, nm));
+        s[i][kt][r] = p;
+        ls += p;
+      }
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    inv[i] = 1.0f / ls;
+  }
+  if (wait_v) {   // V landed (every wave waits for its own pieces, then the workgroup meets)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  // ---- O^T = V^T P^T : k-step = 32 keys = score tiles (2s, 2s+1) ----
+  f32x4_t o[NQ][4];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[i][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int st = 0; st < (NT + 1) / 2; ++st) {
+    union { bf16x8_t v; uint32_t u[4]; } pf[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      pf[i].u[0] = pack_bf16x2(s[i][2 * st][0], s[i][2 * st][1]);
+      pf[i].u[1] = pack_bf16x2(s[i][2 * st][2], s[i][2 * st][3]);
+      if (2 * st + 1 < NT) {
+        pf[i].u[2] = pack_bf16x2(s[i][2 * st + 1][0], s[i][2 * st + 1][1]);
+        pf[i].u[3] = pack_bf16x2(s[i][2 * st + 1][2], s[i][2 * st + 1][3]);
+      } else {
+        pf[i].u[2] = 0; pf[i].u[3] = 0;
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      union { bf16x8_t v; bf16x4_t h[2]; } vf;
+      const char* p0 = sv + (st * 32 + 4 * g + (li >> 2)) * 128 + (((dt * 32) ^ vsw) + 8 * (li & 3));
+      vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(p0));
+      if (2 * st + 1 < NT)
+        vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(p0 + 16 * 128));
+      else
+        vf.h[1] = (bf16x4_t){0, 0, 0, 0};   // keys beyond the staged block
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) o[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[i].v, o[i][dt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int q = qt[i] * 16 + li;
+    if (q < a.N) {
+      bf16_t* orow = obase + (size_t)q * a.D;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<uint2*>(orow + dt * 16 + 4 * g) =
+            make_uint2(pack_bf16x2(o[i][dt][0] * inv[i], o[i][dt][1] * inv[i]),
+                       pack_bf16x2(o[i][dt][2] * inv[i], o[i][dt][3] * inv[i]));
+    }
+  }
+}
+
+template <int NT, int OCC>
+__global__ __launch_bounds__(256, OCC) void vit_attn_bf16_pair_kernel(AttnArgs a) {
+  constexpr int KROWS = NT * 16;
+  __shared__ __attribute__((aligned(16))) char smem[2 * KROWS * 128];
+  char* sk = smem;                // layouts and swizzles as in vit_attn_bf16_kernel
+  char* sv = smem + KROWS * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  const int f = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const size_t ld = (size_t)3 * a.D;
+  const bf16_t* base = reinterpret_cast<const bf16_t*>(a.qkv) + (size_t)f * a.N * ld;
+  const bf16_t* qb = base + h * HD;
+  const bf16_t* kbp = base + a.D + h * HD;
+  const bf16_t* vbp = base + 2 * a.D + h * HD;
+  bf16_t* obase = reinterpret_cast<bf16_t*>(a.out) + (size_t)f * a.N * a.D + h * HD;
+  const int vsw = ((2 * g + (li >> 3)) & 3) << 5;
+  const int qtiles = (a.N + 15) >> 4;
+  const int cnt = wave < qtiles ? (qtiles - wave + 3) >> 2 : 0;   // query tiles wave, wave+4, ... of this wave
+
+  auto load_q = [&](bf16x8_t (&qf)[2][2], const int (&qt)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int qrow = min(qt[i] * 16 + li, a.N - 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        qf[i][ks] = *reinterpret_cast<const bf16x8_t*>(qb + (size_t)qrow * ld + ks * 32 + g * 8);
+    }
+  };
+  bf16x8_t qf[2][2];
+  int qt[2] = {wave, wave + 4};
+  load_q(qf, qt);
+  asm volatile("" : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[1][0]), "+v"(qf[1][1]));   // waited for before any DMA is in flight
+  {
+    constexpr int NP = KROWS / 8;
+    const int prow = lane >> 3, pc = lane & 7;
+    for (int p = wave; p < NP; p += 4) {
+      const int r = p * 8 + prow;
+      const bf16_t* src = kbp + (size_t)min(r, a.N - 1) * ld + ((pc ^ (r & 7)) << 3);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sk + p * 1024), 16, 0, 0);
+    }
+    for (int p = wave; p < NP; p += 4) {
+      const int r = p * 8 + prow;    // rows >= N repeat row N-1: finite values, their probabilities are 0
+      const bf16_t* src = vbp + (size_t)min(r, a.N - 1) * ld + ((pc ^ (((r >> 1) & 3) << 1)) << 3);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sv + p * 1024), 16, 0, 0);
+    }
+    // K landed <=> all but this wave's V pieces retired (waves < NP % 4 issued one piece more)
+    if (wave < (NP & 3)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NP + 3) / 4) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP / 4) : "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  if (cnt >= 2) {
+    attn_tiles<NT, 2>(a, sk, sv, obase, qf, qt, li, g, vsw, true);
+  } else if (cnt == 1) {
+    attn_tiles<NT, 1>(a, sk, sv, obase, qf, qt, li, g, vsw, true);
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    return;
+  }
+  if (cnt > 2) {
+    qt[0] = wave + 8; qt[1] = wave + 12;
+    load_q(qf, qt);
+    if (cnt >= 4) attn_tiles<NT, 2>(a, sk, sv, obase, qf, qt, li, g, vsw, false);
+    else attn_tiles<NT, 1>(a, sk, sv, obase, qf, qt, li, g, vsw, false);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fp32 (parity mode)
 // ------------------------------------------------------------------------------------------------
 constexpr int VROW = (HD + 4) * 4;  // 272-B V rows: keys 4 apart fall on different banks for ds_read_b32
@@ -345,7 +516,8 @@ __global__ __launch_bounds__(256, 1) void vit_attn_f32_kernel(AttnArgs a) {
 
 }  // namespace
 
-// variant: 0 = default (transposing LDS read for V), 1 = 2-byte gather reads (cross-check path)
+// variant: 0 = default (transposing LDS read for V; two query tiles per wave when N = 193..208), 1 = 2-byte gather reads
+// (cross-check path), 2 = one query tile per wave (the earlier N = 193..208 kernel, kept for A/B runs)
 int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t st) {
   MVF_CHECK_ARG(qkv && out && F > 0 && N > 0 && H > 0 && D == H * HD);
   MVF_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0);
@@ -360,7 +532,11 @@ int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H
   dim3 grid(F * H, chunks);
   if (dtype == MVF_BF16) {
     const int ntile = ceil_div(N, 16);
-    if (variant != 0) hipLaunchKernelGGL((vit_attn_bf16_kernel<false, KT>), grid, dim3(256), 0, st, a);
+    if (variant == 1) hipLaunchKernelGGL((vit_attn_bf16_kernel<false, KT>), grid, dim3(256), 0, st, a);
+    else if (a.nblk == 1 && ntile == 13 && variant == 0)
+      hipLaunchKernelGGL((vit_attn_bf16_pair_kernel<13, 3>), grid, dim3(256), 0, st, a);
+    else if (a.nblk == 1 && ntile == 13 && variant == 3)
+      hipLaunchKernelGGL((vit_attn_bf16_pair_kernel<13, 2>), grid, dim3(256), 0, st, a);
     else if (a.nblk == 1 && ntile == 13) hipLaunchKernelGGL((vit_attn_bf16_kernel<true, 13>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((vit_attn_bf16_kernel<true, KT>), grid, dim3(256), 0, st, a);
   } else if (dtype == MVF_F32) {

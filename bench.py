@@ -33,6 +33,17 @@ GEMM_NAMES = {(0, 2304, 768): 'qkv [M,768]x[2304,768]^T', (2, 768, 768): 'proj+r
 PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
 
 
+def rocprof_names(groups, dtype):
+    by = {}
+    for r in groups:
+        e = r['epi']
+        k = 'gemm_tc256_kernel<%d, false>' % e if dtype == 'bf16' else 'gemm_tc_kernel<float, %d>' % e
+        d = by.setdefault(k, {'launches': 0, 'ms': 0.0})
+        d['launches'] += r['launches']
+        d['ms'] += r['ms']
+    return {k: {'launches': d['launches'], 'avg_us': round(d['ms'] * 1e3 / max(d['launches'], 1), 1)} for k, d in by.items()}
+
+
 def pmc_traffic(name):
     """HBM bytes per launch of the named GEMM shape from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
     written by tools/pmc_summary.py from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of tools/gemm_bench.py:
@@ -54,6 +65,10 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--profile-steps', type=int, default=3)
     p.add_argument('--no-lookahead', action='store_true', help='run backbone and head strictly in sequence')
+    p.add_argument('--serial', action='store_true',
+                   help='one kernel at a time for the whole run (one backbone lane, no lookahead): the mode the roofline '
+                        'section is always timed in; use it under rocprofv3 --kernel-trace --stats so that the per-kernel '
+                        'averages there are the ones of roofline.rocprof_kernels')
     return p.parse_args()
 
 
@@ -83,6 +98,8 @@ def cpu_baseline(cfg, model):
 
 def main():
     a = parse()
+    if a.serial:
+        a.no_lookahead = True
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -102,6 +119,9 @@ def main():
     from video_rep_learning_amd.train import DataParallelModel
     from video_rep_learning_amd.datasets import synthetic
 
+    if a.serial:
+        from video_rep_learning_amd import ops as _ops
+        _ops.VIT_LANE_MIN_ROWS = 1 << 62
     cfg = presets.baseline_config_2(compute_dtype=a.dtype)     # penn_mvf.yml + ViT-B/16, T=32, B=4 (dropout 0.1 kept)
     torch.manual_seed(cfg.RNG_SEED)
     model = build_model(cfg, local).to(dev)
@@ -177,7 +197,7 @@ def main():
         groups = []
         for g in range(ng.value):
             name = GEMM_NAMES.get((epi[g], nn[g], kk[g]), 'gemm epi%d N=%d K=%d' % (epi[g], nn[g], kk[g]))
-            groups.append({'name': name, 'launches': cnt[g], 'ms': ms[g], 'flop': fl[g],
+            groups.append({'name': name, 'epi': epi[g], 'launches': cnt[g], 'ms': ms[g], 'flop': fl[g],
                            'avg_us': round(ms[g] * 1e3 / max(cnt[g], 1), 1),
                            'tflops': round(fl[g] / (ms[g] * 1e-3) / 1e12, 1) if ms[g] > 0 else 0.0})
         dom = max(groups, key=lambda r: r['ms'])       # the GEMM shape the step spends most time in
@@ -192,7 +212,10 @@ def main():
                 'all_gemm': {'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 1), 'frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4),
                              'ms_per_step': round(tot_ms / max(a.profile_steps, 1), 3)},
                 'by_kernel': {r['name']: {'launches': r['launches'], 'avg_us': r['avg_us'], 'tflops': r['tflops']}
-                              for r in groups}}
+                              for r in groups},
+                # the same launches under the names rocprofv3 prints: one kernel per epilogue, so proj and fc2 (and
+                # nothing else) share `gemm_tc256_kernel<2, false>`; compare with `bench.py --serial` under rocprofv3
+                'rocprof_kernels': rocprof_names(groups, a.dtype)}
     if world > 1:
         dist.barrier()
 

@@ -398,6 +398,29 @@ def gen_trajectory(mv, rc, scl_mod):
     print('trajectory', losses)
 
 
+def gen_state_keys(mv, rc):
+    """Checkpoint layout of BASELINE config #2 (models/__init__.py:17-27): the reference's state-dict keys and shapes for
+    `embed.*` / `ssl_projection.*`, and the parameter order of its two optimizer groups (utils/optimizer.py:26-42:
+    BatchNorm parameters first, then the rest, in named_modules order) -- the numbering of optimizer_state['state']."""
+    import json
+    d = C.Dims()
+    cfg = ref_cfg(d)
+    embed = mv.MultiEntityTransformerEmbModel(cfg)
+    proj = rc.MLPHead(cfg)
+    top = nn.Module()
+    top.embed, top.ssl_projection = embed, proj
+    keys = {k: list(v.shape) for k, v in top.state_dict().items()}
+    bn, non_bn = [], []
+    names = {id(p): n for n, p in top.named_parameters()}
+    for n, m in top.named_modules():                       # optimizer.py:26-42 with MODEL.TRAIN_BASE == 'frozen'
+        is_bn = isinstance(m, torch.nn.modules.batchnorm._NormBase)
+        for p in m.parameters(recurse=False):
+            (bn if is_bn else non_bn).append(names[id(p)])
+    with open(os.path.join(HERE, 'state_keys.json'), 'w') as f:
+        json.dump({'state_dict': keys, 'optimizer_groups': [bn, non_bn]}, f, indent=0)
+    print('state keys', len(keys), len(bn), len(non_bn))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -409,7 +432,7 @@ def main():
     spec = importlib.util.spec_from_file_location('ref_scl', os.path.join(REF, 'algos', 'scl.py'))
     scl_mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(scl_mod)
-    which = sys.argv[1:] or ['primitives', 'head', 'mlp', 'scl', 'glue', 'traj']
+    which = sys.argv[1:] or ['primitives', 'head', 'mlp', 'scl', 'glue', 'traj', 'keys']
     if 'primitives' in which:
         gen_primitives(mu)
     if 'head' in which:
@@ -422,6 +445,8 @@ def main():
         gen_glue(timm, tr)
     if 'traj' in which:
         gen_trajectory(mv, rc, scl_mod)
+    if 'keys' in which:
+        gen_state_keys(mv, rc)
 
 
 if __name__ == '__main__':

@@ -194,6 +194,34 @@ int mvf_grad_norm(const float* g, size_t n, const float* extra_sq, float* scratc
 int mvf_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, float clip, const float* norm, float gscale, hipStream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * GPU-side view augmentation: one clip [T,3,H,W] of floats in [0,1] -> [T,3,S,S], normalised
+ *   replaces: train.preproc_views (train.py:39-53) applying the ComposeOp of datasets/data_augment.py:372-413
+ *   (random_resized_crop :287-317, flip :10-14, torchvision ColorJitter :340-352, torchvision GaussianBlur :357-365,
+ *   grayscale :61-78, resize :16-22, color_normalization :218-238) or of create_data_augment(augment=False) :416-456
+ *   (uniform_crop :24-59, resize, color_normalization).  The random draws stay on the host, in the reference's order
+ *   (video_rep_learning_amd/datasets/augment.py); a clip's draws arrive here as one MvfAugmentParams.
+ *   Steps, in this order: bilinear resize (align_corners = False) of the crop window to S x S; horizontal flip;
+ *   n_color colour steps (torchvision float-tensor semantics, each clamped to [0,1]; contrast uses the per-FRAME mean of
+ *   the 0.2989/0.587/0.114 gray); blur_kx x blur_ky Gaussian with reflect padding; 0.299/0.587/0.114 grayscale on all
+ *   channels; (v - mean) / std.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct MvfAugmentParams {
+  int crop_top, crop_left, crop_h, crop_w; /* source window inside H x W (whole frame: 0, 0, H, W) */
+  int flip;
+  int n_color;                             /* 0..4 */
+  int color_op[4];                         /* 0 brightness, 1 contrast, 2 saturation, 3 hue; each at most once */
+  float color_factor[4];
+  int blur_kx, blur_ky;                    /* odd, <= 15 (reference: 5, 9); used when blur_sigma > 0 */
+  float blur_sigma;                        /* <= 0: no blur */
+  int gray;
+  float mean[3], std[3];
+} MvfAugmentParams;
+size_t mvf_augment_workspace_bytes(int n_clips, int T, int S);
+/* in [n_clips,T,3,H,W], out [n_clips,T,3,S,S], params: HOST array of n_clips entries (copied into the launches) */
+int mvf_augment_clips(const float* in, float* out, int n_clips, int T, int H, int W, int S, const MvfAugmentParams* params,
+                      void* workspace, size_t ws_bytes, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

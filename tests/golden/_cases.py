@@ -153,3 +153,16 @@ def tensor_digest(x):
     x = x.detach().double().reshape(-1)
     idx = torch.linspace(0, x.numel() - 1, 16).long()
     return torch.cat([x.sum().view(1), x.norm().view(1), x[idx]]).numpy()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# view augmentation (datasets/data_augment.py)
+# ---------------------------------------------------------------------------------------------------------------------
+AUG_CROP_CASES = [(360, 480, 3), (480, 270, 4), (40, 52, 5), (224, 224, 6)]          # (height, width, seed)
+AUG_CLIP_CASES = [(3, 40, 52, 16, 11), (2, 33, 21, 16, 12), (2, 24, 24, 24, 13)]     # (T, H, W, IMAGE_SIZE, seed)
+
+
+def aug_clip(t, h, w, seed):
+    """A clip as the dataset hands it over (penn_action.py:110-111): uint8 frames / 255 -> [T, 3, H, W] in [0, 1]."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, 256, (t, 3, h, w), generator=g).float() / 255.0

@@ -421,6 +421,50 @@ def gen_state_keys(mv, rc):
     print('state keys', len(keys), len(bn), len(non_bn))
 
 
+def gen_augment():
+    """The reference's OWN augmentation functions (datasets/data_augment.py: _get_param_spatial_crop, random_resized_crop,
+    flip, grayscale, resize, uniform_crop, color_normalization, and the RandomOp/AugmentOp/ComposeOp plumbing), imported
+    with an empty `torchvision.transforms` module: ColorJitterOp / GaussianBlurOp, which construct torchvision objects, are
+    NOT exercised (torchvision is absent; see oracle/augment.py)."""
+    import random
+    tv = sys.modules['torchvision']
+    tv.transforms = types.ModuleType('torchvision.transforms')
+    sys.modules['torchvision.transforms'] = tv.transforms
+    da = importlib.import_module('datasets.data_augment')
+    out = {}
+    # crop-parameter draws: (height, width, seed) -> 6 consecutive (i, j, h, w)
+    for n, (hh, ww, seed) in enumerate(C.AUG_CROP_CASES):
+        random.seed(seed)
+        out['crop%d' % n] = np.array([da._get_param_spatial_crop((0.8, 1.0), (3.0 / 4.0, 4.0 / 3.0), hh, ww) for _ in range(6)])
+    out['crop_fallback'] = np.array([da._get_param_spatial_crop((0.8, 1.0), (3.0, 4.0), 40, 52),       # no draw fits
+                                     da._get_param_spatial_crop((0.8, 1.0), (0.1, 0.2), 40, 52)])
+    for n, (t, hh, ww, size, seed) in enumerate(C.AUG_CLIP_CASES):
+        x = C.aug_clip(t, hh, ww, seed)
+        random.seed(seed + 100)
+        state = random.getstate()
+        i, j, h, w = da._get_param_spatial_crop((0.8, 1.0), (3.0 / 4.0, 4.0 / 3.0), hh, ww)
+        random.setstate(state)
+        out['rrc%d' % n] = da.random_resized_crop(x, size, size).numpy()           # same draw as (i, j, h, w)
+        out['rrc%d_param' % n] = np.array([i, j, h, w])
+        out['flip%d' % n] = da.flip(x).numpy()
+        out['gray%d' % n] = da.grayscale(x).numpy()
+        out['resize%d' % n] = da.resize(x, size).numpy()
+        out['norm%d' % n] = da.color_normalization(x).numpy()
+        out['ucrop%d' % n] = da.uniform_crop(x, size).numpy()
+        # the reference's own ops chained by its ComposeOp, draws from `random` in op order
+        pipe = da.ComposeOp([da.AugmentOp(da.random_resized_crop, target_height=size, target_width=size),
+                             da.RandomOp(da.flip, 0.5), da.RandomOp(da.grayscale, 0.2),
+                             da.AugmentOp(da.resize, size=size),
+                             da.AugmentOp(da.color_normalization, mean=[0.485, 0.456, 0.406], stddev=[0.229, 0.224, 0.225])])
+        random.seed(seed + 200)
+        out['pipe%d' % n] = np.stack([pipe(x).numpy() for _ in range(4)])
+        # validation pre-processing exactly as the reference builds it (no torchvision involved)
+        cfg = ad(dict(AUGMENTATION=dict(RANDOM_CROP=True), IMAGE_SIZE=size))
+        out['val%d' % n] = da.create_data_augment(cfg, augment=False)(x).numpy()
+    np.savez_compressed(os.path.join(HERE, 'augment.npz'), **out)
+    print('augment done', len(out))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -432,7 +476,7 @@ def main():
     spec = importlib.util.spec_from_file_location('ref_scl', os.path.join(REF, 'algos', 'scl.py'))
     scl_mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(scl_mod)
-    which = sys.argv[1:] or ['primitives', 'head', 'mlp', 'scl', 'glue', 'traj', 'keys']
+    which = sys.argv[1:] or ['primitives', 'head', 'mlp', 'scl', 'glue', 'traj', 'keys', 'augment']
     if 'primitives' in which:
         gen_primitives(mu)
     if 'head' in which:
@@ -447,6 +491,8 @@ def main():
         gen_trajectory(mv, rc, scl_mod)
     if 'keys' in which:
         gen_state_keys(mv, rc)
+    if 'augment' in which:
+        gen_augment()
 
 
 if __name__ == '__main__':

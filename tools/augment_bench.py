@@ -1,0 +1,60 @@
+"""View-augmentation throughput on the GPU box: one training batch of BASELINE config #2 = 8 clips of
+32 frames, raw 360x480 -> 224, SSL draws.  Prints clips/s, the HBM roofline fraction on ALGORITHMIC bytes (crop window read
+once + output written once) and the oracle (torch CPU, the reference's op sequence) timed on one clip beside it."""
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from video_rep_learning_amd import ops  # noqa: E402
+from video_rep_learning_amd.datasets import augment as P  # noqa: E402
+from video_rep_learning_amd.utils import presets  # noqa: E402
+
+
+def main():
+    cfg = presets.baseline_config_2()
+    n, T, H, W, S = 8, 32, 360, 480, cfg.IMAGE_SIZE
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randint(0, 256, (n, T, 3, H, W), generator=g, dtype=torch.uint8).float() / 255.0).cuda()
+    pol = P.SSLAugment(cfg)
+    random.seed(1)
+    torch.manual_seed(1)
+    draws = [[pol.draw(H, W) for _ in range(n)] for _ in range(20)]
+    for d in draws[:3]:
+        ops.augment_clips(x, d, S)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for d in draws:
+        ops.augment_clips(x, d, S)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / len(draws)
+    algo = sum(T * 3 * 4 * (p.crop_h * p.crop_w + S * S) for d in draws for p in d) / len(draws)
+    gbs = algo / (ms * 1e-3) / 1e9
+    out = {'metric': 'augmented clips/s (8 x 32 x 360x480 -> 224, SSL pipeline)', 'value': round(n / (ms * 1e-3), 1),
+           'ms_per_batch': round(ms, 3),
+           'roofline': {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
+                        'algorithmic_bytes_per_batch': int(algo)}}
+    if '--no-cpu' not in sys.argv:
+        sys.path.insert(0, ROOT)
+        from oracle import augment as A
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        from test_gpu_augment import to_oracle
+        torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+        xc = x[0].cpu()
+        t0 = time.time()
+        for p in draws[0]:
+            A.apply(xc, to_oracle(p), S)
+        dt = time.time() - t0
+        out['cpu_baseline'] = {'value': round(len(draws[0]) / dt, 2), 'unit': 'clips/s', 'cores': torch.get_num_threads(),
+                               'kind': 'port', 'sample': '%d clips of 32 frames through oracle/augment.py, %.1f s' % (len(draws[0]), dt)}
+    print(json.dumps(out))
+
+
+main()

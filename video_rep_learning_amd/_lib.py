@@ -59,6 +59,8 @@ SIGNATURES = {
     'mvf_scl_bwd': 'pppppppppiiiiiiffp',
     'mvf_grad_norm': 'pzpppp',
     'mvf_adam_step': 'ppppzfffffifpfp',
+    'mvf_augment_workspace_bytes': 'iii',
+    'mvf_augment_clips': 'ppiiiiippzp',
 }
 _KIND = {'p': _P, 'i': _I, 'l': _L, 'z': _Z, 'f': _F, 'u': ctypes.c_uint64}
 
@@ -71,6 +73,13 @@ class MvfVitWeights(ctypes.Structure):
                 + [(n, ctypes.POINTER(_P)) for n in
                    ('ln1_w', 'ln1_b', 'qkv_w', 'qkv_b', 'proj_w', 'proj_b', 'ln2_w', 'ln2_b', 'fc1_w', 'fc1_b',
                     'fc2_w', 'fc2_b', 'ls1', 'ls2')])
+
+
+class MvfAugmentParams(ctypes.Structure):
+    """Mirror of `struct MvfAugmentParams` (include/mvf_hip.h)."""
+    _fields_ = [('crop_top', _I), ('crop_left', _I), ('crop_h', _I), ('crop_w', _I), ('flip', _I), ('n_color', _I),
+                ('color_op', _I * 4), ('color_factor', _F * 4), ('blur_kx', _I), ('blur_ky', _I), ('blur_sigma', _F),
+                ('gray', _I), ('mean', _F * 3), ('std', _F * 3)]
 
 
 class MvfError(RuntimeError):
@@ -92,7 +101,7 @@ def load():
     for name, sig in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.argtypes = [_KIND[k] for k in sig]
-        fn.restype = _Z if name in ('mvf_vit_workspace_bytes', 'mvf_bn_workspace_floats') else _I
+        fn.restype = _Z if name in ('mvf_vit_workspace_bytes', 'mvf_bn_workspace_floats', 'mvf_augment_workspace_bytes') else _I
     _lib = lib
     return lib
 

@@ -1,0 +1,293 @@
+// GPU-side view augmentation (include/mvf_hip.h: mvf_augment_clips): two HBM-bound passes per batch of clips
+//   K1 resize_color : bilinear crop-resize (+ flip) and the colour steps up to (not including) contrast; writes the
+//                     intermediate image and, when a contrast step follows, per-block partial sums of its gray value
+//   K2 finish       : per-frame mean from the partials (fixed order: deterministic), contrast and the remaining colour
+//                     steps while loading an LDS tile, separable Gaussian with reflect padding, grayscale, normalisation
+// (the only dependency that forces two passes is contrast's per-frame mean and the blur's neighbourhood)
+// Replaces the per-clip Python loop of train.preproc_views (CARL_MVF/train.py:39-53) over ~8 full-tensor ATen passes per
+// op of datasets/data_augment.py:372-413.  Arithmetic follows the reference's / torchvision's float-tensor formulas
+// operation by operation (no fused multiply-add contraction), see oracle/augment.py.
+#include "common.h"
+#include "mvf_hip_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int MAXC = 8;    // clips per launch (their parameters travel in the kernel arguments)
+constexpr int MAXK = 15;   // largest blur kernel extent
+
+struct ClipParams {
+  int top, left, ch, cw, flip;
+  int n_color, op[4];
+  float fac[4];
+  int contrast_at;          // index of the contrast step, -1 if none
+  int blur, nkx, nky;
+  float kx[MAXK], ky[MAXK];
+  int gray;
+  float mean[3], std[3];
+};
+
+struct AugArgs {
+  const float* in;     // [n, T, 3, H, W]
+  float* buf;          // [n, T, 3, S, S]
+  float* partial;      // [n, T, NB]
+  float* out;          // [n, T, 3, S, S]
+  int n, T, H, W, S, NB;
+  ClipParams c[MAXC];
+};
+
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+__device__ __forceinline__ float tv_gray(float r, float g, float b) { return 0.2989f * r + 0.587f * g + 0.114f * b; }
+__device__ __forceinline__ float blend(float a, float b, float ratio) { return clamp01(ratio * a + (1.0f - ratio) * b); }
+
+// torchvision _rgb2hsv / (h + f) % 1 / _hsv2rgb on one pixel
+__device__ __forceinline__ void hue_shift(float& r, float& g, float& b, float f) {
+  const float maxc = fmaxf(fmaxf(r, g), b), minc = fminf(fminf(r, g), b);
+  const bool eqc = maxc == minc;
+  const float cr = maxc - minc;
+  const float s = cr / (eqc ? 1.0f : maxc);
+  const float crd = eqc ? 1.0f : cr;
+  const float rc = (maxc - r) / crd, gc = (maxc - g) / crd, bc = (maxc - b) / crd;
+  const float hr = (maxc == r) ? (bc - gc) : 0.0f;
+  const float hg = ((maxc == g) && (maxc != r)) ? (2.0f + rc - bc) : 0.0f;
+  const float hb = ((maxc != g) && (maxc != r)) ? (4.0f + gc - rc) : 0.0f;
+  float h = fmodf((hr + hg + hb) / 6.0f + 1.0f, 1.0f);
+  h = h + f;
+  h = h - floorf(h);                         // python % 1.0 on [-0.5, 1.5)
+  const float v = maxc;
+  const float h6 = h * 6.0f;
+  const float fl = floorf(h6);
+  const float fr = h6 - fl;
+  const int i = ((int)fl) % 6;
+  const float p = clamp01(v * (1.0f - s));
+  const float q = clamp01(v * (1.0f - s * fr));
+  const float t = clamp01(v * (1.0f - (s * (1.0f - fr))));
+  switch (i) {
+    case 0: r = v; g = t; b = p; break;
+    case 1: r = q; g = v; b = p; break;
+    case 2: r = p; g = v; b = t; break;
+    case 3: r = p; g = q; b = v; break;
+    case 4: r = t; g = p; b = v; break;
+    default: r = v; g = p; b = q; break;
+  }
+}
+
+__device__ __forceinline__ void point_op(int op, float f, float& r, float& g, float& b) {
+  if (op == 0) {            // adjust_brightness: blend with black
+    r = blend(r, 0.0f, f); g = blend(g, 0.0f, f); b = blend(b, 0.0f, f);
+  } else if (op == 2) {     // adjust_saturation: blend with the pixel's gray
+    const float gr = tv_gray(r, g, b);
+    r = blend(r, gr, f); g = blend(g, gr, f); b = blend(b, gr, f);
+  } else if (op == 3) {
+    hue_shift(r, g, b, f);
+  }
+}
+
+// PyTorch upsample_bilinear2d, align_corners = False: source index and weight of output position d
+__device__ __forceinline__ void src_index(int d, int in, int out, int& i0, int& i1, float& l0, float& l1) {
+  const float scale = (float)in / (float)out;
+  float s = scale * ((float)d + 0.5f) - 0.5f;
+  s = s < 0.0f ? 0.0f : s;
+  i0 = (int)s;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.0f - l1;
+}
+
+__global__ __launch_bounds__(256) void resize_color_kernel(AugArgs a) {
+  const int cidx = blockIdx.z, t = blockIdx.y;
+  const ClipParams& c = a.c[cidx];
+  const int S = a.S, pix = blockIdx.x * 256 + threadIdx.x;
+  float gsum = 0.0f;
+  if (pix < S * S) {
+    const int y = pix / S, x = pix - y * S;
+    const int xs = c.flip ? S - 1 - x : x;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    src_index(y, c.ch, S, y0, y1, ly0, ly1);
+    src_index(xs, c.cw, S, x0, x1, lx0, lx1);
+    const size_t plane = (size_t)a.H * a.W;
+    const float* fb = a.in + ((size_t)(cidx * a.T + t) * 3) * plane + (size_t)c.top * a.W + c.left;
+    float v[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float* p = fb + ch * plane;
+      const float p00 = p[(size_t)y0 * a.W + x0], p01 = p[(size_t)y0 * a.W + x1];
+      const float p10 = p[(size_t)y1 * a.W + x0], p11 = p[(size_t)y1 * a.W + x1];
+      v[ch] = ly0 * (lx0 * p00 + lx1 * p01) + ly1 * (lx0 * p10 + lx1 * p11);
+    }
+    const int stop = c.contrast_at >= 0 ? c.contrast_at : c.n_color;
+    for (int k = 0; k < stop; ++k) point_op(c.op[k], c.fac[k], v[0], v[1], v[2]);
+    float* ob = a.buf + ((size_t)(cidx * a.T + t) * 3) * S * S + pix;
+    ob[0] = v[0]; ob[(size_t)S * S] = v[1]; ob[(size_t)2 * S * S] = v[2];
+    gsum = tv_gray(v[0], v[1], v[2]);
+  }
+  if (c.contrast_at >= 0) {     // block-uniform
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gsum += __shfl_xor(gsum, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gsum;
+    __syncthreads();
+    if (threadIdx.x == 0) a.partial[(size_t)(cidx * a.T + t) * a.NB + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+constexpr int TX = 32, TY = 8;
+__device__ __forceinline__ int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// K2: per-frame mean from K1's partials (fixed order), contrast + the remaining colour steps applied while the tile
+// (with its blur halo, reflect-padded) is loaded into LDS, Gaussian as a horizontal then a vertical pass over LDS,
+// grayscale, normalisation.  Halo pixels repeat the pointwise colour work of their owners (~1.9x for a 5 x 9 kernel on a
+// 32 x 8 tile) instead of a separate read-modify-write pass over the intermediate image.
+__global__ __launch_bounds__(256) void finish_kernel(AugArgs a) {
+  const int ft = blockIdx.z;                  // clip * T + frame
+  const int cidx = ft / a.T;
+  const ClipParams& c = a.c[cidx];
+  const int S = a.S;
+  __shared__ float tile[3][(TY + MAXK - 1) * (TX + MAXK - 1)];
+  __shared__ float hrow[3][(TY + MAXK - 1) * TX];
+  __shared__ float red[4];
+  __shared__ float smean;
+  float mean = 0.0f;
+  if (c.contrast_at >= 0) {                   // block-uniform
+    const float* pp = a.partial + (size_t)ft * a.NB;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < a.NB; i += 256) s += pp[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) smean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(S * S);
+    __syncthreads();
+    mean = smean;
+  }
+  const int hx = c.blur ? c.nkx >> 1 : 0, hy = c.blur ? c.nky >> 1 : 0;
+  const int tw = TX + 2 * hx, th = TY + 2 * hy;
+  const float* ib = a.buf + (size_t)ft * 3 * S * S;
+  for (int i = threadIdx.x; i < tw * th; i += 256) {
+    const int ly = i / tw, lx = i - ly * tw;
+    // reflect, then clamp: positions beyond the edge of a partial tile only feed pixels that are not stored
+    const int gy = min(max(reflect(blockIdx.y * TY + ly - hy, S), 0), S - 1);
+    const int gx = min(max(reflect(blockIdx.x * TX + lx - hx, S), 0), S - 1);
+    const float* p = ib + (size_t)gy * S + gx;
+    float r = p[0], g = p[(size_t)S * S], b = p[(size_t)2 * S * S];
+    if (c.contrast_at >= 0) {
+      const float f = c.fac[c.contrast_at];
+      r = blend(r, mean, f); g = blend(g, mean, f); b = blend(b, mean, f);
+      for (int k = c.contrast_at + 1; k < c.n_color; ++k) point_op(c.op[k], c.fac[k], r, g, b);
+    }
+    tile[0][i] = r; tile[1][i] = g; tile[2][i] = b;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> 5;
+  float v[3];
+  if (c.blur) {
+    for (int i = threadIdx.x; i < th * TX; i += 256) {      // horizontal pass: th rows x TX columns
+      const int ly = i / TX, lx = i - ly * TX;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        float acc = 0.0f;
+        for (int k = 0; k < c.nkx; ++k) acc += c.kx[k] * tile[ch][ly * tw + lx + k];
+        hrow[ch][i] = acc;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      float acc = 0.0f;
+      for (int k = 0; k < c.nky; ++k) acc += c.ky[k] * hrow[ch][(ty + k) * TX + tx];
+      v[ch] = acc;
+    }
+  } else {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) v[ch] = tile[ch][ty * tw + tx];
+  }
+  const int x = blockIdx.x * TX + tx, y = blockIdx.y * TY + ty;
+  if (x >= S || y >= S) return;
+  if (c.gray) {
+    const float gch = 0.299f * v[0] + 0.587f * v[1] + 0.114f * v[2];
+    v[0] = v[1] = v[2] = gch;
+  }
+  float* ob = a.out + (size_t)ft * 3 * S * S + (size_t)y * S + x;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) ob[(size_t)ch * S * S] = (v[ch] - c.mean[ch]) / c.std[ch];
+}
+
+// torchvision _get_gaussian_kernel1d in fp32: linspace(-half, half, k), exp(-0.5 (x / sigma)^2), / sum
+void gaussian1d(int k, float sigma, float* w) {
+  const float half = (float)(k - 1) * 0.5f;
+  const float step = k > 1 ? (2.0f * half) / (float)(k - 1) : 0.0f;
+  float sum = 0.0f;
+  for (int i = 0; i < k; ++i) {
+    // torch.linspace fills symmetrically from both ends: start + i*step for the first half, end - (k-1-i)*step after it
+    const float x = i < k / 2 ? -half + step * (float)i : half - step * (float)(k - 1 - i);
+    const float q = x / sigma;
+    w[i] = expf(-0.5f * (q * q));
+    sum += w[i];
+  }
+  for (int i = 0; i < k; ++i) w[i] = w[i] / sum;
+}
+
+}  // namespace
+
+extern "C" size_t mvf_augment_workspace_bytes(int n_clips, int T, int S) {
+  if (n_clips <= 0 || T <= 0 || S <= 0) return 0;
+  const size_t nb = ((size_t)S * S + 255) / 256;
+  return ((size_t)n_clips * T * 3 * S * S + (size_t)n_clips * T * nb) * sizeof(float);
+}
+
+extern "C" int mvf_augment_clips(const float* in, float* out, int n_clips, int T, int H, int W, int S,
+                                 const MvfAugmentParams* params, void* workspace, size_t ws_bytes, hipStream_t st) {
+  MVF_CHECK_ARG(in && out && params && workspace && n_clips > 0 && T > 0 && H > 0 && W > 0 && S > 0);
+  MVF_CHECK_ARG(ws_bytes >= mvf_augment_workspace_bytes(n_clips, T, S));
+  const int NB = (S * S + 255) / 256;
+  float* buf = reinterpret_cast<float*>(workspace);
+  float* partial = buf + (size_t)n_clips * T * 3 * S * S;
+  for (int i = 0; i < n_clips; ++i) {   // validate everything before the first launch
+    const MvfAugmentParams& p = params[i];
+    MVF_CHECK_ARG(p.crop_h > 0 && p.crop_w > 0 && p.crop_top >= 0 && p.crop_left >= 0 && p.crop_top + p.crop_h <= H &&
+                  p.crop_left + p.crop_w <= W);
+    MVF_CHECK_ARG(p.n_color >= 0 && p.n_color <= 4);
+    int seen = 0;
+    for (int k = 0; k < p.n_color; ++k) {
+      MVF_CHECK_ARG(p.color_op[k] >= 0 && p.color_op[k] <= 3 && !(seen & (1 << p.color_op[k])));
+      seen |= 1 << p.color_op[k];
+    }
+    if (p.blur_sigma > 0.0f)
+      MVF_CHECK_ARG(p.blur_kx > 0 && p.blur_ky > 0 && (p.blur_kx & 1) && (p.blur_ky & 1) && p.blur_kx <= MAXK &&
+                    p.blur_ky <= MAXK && p.blur_kx / 2 < S && p.blur_ky / 2 < S);   // reflect padding needs pad < size
+    for (int ch = 0; ch < 3; ++ch) MVF_CHECK_ARG(p.std[ch] != 0.0f);
+  }
+  for (int c0 = 0; c0 < n_clips; c0 += MAXC) {
+    const int n = std::min(MAXC, n_clips - c0);
+    AugArgs a;
+    a.in = in + (size_t)c0 * T * 3 * H * W;
+    a.buf = buf + (size_t)c0 * T * 3 * S * S;
+    a.partial = partial + (size_t)c0 * T * NB;
+    a.out = out + (size_t)c0 * T * 3 * S * S;
+    a.n = n; a.T = T; a.H = H; a.W = W; a.S = S; a.NB = NB;
+    for (int i = 0; i < n; ++i) {
+      const MvfAugmentParams& p = params[c0 + i];
+      ClipParams& c = a.c[i];
+      c.top = p.crop_top; c.left = p.crop_left; c.ch = p.crop_h; c.cw = p.crop_w; c.flip = p.flip != 0;
+      c.n_color = p.n_color; c.contrast_at = -1;
+      for (int k = 0; k < 4; ++k) {
+        c.op[k] = k < p.n_color ? p.color_op[k] : 0;
+        c.fac[k] = k < p.n_color ? p.color_factor[k] : 1.0f;
+        if (k < p.n_color && p.color_op[k] == 1) c.contrast_at = k;
+      }
+      c.blur = p.blur_sigma > 0.0f; c.nkx = c.blur ? p.blur_kx : 1; c.nky = c.blur ? p.blur_ky : 1;
+      for (int k = 0; k < MAXK; ++k) c.kx[k] = c.ky[k] = 0.0f;
+      if (c.blur) { gaussian1d(c.nkx, p.blur_sigma, c.kx); gaussian1d(c.nky, p.blur_sigma, c.ky); }
+      c.gray = p.gray != 0;
+      for (int ch = 0; ch < 3; ++ch) { c.mean[ch] = p.mean[ch]; c.std[ch] = p.std[ch]; }
+    }
+    const dim3 g1(NB, T, n);
+    hipLaunchKernelGGL(resize_color_kernel, g1, dim3(256), 0, st, a);
+    MVF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(finish_kernel, dim3((S + TX - 1) / TX, (S + TY - 1) / TY, T * n), dim3(256), 0, st, a);
+    MVF_LAUNCH_CHECK();
+  }
+  return MVF_OK;
+}

@@ -12,8 +12,11 @@ import torch
 
 class SyntheticClips:
     def __init__(self, batch_size, num_frames, image_size=224, iters=50, seed=1234, device='cpu', seq_len=100,
-                 pad_every=0, resident=True):
+                 pad_every=0, resident=True, raw_hw=None):
+        """raw_hw = (H, W): emit frames as the datasets do BEFORE pre-processing (penn_action.py:110-111: uint8 / 255, at
+        the video's own size) so that the GPU-side augmentation (datasets/augment.py) is part of the loop."""
         self.b, self.t, self.s = batch_size, num_frames, image_size
+        self.raw_hw = raw_hw
         self.iters, self.seed, self.device = iters, seed, device
         self.seq_len, self.pad_every, self.resident = seq_len, pad_every, resident
         self.sampler = None
@@ -26,7 +29,11 @@ class SyntheticClips:
     def _make(self, it):
         g = torch.Generator().manual_seed(self.seed + 7919 * it)
         b, t, s = self.b, self.t, self.s
-        views = [torch.randn(b, t, 3, s, s, generator=g) for _ in range(2)]
+        if self.raw_hw is None:
+            views = [torch.randn(b, t, 3, s, s, generator=g) for _ in range(2)]
+        else:
+            views = [torch.randint(0, 256, (b, t, 3) + tuple(self.raw_hw), generator=g, dtype=torch.uint8).float() / 255.0
+                     for _ in range(2)]
         seq_lens = torch.full((b, 2), self.seq_len, dtype=torch.long)
         steps = torch.sort(torch.randint(0, self.seq_len, (b, 2, t), generator=g), dim=-1)[0]
         masks = torch.ones(b, 2, t)
@@ -50,20 +57,26 @@ class SyntheticClips:
                 yield self._make(it)
 
 
-def construct_dataloader(cfg, split, device='cpu', iters=None, rank=0, resident=False):
+def construct_dataloader(cfg, split, device='cpu', iters=None, rank=0, resident=False, raw_hw=None):
     loader = SyntheticClips(cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.NUM_FRAMES, cfg.IMAGE_SIZE,
                             iters=iters if iters is not None else 50, seed=1234 + rank + (0 if split == 'train' else 10 ** 6),
-                            device=device, pad_every=4 if split == 'train' else 0, resident=resident)
+                            device=device, pad_every=4 if split == 'train' else 0, resident=resident, raw_hw=raw_hw)
     return loader, None
 
 
-def get_data_preprocess(cfg, split):
-    """Synthetic frames are already normalised; GPU-side augmentation (data_augment.py) is SURVEY 8(f) row 1."""
-    return lambda clip: clip
+def get_data_preprocess(cfg, split, raw=False):
+    """Normalised synthetic frames need no pre-processing (None); raw ones go through the reference's pipeline for the split
+    (datasets/augment.py: get_data_preprocess)."""
+    if not raw:
+        return None
+    from . import augment
+    return augment.get_data_preprocess(cfg, split)
 
 
 def preproc_views(view_0, view_1, data_preprocess, device):
-    """train.preproc_views (train.py:39-53): -> [B, 2, T, 3, H, W] on `device`."""
-    view_0 = data_preprocess(view_0.to(device, non_blocking=True))
-    view_1 = data_preprocess(view_1.to(device, non_blocking=True))
-    return torch.stack([view_0, view_1], dim=1)
+    """train.preproc_views (train.py:39-53): -> [B, 2, T, 3, S, S] on `device`."""
+    view_0, view_1 = view_0.to(device, non_blocking=True), view_1.to(device, non_blocking=True)
+    if data_preprocess is None:
+        return torch.stack([view_0, view_1], dim=1)
+    from . import augment
+    return augment.preproc_views(view_0, view_1, data_preprocess)

@@ -755,6 +755,32 @@ def vit_forward(frames, packed, frames_per_chunk=0, want_cls=True, attn_variant=
 
 
 # ------------------------------------------------------------------------------------------------
+# view augmentation
+# ------------------------------------------------------------------------------------------------
+_aug_ws = {}
+
+
+def augment_clips(clips, params, size):
+    """clips [n, T, 3, H, W] fp32 in [0, 1] on the device, params: n `_lib.MvfAugmentParams` (one clip's draws each)
+    -> [n, T, 3, size, size] fp32, normalised (include/mvf_hip.h: mvf_augment_clips)."""
+    if not clips.is_cuda:
+        raise _lib.MvfError('augment_clips received a %s tensor (no CPU fallback)' % clips.device)
+    clips = clips.contiguous().float()
+    n, T, c, H, W = clips.shape
+    assert c == 3 and len(params) == n, (clips.shape, len(params))
+    nbytes = _lib.load().mvf_augment_workspace_bytes(n, T, size)
+    key = (clips.device.index, torch.cuda.current_stream(clips.device).cuda_stream)
+    ws = _aug_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _aug_ws[key] = torch.empty(nbytes, device=clips.device, dtype=torch.uint8)
+    out = torch.empty(n, T, 3, size, size, device=clips.device, dtype=torch.float32)
+    arr = (_lib.MvfAugmentParams * n)(*params)
+    call('mvf_augment_clips', clips.data_ptr(), out.data_ptr(), n, T, H, W, size, ctypes.cast(arr, ctypes.c_void_p),
+         ws.data_ptr(), ws.numel(), stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # optimiser
 # ------------------------------------------------------------------------------------------------
 def grad_norm(flat_grad, scratch, out, extra_sq=None):

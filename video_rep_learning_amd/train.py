@@ -188,10 +188,11 @@ def main(argv=None):
     if not args.synthetic:
         raise NotImplementedError('only --synthetic data is wired in this build: the video decoders / samplers of '
                                   'CARL_MVF/datasets are host-side I/O outside the hot path (SURVEY section 2)')
-    train_loader, _ = synthetic.construct_dataloader(cfg, 'train', device=device, rank=rank)
-    val_loader, _ = synthetic.construct_dataloader(cfg, 'val', device=device, rank=rank, iters=4)
-    train_preproc = synthetic.get_data_preprocess(cfg, 'train')
-    val_preproc = synthetic.get_data_preprocess(cfg, 'val')
+    raw_hw = tuple(args.synthetic_raw) if getattr(args, 'synthetic_raw', None) else None
+    train_loader, _ = synthetic.construct_dataloader(cfg, 'train', device=device, rank=rank, raw_hw=raw_hw)
+    val_loader, _ = synthetic.construct_dataloader(cfg, 'val', device=device, rank=rank, iters=4, raw_hw=raw_hw)
+    train_preproc = synthetic.get_data_preprocess(cfg, 'train', raw=raw_hw is not None)   # train.py:294-297
+    val_preproc = synthetic.get_data_preprocess(cfg, 'val', raw=raw_hw is not None)
 
     start_epoch = load_checkpoint(cfg, model, optimizer)
     cfg.TRAIN.MAX_ITERS = cfg.TRAIN.MAX_EPOCHS * len(train_loader)

@@ -27,6 +27,8 @@ def build_parser():
     p.add_argument('--device', type=str, default=None, help="'cuda' (MI355X via HIP) -- the only product device")
     p.add_argument('--backend', type=str, default=None, help="torch.distributed backend: 'nccl' (= RCCL) | 'gloo'")
     p.add_argument('--synthetic', action='store_true', default=False, help='train on synthetic clips of the configured shape')
+    p.add_argument('--synthetic_raw', type=int, nargs=2, default=None, metavar=('H', 'W'),
+                   help='synthetic clips as RAW [0,1] frames of this size: the GPU-side augmentation runs in the loop')
     p.add_argument('--max_iters', type=int, default=0, help='stop each epoch after this many iterations (0 = full)')
     p.add_argument('--opts', default=None, nargs=argparse.REMAINDER, help='KEY VALUE pairs overriding the config')
     return p
@@ -67,6 +69,8 @@ def load_config(args):
         for full_key, v in zip(opts[0::2], opts[1::2]):
             keys = full_key.split('.')
             d = cfg
+            if keys[0] == 'MI355X' and 'MI355X' not in cfg:      # the build's own optional section
+                cfg['MI355X'] = EasyDict()
             for k in keys[:-1]:
                 d = d[k]
             # reference: d[subkey] must exist (KeyError otherwise); build-specific optional keys may be created

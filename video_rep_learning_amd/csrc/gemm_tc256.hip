@@ -42,6 +42,8 @@
 //    tiles into 16-byte stores (gemm_tc_epi.h).
 //  * tried and rejected: N-grouping (each XCD serving only nbn/4 weight panels so that W stays L2-resident) -- no change
 //    at all on fc1 (315 us either way): W re-fetches are not what the loop waits for.
+//  * tried and rejected: a start-phase offset between neighbouring workgroups of the short-K read-modify GEMM (proj) so that
+//    their epilogues' residual traffic does not arrive as one chip-wide burst -- 104 -> 104..112 us, 11.6 -> 11.9 ms/step.
 //  * tried and rejected (PMC): rotating the K loop per A row-panel to shorten W's L2 re-use distance -- the L2 hits come
 //    from workgroups reading the SAME slices at the SAME time; rotation cut the hit rate from 74 % to 47 % (fc2).
 //  * XCD-aware tile walk: workgroups b, b+8, ... share an XCD (round-robin dispatch, speed only); group x = b & 7 owns a

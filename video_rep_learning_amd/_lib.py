@@ -94,6 +94,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: the wheel carries its own libamdhip64; if this library pulled in /opt/rocm's copy before torch is
+    # imported, the process would hold two HIP runtimes and every launch from here fails with hipErrorNoDevice (100)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise MvfError('libmvf_hip.so not found at %s -- build it with `python -m video_rep_learning_amd.csrc.build` '
                        '(there is no CPU fallback)' % LIB_PATH)

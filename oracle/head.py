@@ -69,6 +69,7 @@ class HeadCfg:
         self.ln_keys = False         # SMART_LN_KEYS
         self.val_pass = False        # VAL_PASS
         self.disjoint = False        # SMART_DISJOINT
+        self.fwb = False             # FIXED_WIDTH_BASELINE
         self.n_taps = 1              # len(SMART_FEATS.split(','))
         self.bn_eps = 1e-5
         self.bn_momentum = 0.1
@@ -228,7 +229,14 @@ def mvf_head(feat, masks, p, cfg, training=False, cls_emb=None, update_running=F
     returns embeddings [Bc, T, E]
     """
     bc, t, n, c = feat.shape
-    pooled, probs = token_pooling(feat.reshape(bc * t, n, c), p, 'pooling.', cfg, bc, cls_emb)  # [Bc*T, ntok, d]
+    if cfg.fwb:
+        # FWBPooling.forward (mvformer.py:455-463): lin_conv(cls).reshape([F, -1, ntok]) is [F, spc, ntok]; the head
+        # then moves the token axis forward (mvformer.py:140-142)
+        tt = cfg.nst + cfg.nsdt
+        pooled = linear(cls_emb, p, 'pooling.lin_conv').reshape(bc * t, -1, tt).transpose(1, 2)
+        probs = None
+    else:
+        pooled, probs = token_pooling(feat.reshape(bc * t, n, c), p, 'pooling.', cfg, bc, cls_emb)  # [Bc*T, ntok, d]
     ntok = pooled.shape[1]
     x = pooled
     if cfg.one_hot == 'pool':

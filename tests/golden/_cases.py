@@ -35,6 +35,7 @@ class Dims:
         self.ln_keys = False
         self.disjoint = False
         self.dyn_ctrl = 'separate'
+        self.fwb = False       # FIXED_WIDTH_BASELINE (FWBPooling, mvformer.py:421-463)
         self.train_len = 32
         self.proj = 128        # cfg.MODEL.PROJECTION_SIZE
         for k, v in kw.items():
@@ -73,13 +74,16 @@ def head_params(d, seed):
     g = torch.Generator().manual_seed(seed)
     p = {}
     ca = 'pooling.cross_att.'
-    if d.nst > 0:
+    if d.fwb:
+        _linear(p, g, 'pooling.lin_conv', d.C // d.n_taps, d.spc * d.ntok, gain=2.0)
+    if d.nst > 0 and not d.fwb:
         p[ca + 'Q_s'] = _u(g, (1, d.nst, d.spc), 4.0 / math.sqrt(d.spc))
         p[ca + 'Q_s_b'] = _u(g, (d.spc,), 1.0 / math.sqrt(d.spc))
-    _linear(p, g, ca + 'linear_K2d', d.C, d.spc, gain=4.0)
-    if not d.val_pass:
+    if not d.fwb:
+        _linear(p, g, ca + 'linear_K2d', d.C, d.spc, gain=4.0)
+    if not d.val_pass and not d.fwb:
         _linear(p, g, ca + 'linear_V2d', d.C, d.spc)
-    if d.nsdt > 0:
+    if d.nsdt > 0 and not d.fwb:
         _linear(p, g, ca + 'in2dynQ', d.C // d.n_taps, d.spc * d.nsdt, gain=4.0)
     cin = d.C if d.val_pass else d.spc
     if d.one_hot == 'pool':

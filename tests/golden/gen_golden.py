@@ -84,6 +84,8 @@ def ref_cfg(d, proj=True):
               SMART_FINAL=d.smart_final, SMART_FEATS=','.join(['3', '7', '11'][:d.n_taps]) if d.n_taps > 1 else '11',
               VAL_PASS=d.val_pass, SMART_DISJOINT=d.disjoint, SMART_LN_KEYS=d.ln_keys, DYNAMIC_CTRL=d.dyn_ctrl,
               FUSION_TYPE='smart')
+    if d.fwb:
+        em['FIXED_WIDTH_BASELINE'] = True
     return ad(dict(MODEL=dict(EMBEDDER_MODEL=em, BASE_MODEL=dict(OUT_CHANNEL=d.C), PROJECTION=proj,
                               PROJECTION_SIZE=d.proj, L2_NORMALIZE=True),
                    TRAIN=dict(NUM_FRAMES=d.train_len),
@@ -126,11 +128,18 @@ HEAD_CASES = {
 }
 
 
-def gen_head(mv):
+# cases added later keep their own seeds and file (the seeds of HEAD_CASES depend on the sorted case list)
+HEAD_CASES_FWB = {
+    'fwb_train': (dict(SMALL, fwb=True), 3, 8, 16, 3, True, 2001),
+    'fwb_eval':  (dict(SMALL, fwb=True, nst=2, nsdt=1, one_hot='none', smart_final='avg'), 2, 8, 16, 0, False, 2002),
+}
+
+
+def gen_head(mv, cases=None, fname='head.npz'):
     out = {}
-    for name, (kw, bc, t, n, pad, training) in HEAD_CASES.items():
+    cases = cases or {k: v + (1000 + sorted(HEAD_CASES).index(k),) for k, v in HEAD_CASES.items()}
+    for name, (kw, bc, t, n, pad, training, seed) in cases.items():
         d = C.Dims(**kw)
-        seed = 1000 + sorted(HEAD_CASES).index(name)
         params = C.head_params(d, seed)
         feat, masks, cls = C.head_inputs(d, bc, t, n, seed + 500, pad)
         mod = mv.MultiEntityTransformerEmbModel(ref_cfg(d))
@@ -138,7 +147,8 @@ def gen_head(mv):
         mod.train(training)
         emb = mod(to_ref_x(feat), video_masks=masks, cls_emb=cls)
         rec = {'emb': emb.detach().numpy()}
-        rec['attn'] = mod.pooling.cross_att.attn_matrix.numpy()[: t]  # last clip's [T, nq, N]
+        if not d.fwb:
+            rec['attn'] = mod.pooling.cross_att.attn_matrix.numpy()[: t]  # last clip's [T, nq, N]
         g = torch.Generator().manual_seed(seed + 900)
         gout = torch.randn(emb.shape, generator=g)
         (emb * gout).sum().backward()
@@ -153,7 +163,7 @@ def gen_head(mv):
         for k, v in rec.items():
             out['%s/%s' % (name, k)] = v
         print('head', name, tuple(emb.shape), float(emb.abs().mean()))
-    np.savez_compressed(os.path.join(HERE, 'head.npz'), **out)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
 
 
 def gen_primitives(mu):
@@ -476,11 +486,13 @@ def main():
     spec = importlib.util.spec_from_file_location('ref_scl', os.path.join(REF, 'algos', 'scl.py'))
     scl_mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(scl_mod)
-    which = sys.argv[1:] or ['primitives', 'head', 'mlp', 'scl', 'glue', 'traj', 'keys', 'augment']
+    which = sys.argv[1:] or ['primitives', 'head', 'mlp', 'scl', 'glue', 'traj', 'keys', 'augment', 'fwb']
     if 'primitives' in which:
         gen_primitives(mu)
     if 'head' in which:
         gen_head(mv)
+    if 'fwb' in which:
+        gen_head(mv, HEAD_CASES_FWB, 'head_fwb.npz')
     if 'mlp' in which:
         gen_mlp_head(rc)
     if 'scl' in which:

@@ -36,7 +36,8 @@ def oracle_cfgs(cfg):
                           one_hot=em.get('SMART_ONE_HOT', 'none'), smart_final=em.get('SMART_FINAL', 'max'),
                           num_heads=em.NUM_HEADS, num_layers=em.NUM_LAYERS, train_len=cfg.TRAIN.NUM_FRAMES,
                           dyn_ctrl=em.get('DYNAMIC_CTRL', 'separate'), disjoint=bool(em.get('SMART_DISJOINT', False)),
-                          val_pass=bool(em.get('VAL_PASS', False)), n_taps=len(taps))
+                          val_pass=bool(em.get('VAL_PASS', False)), n_taps=len(taps),
+                          fwb=bool(em.get('FIXED_WIDTH_BASELINE', False)))
     scl_cfg = dict(negative_type=cfg.SCL.NEGATIVE_TYPE, temperature=cfg.SCL.SOFTMAX_TEMPERATURE,
                    label_variance=cfg.SCL.LABEL_VARIENCE)
     return vit_cfg, head_cfg, scl_cfg
@@ -83,7 +84,7 @@ SMALL = dict(network='TIMM-vit_small_patch16_224.dino', num_frames=8, batch_size
 
 # fg99 / long64 / dinov2: the head and sequence shapes of BASELINE configs[2], [3] and [4] at a small image size
 @pytest.mark.parametrize('variant', ['base', 'avg_enc_nst6', 'max_none', 'lin', 'dynamic', 'disjoint', 'batch_neg', 'fg99',
-                                     'long64', 'dinov2'])
+                                     'long64', 'dinov2', 'fwb'])
 def test_small_model_loss_and_grads(variant):
     kw = dict(SMALL)
     if variant == 'avg_enc_nst6':
@@ -100,6 +101,8 @@ def test_small_model_loss_and_grads(variant):
         kw.update(SMART_TOKENS=6, CAPACITY_SCALAR=6, EMBEDDING_SIZE=256, SMART_FEATS='9,10,11', SMART_FINAL='avg')
     elif variant == 'long64':    # 64-frame clips: temporal sequence S = 3 x 64 = 192
         kw.update(num_frames=64, batch_size=1)
+    elif variant == 'fwb':       # fixed-width baseline: entities are slices of a linear map of the CLS embedding
+        kw.update(FIXED_WIDTH_BASELINE=True)
     elif variant == 'dinov2':    # LayerScale + patch 14 backbone (DINOv2 family)
         kw.update(network='TIMM-vit_small_patch14_dinov2.lvd142m', image_size=28)
     cfg, model = make(3, **kw)

@@ -15,7 +15,7 @@ from oracle import vit as OV
 def hcfg(d):
     return OH.HeadCfg(nst=d.nst, nsdt=d.nsdt, spc=d.spc, one_hot=d.one_hot, smart_final=d.smart_final,
                       num_heads=d.heads, num_layers=d.layers, train_len=d.train_len, dyn_ctrl=d.dyn_ctrl,
-                      ln_keys=d.ln_keys, val_pass=d.val_pass, disjoint=d.disjoint, n_taps=d.n_taps)
+                      ln_keys=d.ln_keys, val_pass=d.val_pass, disjoint=d.disjoint, n_taps=d.n_taps, fwb=d.fwb)
 
 
 def close(a, b, rtol=1e-4, atol=1e-5):
@@ -61,19 +61,23 @@ def test_encoder(golden, s):
     close(x.grad, gp['encoder/S%d_gx' % s], rtol=2e-4)
 
 
-@pytest.mark.parametrize('name', sorted(G.HEAD_CASES))
+ALL_HEAD_CASES = {k: v + (1000 + sorted(G.HEAD_CASES).index(k), 'head') for k, v in G.HEAD_CASES.items()}
+ALL_HEAD_CASES.update({k: v + ('head_fwb',) for k, v in G.HEAD_CASES_FWB.items()})     # FWBPooling ablation
+
+
+@pytest.mark.parametrize('name', sorted(ALL_HEAD_CASES))
 def test_head_forward_backward(golden, name):
-    gh = golden('head')
-    kw, bc, t, n, pad, training = G.HEAD_CASES[name]
+    kw, bc, t, n, pad, training, seed, fname = ALL_HEAD_CASES[name]
+    gh = golden(fname)
     d = C.Dims(**kw)
-    seed = 1000 + sorted(G.HEAD_CASES).index(name)
     params = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and 'running' not in k else v.clone())
               for k, v in C.head_params(d, seed).items()}
     feat, masks, cls = C.head_inputs(d, bc, t, n, seed + 500, pad)
     emb, aux = OH.mvf_head(feat, masks, params, hcfg(d), training=training, cls_emb=cls, update_running=training,
                            return_aux=True)
     close(emb, gh[name + '/emb'], rtol=2e-4, atol=2e-5)
-    close(aux['probs'][-t:], gh[name + '/attn'], rtol=2e-4, atol=1e-6)
+    if not d.fwb:
+        close(aux['probs'][-t:], gh[name + '/attn'], rtol=2e-4, atol=1e-6)
     gout = torch.randn(emb.shape, generator=torch.Generator().manual_seed(seed + 900))
     (emb * gout).sum().backward()
     full = d.C <= 256

@@ -133,6 +133,39 @@ class LearnableTokenPooling(nn.Module):
         return self.cross_att(taps, dyn_in if self.nsdt > 0 else None)
 
 
+class FWBPooling(nn.Module):
+    """Fixed-width baseline (mvformer.py:421-463): the ntok "entities" are slices of ONE linear map of the frame's CLS
+    embedding, no spatial pooling.  lin_conv(cls).reshape([F, -1, ntok]) is channel-major, so entity j of channel c is
+    output column c * ntok + j."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        if 'SMART_TOKENS' not in cfg.MODEL.EMBEDDER_MODEL:
+            print('Using default number of SMART_TOKENS: 5')
+        if 'SMART_POOL_CHANNELS' not in cfg.MODEL.EMBEDDER_MODEL:
+            print('Using default number of SMART_POOL_CHANNELS: 384')
+        print('RUNNING FIXED WIDTH BASELINE')
+        self.nst = _em(cfg, 'SMART_TOKENS', 5)
+        self.nsdt = _em(cfg, 'SMART_DYNAMIC_TOKENS', 0)
+        self.spc = _em(cfg, 'SMART_POOL_CHANNELS', 384)
+        self.in_c = cfg.MODEL.BASE_MODEL.OUT_CHANNEL
+        d_dyn_in = self.in_c
+        if 'SMART_FEATS' in cfg.MODEL.EMBEDDER_MODEL:
+            sfl = str(cfg.MODEL.EMBEDDER_MODEL.SMART_FEATS)
+            if ',' in sfl:
+                d_dyn_in = int(d_dyn_in / len(sfl.split(',')))
+        self.lin_conv = nn.Linear(d_dyn_in, self.spc * (self.nst + self.nsdt))
+
+    def forward(self, taps, cls_in):
+        """-> [Bc, ntok, T, spc] rows in (clip, entity, frame) order, like LearnableTokenPooling."""
+        if cls_in is None:
+            raise ops._lib.MvfError('FIXED_WIDTH_BASELINE needs the backbone CLS embedding')
+        tt = self.nst + self.nsdt
+        y = ops.linear(cls_in, self.lin_conv.weight, self.lin_conv.bias)          # [Bc*T, spc*tt]
+        return y.view(taps.n_clips, taps.n_frames, self.spc, tt).permute(0, 3, 1, 2).contiguous()
+
+
 class MultiEntityTransformerEmbModel(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -150,13 +183,11 @@ class MultiEntityTransformerEmbModel(nn.Module):
         if self.one_hot_pos == 'pool':
             in_channels += (self.nst + self.nsdt)
         self.fwb = bool(_em(cfg, 'FIXED_WIDTH_BASELINE', False))
-        if self.fwb:
-            raise NotImplementedError('FIXED_WIDTH_BASELINE (FWBPooling ablation) is outside the MI355X hot path')
         cap_scalar = cfg.MODEL.EMBEDDER_MODEL.CAPACITY_SCALAR
         fc_params = _em(cfg, 'FC_LAYERS', None)
         self.embedding_size = cfg.MODEL.EMBEDDER_MODEL.EMBEDDING_SIZE
         hidden_channels = cfg.MODEL.EMBEDDER_MODEL.HIDDEN_SIZE
-        self.pooling = LearnableTokenPooling(cfg)
+        self.pooling = FWBPooling(cfg) if self.fwb else LearnableTokenPooling(cfg)      # mvformer.py:63-67
         if fc_params is None:
             self.fc_layers = nn.Identity()
         else:

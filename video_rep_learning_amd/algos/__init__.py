@@ -1,14 +1,23 @@
-"""Training-algorithm registry (CARL_MVF/algos/__init__.py:7-20).  Only 'scl' -- the algorithm of every
-configs_mvf/*.yml -- is on the MI355X hot path; tcc/tcn/classification are the original CARL baselines."""
-from .scl import SCL
+"""`get_algo(cfg)` -> object with `compute_loss(...)` (the reference's algo registry surface).  TRAINING_ALGO 'scl' is the
+algorithm of every configs_mvf/*.yml; tcc / tcn / classification are the CARL baselines and not on the MI355X path."""
+from . import scl as _scl
 
-ALGO_NAME_TO_ALGO_CLASS = {
-    'scl': SCL,
-}
+_REGISTRY = {}
+
+
+def register(name):
+    def deco(cls):
+        _REGISTRY[name] = cls
+        return cls
+    return deco
+
+
+register('scl')(_scl.SCL)
 
 
 def get_algo(cfg):
-    algo_name = cfg.TRAINING_ALGO
-    if algo_name not in ALGO_NAME_TO_ALGO_CLASS:
-        raise ValueError('%s not supported yet.' % algo_name)
-    return ALGO_NAME_TO_ALGO_CLASS[algo_name](cfg)
+    name = cfg.TRAINING_ALGO
+    cls = _REGISTRY.get(name)
+    if cls is None:
+        raise ValueError('%s not supported yet.' % name)     # the reference's message for an unknown algo
+    return cls(cfg)

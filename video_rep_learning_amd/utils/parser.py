@@ -1,7 +1,9 @@
-"""CLI + config loading with the reference's surface (CARL_MVF/utils/parser.py:15-131):
-`--local_rank --workdir --logdir --continue_train --visualize --cfg_file --opts K V ... --tempcfg`, YAML merged
-SHALLOWLY over the defaults, `--opts` values typed by the existing value, EVAL batch/frames forced to TRAIN's.
-Additions (torchrun era): `--local-rank` alias and the LOCAL_RANK env default; `--device`/`--backend`."""
+"""Command line and config assembly with the reference's surface (CARL_MVF/utils/parser.py): the same flags
+(`--local_rank --workdir --logdir --continue_train --visualize --cfg_file --tempcfg --opts K V ...`), a YAML merged
+SHALLOWLY over the defaults (a top-level key of the file replaces the default block), `--opts` values typed after the
+value they replace, EVAL batch size / frame count tied to TRAIN's, and LOGDIR/config.yml written on first use and re-read
+on later runs.  Added for this build: `--local-rank` / LOCAL_RANK (torchrun), `--device`, `--backend`, `--synthetic`,
+`--synthetic_raw H W`, `--max_iters`, and creation of the optional MI355X.* / MODEL.EMBEDDER_MODEL.* keys from `--opts`."""
 import argparse
 import os
 
@@ -12,103 +14,115 @@ from .config import get_cfg, EasyDict
 
 logger = logging.get_logger(__name__)
 
+# (flags, argparse keywords) -- one row per option
+_OPTIONS = (
+    (('--local_rank', '--local-rank'), dict(dest='local_rank', type=int, default=None, help='rank in local processes')),
+    (('--workdir',), dict(type=str, default='/home/username/datasets', help='Path to datasets and pretrained models.')),
+    (('--logdir',), dict(type=str, default=None, help='Path to logs.')),
+    (('--continue_train',), dict(action='store_true', default=False)),
+    (('--visualize',), dict(action='store_true', default=False)),
+    (('--cfg_file',), dict(type=str, default=None, help='Path to the config file')),
+    (('--tempcfg',), dict(action='store_true', default=False,
+                          help='run with the given config and ignore an existing LOGDIR/config.yml')),
+    (('--device',), dict(type=str, default=None, help="'cuda' (MI355X via HIP) -- the only product device")),
+    (('--backend',), dict(type=str, default=None, help="torch.distributed backend: 'nccl' (= RCCL) | 'gloo'")),
+    (('--synthetic',), dict(action='store_true', default=False, help='train on synthetic clips of the configured shape')),
+    (('--synthetic_raw',), dict(type=int, nargs=2, default=None, metavar=('H', 'W'),
+                                help='synthetic clips as RAW [0,1] frames of this size: the GPU-side augmentation runs '
+                                     'in the loop')),
+    (('--max_iters',), dict(type=int, default=0, help='stop each epoch after this many iterations (0 = full)')),
+    (('--opts',), dict(default=None, nargs=argparse.REMAINDER, help='KEY VALUE pairs overriding the config')),
+)
+# sections whose keys are probed with `in` by the model code and may therefore be introduced from the command line
+_OPEN_PREFIXES = ('MI355X.', 'MODEL.EMBEDDER_MODEL.')
+_OPEN_KEYS = ('MODEL.BASE_MODEL.WEIGHTS',)
+
 
 def build_parser():
     p = argparse.ArgumentParser(description='MV-Former SCL training (MI355X-native).')
-    p.add_argument('--local_rank', '--local-rank', dest='local_rank', type=int,
-                   default=int(os.environ.get('LOCAL_RANK', 0)), help='rank in local processes')
-    p.add_argument('--workdir', type=str, default='/home/username/datasets', help='Path to datasets and pretrained models.')
-    p.add_argument('--logdir', type=str, default=None, help='Path to logs.')
-    p.add_argument('--continue_train', action='store_true', default=False)
-    p.add_argument('--visualize', action='store_true', default=False)
-    p.add_argument('--cfg_file', type=str, default=None, help='Path to the config file')
-    p.add_argument('--tempcfg', action='store_true', default=False,
-                   help='run with the given config and ignore an existing LOGDIR/config.yml')
-    p.add_argument('--device', type=str, default=None, help="'cuda' (MI355X via HIP) -- the only product device")
-    p.add_argument('--backend', type=str, default=None, help="torch.distributed backend: 'nccl' (= RCCL) | 'gloo'")
-    p.add_argument('--synthetic', action='store_true', default=False, help='train on synthetic clips of the configured shape')
-    p.add_argument('--synthetic_raw', type=int, nargs=2, default=None, metavar=('H', 'W'),
-                   help='synthetic clips as RAW [0,1] frames of this size: the GPU-side augmentation runs in the loop')
-    p.add_argument('--max_iters', type=int, default=0, help='stop each epoch after this many iterations (0 = full)')
-    p.add_argument('--opts', default=None, nargs=argparse.REMAINDER, help='KEY VALUE pairs overriding the config')
+    for flags, kw in _OPTIONS:
+        p.add_argument(*flags, **kw)
     return p
 
 
 def parse_args(argv=None):
-    return build_parser().parse_args(argv)
+    args = build_parser().parse_args(argv)
+    if args.local_rank is None:
+        args.local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    return args
+
+
+_BOOL_WORDS = {'true': True, 'True': True, 'false': False, 'False': False}
 
 
 def convert_value(old, v):
-    """Type `v` (a string from the command line) like the existing value (parser.py:46-61)."""
-    if isinstance(old, bool):
-        s = v.strip()
-        if s in ('False', 'false'):
-            return False
-        if s in ('True', 'true'):
-            return True
-        return None  # the reference falls through and returns None here
-    if isinstance(old, str):
-        return str(v)
-    if isinstance(old, int):
-        return int(v)
-    if isinstance(old, float):
-        return float(v)
+    """`v` (text from the command line) typed like `old`.  bool before int (bool is an int); an unrecognised boolean word
+    yields None, as in the reference; list items take the type of the old list's first item and are space-separated
+    inside optional brackets."""
+    kind = type(old)
+    if kind is bool:
+        return _BOOL_WORDS.get(v.strip())
+    if kind in (str, int, float):
+        return kind(v)
     if isinstance(old, (list, tuple)):
-        return [convert_value(old[0], x) for x in v.strip('[').strip(']').split(' ')]
-    raise ValueError("Don't support for config type:", type(old))
+        return [convert_value(old[0], item) for item in v.strip('[').strip(']').split(' ')]
+    raise ValueError("Don't support for config type:", kind)
+
+
+def _override(cfg, dotted, text):
+    *parents, leaf = dotted.split('.')
+    if parents and parents[0] == 'MI355X' and 'MI355X' not in cfg:      # the build's own optional section
+        cfg['MI355X'] = EasyDict()
+    node = cfg
+    for name in parents:
+        node = node[name]                                               # KeyError for an unknown section, as upstream
+    if leaf in node:
+        node[leaf] = convert_value(node[leaf], text)
+    elif dotted.startswith(_OPEN_PREFIXES) or dotted in _OPEN_KEYS:
+        node[leaf] = yaml.safe_load(text)
+    else:
+        raise KeyError(dotted)
 
 
 def load_config(args):
     cfg = get_cfg()
-    if getattr(args, 'cfg_file', None) is not None and os.path.exists(args.cfg_file):
-        logger.info('Using config from %s.', args.cfg_file)
-        with open(args.cfg_file, 'r') as f:
+    path = getattr(args, 'cfg_file', None)
+    if path is not None and os.path.exists(path):
+        logger.info('Using config from %s.', path)
+        with open(path, 'r') as f:
             cfg.update(yaml.safe_load(f))
-    opts = getattr(args, 'opts', None)
-    if opts:
-        for full_key, v in zip(opts[0::2], opts[1::2]):
-            keys = full_key.split('.')
-            d = cfg
-            if keys[0] == 'MI355X' and 'MI355X' not in cfg:      # the build's own optional section
-                cfg['MI355X'] = EasyDict()
-            for k in keys[:-1]:
-                d = d[k]
-            # reference: d[subkey] must exist (KeyError otherwise); build-specific optional keys may be created
-            if keys[-1] in d:
-                d[keys[-1]] = convert_value(d[keys[-1]], v)
-            elif keys[0] == 'MI355X' or full_key.startswith('MODEL.EMBEDDER_MODEL.') or full_key == 'MODEL.BASE_MODEL.WEIGHTS':
-                d[keys[-1]] = yaml.safe_load(v)
-            else:
-                raise KeyError(full_key)
-    if getattr(args, 'logdir', None) is not None:
-        cfg.LOGDIR = args.logdir
-    else:
-        cfg.LOGDIR = os.path.join('/tmp', cfg.LOGDIR)
+    pairs = getattr(args, 'opts', None) or ()
+    for key, text in zip(pairs[0::2], pairs[1::2]):
+        _override(cfg, key, text)
+    logdir = getattr(args, 'logdir', None)
+    cfg.LOGDIR = logdir if logdir is not None else os.path.join('/tmp', cfg.LOGDIR)
     cfg.EVAL.BATCH_SIZE = cfg.TRAIN.BATCH_SIZE
     cfg.EVAL.NUM_FRAMES = cfg.TRAIN.NUM_FRAMES
     return cfg
 
 
 def to_dict(config):
-    if isinstance(config, (list, tuple)):
-        return [to_dict(c) for c in config]
+    """EasyDict tree -> plain containers (what yaml.safe_dump accepts)."""
     if isinstance(config, dict):
         return {k: to_dict(v) for k, v in config.items()}
+    if isinstance(config, (list, tuple)):
+        return [to_dict(c) for c in config]
     return config
 
 
 def setup_train_dir(cfg, logdir, continue_train=False, tempcfg=False):
-    """parser.py:106-131: persist the config on first use, otherwise re-read the stored one (unless --tempcfg)."""
-    os.makedirs(logdir, exist_ok=True)
-    config_path = os.path.join(logdir, 'config.yml')
-    if not os.path.exists(config_path):
-        logger.info('Using config from config.py as no config.yml file exists in %s', logdir)
-        with open(config_path, 'w') as f:
-            yaml.safe_dump({k: to_dict(v) for k, v in cfg.items() if k != 'args'}, f, default_flow_style=False)
-    elif tempcfg:
-        print('tempcfg mode enabled, will ignore existing config file')
-    else:
-        logger.info('Using config from config.yml that exists in %s.', logdir)
-        with open(config_path, 'r') as f:
-            cfg.update(yaml.safe_load(f))
+    """First run in `logdir`: store the effective config as config.yml.  Later runs: the stored file wins over the command
+    line (so a resumed job cannot silently change shape) unless --tempcfg says otherwise."""
     os.makedirs(os.path.join(logdir, 'train_logs'), exist_ok=True)
+    stored = os.path.join(logdir, 'config.yml')
+    if not os.path.exists(stored):
+        logger.info('Using config from config.py as no config.yml file exists in %s', logdir)
+        with open(stored, 'w') as f:
+            yaml.safe_dump(to_dict({k: v for k, v in cfg.items() if k != 'args'}), f, default_flow_style=False)
+        return
+    if tempcfg:
+        print('tempcfg mode enabled, will ignore existing config file')
+        return
+    logger.info('Using config from config.yml that exists in %s.', logdir)
+    with open(stored, 'r') as f:
+        cfg.update(yaml.safe_load(f))

@@ -36,7 +36,8 @@ def main():
     np_ = 196
     lib = _lib.load()
     ref = None
-    for S in (1, 2, 4, 1, 2):
+    offsets = [int(v) for v in os.environ.get('LANE_OFFSETS_US', '0').split(',')]
+    for S, off_us in [(1, 0)] + [(2, o) for o in offsets] + [(1, 0)] + [(2, o) for o in offsets]:
         fs = F // S
         streams = [torch.cuda.Stream() for _ in range(S)]
         nbytes = lib.mvf_vit_workspace_bytes(pk.code, fs, np_ + 1, 768, 16)
@@ -47,6 +48,9 @@ def main():
 
         def run():
             for s in range(S):
+                if s > 0 and off_us > 0:
+                    with torch.cuda.stream(streams[s]):
+                        torch.cuda._sleep(int(off_us * 1e-6 * 2.1e9) * s)
                 tab = (ctypes.c_void_p * 4)(*[t.data_ptr() + s * fs * np_ * 768 * 2 for t in taps])
                 _lib.call('mvf_vit_fwd', ctypes.byref(pk.struct), pk.code, x.data_ptr() + s * fs * 3 * 224 * 224 * 4, fs,
                           tab, cls.data_ptr() + s * fs * 768 * 4, wss[s].data_ptr(), wss[s].numel(), fs, 0,
@@ -63,7 +67,7 @@ def main():
         if ref is None:
             ref = [t.clone() for t in taps]
         same = all(torch.equal(a, b) for a, b in zip(ref, taps))
-        print('streams %d x %d frames: %.3f ms  (%.1f frames/s)  bitwise same as 1 stream: %s' % (S, fs, dt * 1e3, F / dt, same),
+        print('offset %4d us  streams %d x %d frames: %.3f ms  (%.1f frames/s)  bitwise same as 1 stream: %s' % (off_us, S, fs, dt * 1e3, F / dt, same),
               flush=True)
 
 

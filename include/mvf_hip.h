@@ -122,6 +122,9 @@ int mvf_colsum(const float* x, long ld, int rows, int cols, float* out, int accu
 
 /* dx = dy * [y > 0]  (ReLU backward of the FFN, models/utils.py:190) */
 int mvf_relu_bwd(const float* dy, const float* y, float* dx, size_t n, hipStream_t stream);
+/* exact-erf GELU (timm Mlp of a TRAINABLE ViT block): y = x Phi(x); dx = dy (Phi(x) + x phi(x)) */
+int mvf_gelu_fwd(const float* x, float* y, size_t n, hipStream_t stream);
+int mvf_gelu_bwd(const float* dy, const float* x, float* dx, size_t n, hipStream_t stream);
 
 /* y = resid + dropout_p(x) with a counter-based mask (nn.Dropout + residual add, models/utils.py:153-159;
  * mvformer.py:76; resid may be NULL); backward = same call on dy with resid = NULL */
@@ -175,6 +178,10 @@ int mvf_lstp_softmax_fwd(const float* scores, float* P, float* Pm, float* rowsum
 int mvf_lstp_softmax_bwd(const float* P, const float* Pm, const float* dP, const float* drow, float* dS, int F, int N,
                          int nq, float inv_sqrt_d, hipStream_t stream);
 int mvf_lstp_reduce_frames(const float* G, float* out, int Bc, int nq, int T, int C, hipStream_t stream);
+/* gradient of the pooling w.r.t. the tokens (partially frozen backbone):
+ * dx[t][f*N+n, :] = sum_j W[f,j,n] dpooled[b,j,t,:] + dS[f,j,n] vec[f|0,j,:]; dx_host: HOST array of n_taps fp32 [F*N, D] */
+int mvf_lstp_dx(float* const* dx_host, int n_taps, int D, int F, int N, int T, int nq, const float* w, const float* ds,
+                const float* dpooled, const float* vec, int per_frame, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sequence-contrastive loss (algos/scl.py:52-105), fused forward / backward

@@ -484,6 +484,79 @@ def test_lstp_pool_vs_plain_attention(dtype, nq, disjoint):
         check(pd['cross_att.linear_V2d.bias'].grad, pr['cross_att.linear_V2d.bias'].grad, 10 * tol, 'db_V')
 
 
+@pytest.mark.parametrize('nq,disjoint,per_frame', [(3, False, False), (2, True, False), (3, False, True)])
+def test_lstp_token_gradients(nq, disjoint, per_frame):
+    """d(loss)/d(tokens) of the pooling (needed once tapped backbone blocks are trainable: mvf_lstp_dx) against autograd
+    through the oracle's K/V-projection + attention."""
+    Bc, T, N, D, ntap, spc = 2, 4, 49, 64, 3, 24
+    Cc, F = D * ntap, Bc * T
+    d = C.Dims(C=Cc, n_taps=ntap, spc=spc, nst=nq, disjoint=disjoint)
+    p = {k[len('pooling.'):]: v for k, v in C.head_params(d, 33).items() if k.startswith('pooling.')}
+    feat = torch.randn(F, N, Cc, generator=gen(34))
+    fr = feat.double().requires_grad_(True)
+    pr = {k: v.double() for k, v in p.items()}
+    cfg = OH.HeadCfg(nst=nq, spc=spc, disjoint=disjoint, n_taps=ntap)
+    if per_frame:      # per-frame query vectors: emulate with a per-frame perturbation of the static queries
+        dq = torch.randn(F, nq, spc, generator=gen(35)).double() * 0.3
+    outs = []
+    for c in range(Bc):
+        if not per_frame:
+            outs.append(OH.lstp_cross_att(fr.view(Bc, T, N, Cc)[c], pr, 'cross_att.', cfg)[0])
+        else:
+            for t in range(T):
+                pp = dict(pr)
+                pp['cross_att.Q_s'] = pr['cross_att.Q_s'] + dq[c * T + t].unsqueeze(0)
+                outs.append(OH.lstp_cross_att(fr.view(Bc, T, N, Cc)[c, t:t + 1], pp, 'cross_att.', cfg)[0])
+    ref = torch.cat(outs, 0)
+    gy = torch.randn(F, nq, spc, generator=gen(36))
+    (ref * gy.double()).sum().backward()
+
+    taps = [feat[:, :, j * D:(j + 1) * D].reshape(F * N, D).contiguous().to(DEV).requires_grad_(True) for j in range(ntap)]
+    pd = {k: v.to(DEV) for k, v in p.items()}
+    q = (pd['cross_att.Q_s'] + pd['cross_att.Q_s_b'])[0]
+    if per_frame:
+        qf = q.unsqueeze(0) + dq.float().to(DEV)                                  # [F, nq, spc]
+        wq = (qf.reshape(F * nq, spc) @ pd['cross_att.linear_K2d.weight']).view(Bc, T, nq, Cc).permute(0, 2, 1, 3).contiguous()
+    else:
+        wq = ops.matmul(q, pd['cross_att.linear_K2d.weight'])
+    pooled, rowsum = ops.lstp_pool(wq, taps, F, N, T, nq, spc, disjoint=disjoint)
+    out = ops.linear(pooled, pd['cross_att.linear_V2d.weight'], None) + rowsum.unsqueeze(-1) * pd['cross_att.linear_V2d.bias']
+    got = out.permute(0, 2, 1, 3).reshape(F, nq, spc)
+    check(got, ref, 1e-4, 'lstp out')
+    (got * gy.to(DEV)).sum().backward()
+    gx = torch.cat([t.grad.view(F, N, D) for t in taps], 2)
+    check(gx, fr.grad, 2e-4, 'd tokens')
+
+
+def test_gelu_and_wide_layernorm_backward():
+    """Ops of a trainable ViT block that the frozen path never needed: exact-erf GELU forward/backward and LayerNorm backward
+    at ViT widths (768, 1024; the head's LayerNorms are 256 wide)."""
+    x = (torch.randn(37, 3072, generator=gen(40)) * 2.0)
+    xd = x.double().requires_grad_(True)
+    yr = torch.nn.functional.gelu(xd)
+    gy = torch.randn(x.shape, generator=gen(41))
+    (yr * gy.double()).sum().backward()
+    xg = _leaf(x)
+    y = ops.gelu(xg)
+    (y * gy.to(DEV)).sum().backward()
+    check(y, yr, 2e-6, 'gelu')
+    check(xg.grad, xd.grad, 2e-6, 'gelu grad')
+    for D in (768, 1024):
+        x = torch.randn(53, D, generator=gen(42)) * 1.7 + 0.3
+        g, b = torch.randn(D, generator=gen(43)) * 0.2 + 1.0, torch.randn(D, generator=gen(44)) * 0.1
+        xd, gd, bd = x.double().requires_grad_(True), g.double().requires_grad_(True), b.double().requires_grad_(True)
+        yr = torch.nn.functional.layer_norm(xd, (D,), gd, bd, 1e-6)
+        gy = torch.randn(53, D, generator=gen(45))
+        (yr * gy.double()).sum().backward()
+        xg, gg, bg = _leaf(x), _leaf(g), _leaf(b)
+        y = ops.layer_norm(xg, gg, bg, 1e-6)
+        (y * gy.to(DEV)).sum().backward()
+        check(y, yr, 1e-5, 'ln %d' % D)
+        check(xg.grad, xd.grad, 2e-5, 'ln dx %d' % D)
+        check(gg.grad, gd.grad, 2e-5, 'ln dg %d' % D)
+        check(bg.grad, bd.grad, 2e-5, 'ln db %d' % D)
+
+
 # ------------------------------------------------------------------------------------------------ SCL loss
 @pytest.mark.parametrize('name', sorted(G.SCL_CASES))
 def test_scl_vs_golden_and_oracle(golden, name):

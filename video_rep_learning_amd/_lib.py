@@ -34,6 +34,8 @@ SIGNATURES = {
     'mvf_hlinear_bwd': 'plplplplplpiiiip',
     'mvf_colsum': 'pliipip',
     'mvf_relu_bwd': 'pppzp',
+    'mvf_gelu_fwd': 'ppzp',
+    'mvf_gelu_bwd': 'pppzp',
     'mvf_dropout_add': 'pppzfuup',
     'mvf_ln_fwd': 'ppppppiifp',
     'mvf_ln_bwd': 'ppppppppiiiip',
@@ -55,6 +57,7 @@ SIGNATURES = {
     'mvf_lstp_softmax_fwd': 'ppppiiifip',
     'mvf_lstp_softmax_bwd': 'pppppiiifp',
     'mvf_lstp_reduce_frames': 'ppiiiip',
+    'mvf_lstp_dx': 'piiiiiippppip',
     'mvf_scl_fwd': 'pppppppppiiiiffp',
     'mvf_scl_bwd': 'pppppppppiiiiiiffp',
     'mvf_grad_norm': 'pzpppp',

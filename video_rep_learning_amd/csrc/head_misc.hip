@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // float atomics (rows/16 adders per address) into dg/db, which the caller zeroed or which already hold this step's
 // gradient (flat gradient buffer).  Replaces a dx kernel + a 4-workgroup column-reduction kernel (50 us at 768 rows).
 constexpr int LN_ROWS_PER_WAVE = 4;
+template <int NCMAX>   // columns per lane: D <= 64 * NCMAX (8: the head's widths, 24: ViT widths up to 1536)
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ g, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
@@ -41,10 +42,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      int accumulate) {
   extern __shared__ float red[];  // [4 waves][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nc = (D + 63) / 64;   // columns per lane (<= 8: D <= 512)
-  float pg[8], pb[8];
+  const int nc = (D + 63) / 64;   // columns per lane (<= NCMAX)
+  float pg[NCMAX], pb[NCMAX];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) { pg[q] = 0.f; pb[q] = 0.f; }
+  for (int q = 0; q < NCMAX; ++q) { pg[q] = 0.f; pb[q] = 0.f; }
   for (int rr = 0; rr < LN_ROWS_PER_WAVE; ++rr) {
     const int row = (blockIdx.x * 4 + wave) * LN_ROWS_PER_WAVE + rr;
     if (row >= rows) break;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     const float mu = mean[row], rs = rstd[row];
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < NCMAX; ++q) {
       const int c = lane + q * 64;
       if (q < nc && c < D) {
         const float d = dy[o + c], xh = (x[o + c] - mu) * rs;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     c1 = wave_sum(c1) / D;
     c2 = wave_sum(c2) / D;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < NCMAX; ++q) {
       const int c = lane + q * 64;
       if (q < nc && c < D) {
         const float v = rs * (dy[o + c] * g[c] - c1 - (x[o + c] - mu) * rs * c2);
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
   if (dg == nullptr) return;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
+  for (int q = 0; q < NCMAX; ++q) {
     const int c = lane + q * 64;
     if (q < nc && c < D) { red[(wave * 2 + 0) * D + c] = pg[q]; red[(wave * 2 + 1) * D + c] = pb[q]; }
   }
@@ -300,6 +301,22 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __res
     dx[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
 
+// exact-erf GELU of the trainable ViT blocks (timm Mlp act_layer = nn.GELU): y = x Phi(x), dx = dy (Phi(x) + x phi(x))
+__global__ void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    y[i] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  }
+}
+__global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+    dx[i] = dy[i] * (cdf + v * pdf);
+  }
+}
+
 // y = resid + dropout_p(x)  (nn.Dropout + residual add of ResidualConnection, models/utils.py:153-159; plain
 // nn.Dropout when resid == null).  Counter-based mask: keep(i) = hash(seed, offset + i) >= p * 2^32, so the
 // backward regenerates the identical mask from (seed, offset) and nothing is stored.
@@ -328,13 +345,18 @@ extern "C" int mvf_ln_fwd(const float* x, const float* g, const float* b, float*
 extern "C" int mvf_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, float* dx,
                           float* dg, float* db, int rows, int D, int accumulate_dx, int accumulate_params,
                           hipStream_t st) {
-  MVF_CHECK_ARG(dy && x && g && mean && rstd && dx && rows > 0 && D > 0 && D <= 512 && ((dg == nullptr) == (db == nullptr)));
+  MVF_CHECK_ARG(dy && x && g && mean && rstd && dx && rows > 0 && D > 0 && D <= 1536 && ((dg == nullptr) == (db == nullptr)));
   if (dg && !accumulate_params) {
     if (hipMemsetAsync(dg, 0, (size_t)D * 4, st) != hipSuccess || hipMemsetAsync(db, 0, (size_t)D * 4, st) != hipSuccess)
       return MVF_ERR_ARG;
   }
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(ceil_div(rows, 4 * LN_ROWS_PER_WAVE)), dim3(256), (size_t)8 * D * 4, st, dy, x, g,
-                     mean, rstd, dx, dg, db, rows, D, accumulate_dx);
+  const dim3 grid(ceil_div(rows, 4 * LN_ROWS_PER_WAVE));
+  if (D <= 512)
+    hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, dim3(256), (size_t)8 * D * 4, st, dy, x, g, mean, rstd, dx, dg, db, rows, D,
+                       accumulate_dx);
+  else   // ViT widths (trainable backbone blocks): 768 .. 1536
+    hipLaunchKernelGGL(ln_bwd_kernel<24>, grid, dim3(256), (size_t)8 * D * 4, st, dy, x, g, mean, rstd, dx, dg, db, rows, D,
+                       accumulate_dx);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }
@@ -437,6 +459,20 @@ extern "C" int mvf_l2norm_bwd(const float* dy, const float* y, const float* nrm,
 extern "C" int mvf_relu_bwd(const float* dy, const float* y, float* dx, size_t n, hipStream_t st) {
   MVF_CHECK_ARG(dy && y && dx && n > 0);
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, dy, y, dx, n);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_gelu_fwd(const float* x, float* y, size_t n, hipStream_t st) {
+  MVF_CHECK_ARG(x && y && n > 0);
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, y, n);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_gelu_bwd(const float* dy, const float* x, float* dx, size_t n, hipStream_t st) {
+  MVF_CHECK_ARG(dy && x && dx && n > 0);
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, dy, x, dx, n);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

@@ -320,6 +320,55 @@ extern "C" int mvf_lstp_softmax_bwd(const float* P, const float* Pm, const float
   return MVF_OK;
 }
 
+// ---- gradient w.r.t. the tokens (trainable backbone blocks only; the frozen path never needs it) ----------------
+//   dx[f,n,c] = sum_j ( W[f,j,n] * dpooled[b,j,t,c]  +  dS[f,j,n] * vec[f|0, j, c] )        (f = b*T + t)
+// W = the weights the forward summed with (P, or the masked Pm under SMART_DISJOINT), dS = d(raw scores) from
+// mvf_lstp_softmax_bwd.  One thread per (token, 4 channels): 2*nq small-vector FMAs, writes fp32 [F*N, D] per tap.
+struct DxArgs {
+  float* dx[MAXTAPS];
+  int n_taps, D, F, N, T, nq, per_frame;
+  const float* w; const float* ds; const float* dpooled; const float* vec;
+};
+
+__global__ __launch_bounds__(256) void lstp_dx_kernel(DxArgs a) {
+  const int C = a.n_taps * a.D;
+  const int c4n = C >> 2;
+  const int f = blockIdx.y;
+  const int b = f / a.T, t = f - b * a.T;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.N * c4n; i += gridDim.x * 256) {
+    const int n = i / c4n, c = (i - n * c4n) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < a.nq; ++j) {
+      const float wv = a.w[((size_t)f * a.nq + j) * a.N + n];
+      const float dv = a.ds[((size_t)f * a.nq + j) * a.N + n];
+      const float4 dp = *reinterpret_cast<const float4*>(a.dpooled + (((size_t)b * a.nq + j) * a.T + t) * C + c);
+      const float4 vq = *reinterpret_cast<const float4*>(
+          a.vec + (a.per_frame ? (((size_t)b * a.nq + j) * a.T + t) * C : (size_t)j * C) + c);
+      acc.x += wv * dp.x + dv * vq.x; acc.y += wv * dp.y + dv * vq.y;
+      acc.z += wv * dp.z + dv * vq.z; acc.w += wv * dp.w + dv * vq.w;
+    }
+    const int tap = c / a.D, cc = c - tap * a.D;
+    *reinterpret_cast<float4*>(a.dx[tap] + ((size_t)f * a.N + n) * a.D + cc) = acc;
+  }
+}
+
+extern "C" int mvf_lstp_dx(float* const* dx_host, int n_taps, int D, int F, int N, int T, int nq, const float* w,
+                           const float* ds, const float* dpooled, const float* vec, int per_frame, hipStream_t st) {
+  MVF_CHECK_ARG(dx_host && w && ds && dpooled && vec && n_taps > 0 && n_taps <= MAXTAPS && D > 0 && D % 4 == 0 && F > 0 &&
+                N > 0 && T > 0 && F % T == 0 && nq > 0 && nq <= MAXQ);
+  DxArgs a{};
+  for (int i = 0; i < n_taps; ++i) {
+    MVF_CHECK_ARG(dx_host[i] != nullptr && ((uintptr_t)dx_host[i] & 15) == 0);
+    a.dx[i] = dx_host[i];
+  }
+  a.n_taps = n_taps; a.D = D; a.F = F; a.N = N; a.T = T; a.nq = nq; a.per_frame = per_frame;
+  a.w = w; a.ds = ds; a.dpooled = dpooled; a.vec = vec;
+  const int work = N * (n_taps * D / 4);
+  hipLaunchKernelGGL(lstp_dx_kernel, dim3(std::min(ceil_div(work, 256), 64), F), dim3(256), 0, st, a);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
 extern "C" int mvf_lstp_reduce_frames(const float* G, float* out, int Bc, int nq, int T, int C, hipStream_t st) {
   MVF_CHECK_ARG(G && out && Bc > 0 && nq > 0 && T > 0 && C > 0);
   hipLaunchKernelGGL(lstp_reduce_frames_kernel, dim3(ceil_div(C, 64), nq), dim3(256), 0, st, G, out, Bc, nq, T, C);

@@ -216,6 +216,31 @@ def layer_norm(x, g, b, eps=1e-5):
 
 
 # ------------------------------------------------------------------------------------------------
+# exact-erf GELU (trainable ViT blocks)
+# ------------------------------------------------------------------------------------------------
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        call('mvf_gelu_fwd', ptr(x), ptr(y), x.numel(), stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        call('mvf_gelu_bwd', ptr(dy), ptr(x), ptr(dx), x.numel(), stream())
+        return dx
+
+
+def gelu(x):
+    return _Gelu.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------
 # BatchNorm1d (+ optional fused ReLU), with cross-rank statistics when `group_size > 1` (SyncBN)
 # ------------------------------------------------------------------------------------------------
 def _world(group):
@@ -512,7 +537,9 @@ class _LSTPPool(torch.autograd.Function):
     Returns (pooled [Bc, nq, T, C], rowsum [Bc, nq, T] = sum_n A -- identically 1 unless disjoint)."""
 
     @staticmethod
-    def forward(ctx, vec, taps, F, N, T, nq, inv_sqrt_d, disjoint, holder):
+    def forward(ctx, vec, taps, F, N, T, nq, inv_sqrt_d, disjoint, holder, *grad_taps):
+        # grad_taps: the same tensors again as differentiable inputs when the tapped blocks are trainable (fp32 taps)
+        ctx.want_dx = len(grad_taps) > 0 and any(t.requires_grad for t in grad_taps)
         dt = BF16 if taps[0].dtype == torch.bfloat16 else F32
         D = taps[0].shape[1]
         C = D * len(taps)
@@ -530,7 +557,7 @@ class _LSTPPool(torch.autograd.Function):
         pooled = torch.empty(F // T, nq, T, C, device=dev, dtype=torch.float32)
         call('mvf_lstp_wsum', tab, len(taps), dt, D, F, N, T, nq, ptr(Pm if disjoint else P), ptr(pooled), stream())
         ctx.taps = taps
-        ctx.save_for_backward(P, Pm)
+        ctx.save_for_backward(P, Pm, vec if ctx.want_dx else None)
         ctx.cfg = (F, N, T, nq, inv_sqrt_d, per_frame, dt, D, C)
         if holder is not None:
             holder['attn'] = Pm if disjoint else P      # [F, nq, N], like LSTPCrossAtt.attn_matrix
@@ -543,7 +570,7 @@ class _LSTPPool(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dpooled, drs):
-        P, Pm = ctx.saved_tensors
+        P, Pm, vec = ctx.saved_tensors
         F, N, T, nq, inv_sqrt_d, per_frame, dt, D, C = ctx.cfg
         taps = ctx.taps
         tab = _tap_table(taps)
@@ -563,12 +590,23 @@ class _LSTPPool(torch.autograd.Function):
         else:
             dvec = torch.empty(nq, C, device=dev, dtype=torch.float32)
             call('mvf_lstp_reduce_frames', ptr(G), ptr(dvec), F // T, nq, T, C, stream())
-        return dvec, None, None, None, None, None, None, None, None
+        dtaps = ()
+        if ctx.want_dx:
+            if dt != F32:
+                raise _lib.MvfError('token gradients need fp32 taps (trainable backbone blocks run in fp32)')
+            dtaps = tuple(torch.empty_like(t) for t in taps)
+            arr = (ctypes.c_void_p * len(taps))(*[t.data_ptr() for t in dtaps])
+            call('mvf_lstp_dx', arr, len(taps), D, F, N, T, nq, ptr(Pm if Pm is not None else P), ptr(dS), ptr(dpooled),
+                 ptr(vec), int(per_frame), stream())
+        return (dvec, None, None, None, None, None, None, None, None) + dtaps
 
 
 def lstp_pool(vec, taps, F, N, T, nq, d_model, disjoint=False, holder=None):
-    """-> (pooled [Bc, nq, T, C], rowsum [Bc, nq, T])."""
-    return _LSTPPool.apply(vec, tuple(taps), F, N, T, nq, 1.0 / math.sqrt(d_model), disjoint, holder)
+    """-> (pooled [Bc, nq, T, C], rowsum [Bc, nq, T]).  Taps that require grad (outputs of trainable backbone blocks) get
+    their gradient from mvf_lstp_dx."""
+    taps = tuple(taps)
+    grad_taps = taps if any(t.requires_grad for t in taps) else ()
+    return _LSTPPool.apply(vec, taps, F, N, T, nq, 1.0 / math.sqrt(d_model), disjoint, holder, *grad_taps)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -65,6 +65,12 @@ size_t mvf_vit_workspace_bytes(int dtype, int frames_per_chunk, int tokens, int 
  * CLS row dropped), cls_out [F, dim] fp32 (final LN, token 0; may be NULL).  frames_per_chunk <= 0: all. */
 int mvf_vit_fwd(const MvfVitWeights* w, int dtype, const float* frames, int F, void* const* taps_out, float* cls_out,
                 void* workspace, size_t ws_bytes, int frames_per_chunk, int attn_variant, hipStream_t stream);
+/* The same, also handing out the fp32 residual stream x_out [F*tokens, dim] (CLS row included) after the last of the
+ * w->depth blocks: the frozen FRONT END of a partially frozen backbone (ViTFrontEnd, models/transformer.py:342-361).
+ * depth may be 0 (patch + position embedding only); taps_out / cls_out may be NULL. */
+int mvf_vit_fwd_x(const MvfVitWeights* w, int dtype, const float* frames, int F, void* const* taps_out, float* cls_out,
+                  float* x_out, void* workspace, size_t ws_bytes, int frames_per_chunk, int attn_variant,
+                  hipStream_t stream);
 
 /* measurement hooks (bench.py roofline): when enabled, every GEMM launch of mvf_vit_fwd is bracketed by HIP events
  * on the launch stream; collect() waits for them and returns, per GEMM shape (epilogue kind, N, K) -- group g <

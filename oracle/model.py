@@ -27,9 +27,26 @@ def backbone_features(frames, params, vit_cfg):
     The reference chunks frames by FRAMES_PER_BATCH (transformer.py:180-214); per-frame
     independent, so one pass gives the same numbers."""
     w = sub(params, 'backbone.model.')
+    layer = vit_cfg.get('layer', None)
+    if layer is None:                      # fully frozen backbone (transformer.py:93-99)
+        with torch.no_grad():
+            feats, cls = ovit.vit_forward(frames, w, vit_cfg['heads'], vit_cfg['patch'], tuple(vit_cfg['taps']))
+        return feats[:, 1:], cls  # drop CLS (transformer.py:204)
+    # partially frozen (transformer.py:100-116): ViTFrontEnd = blocks [0, layer) under no_grad; ViTBackEnd = trainable deep
+    # copies of blocks [layer, depth) + norm, stored as res_finetune.model.blocks.<i - layer> / res_finetune.model.norm
     with torch.no_grad():
-        feats, cls = ovit.vit_forward(frames, w, vit_cfg['heads'], vit_cfg['patch'], tuple(vit_cfg['taps']))
-    return feats[:, 1:], cls  # drop CLS (transformer.py:204)
+        _, x = ovit.vit_forward(frames, w, vit_cfg['heads'], vit_cfg['patch'], taps=(), last_block=layer)
+    back = sub(params, 'res_finetune.model.')
+    wb = {}
+    for k, v in back.items():
+        if k.startswith('blocks.'):
+            _, j, rest = k.split('.', 2)
+            wb['blocks.%d.%s' % (int(j) + layer, rest)] = v
+        else:
+            wb[k] = v
+    feats, cls = ovit.vit_forward(None, wb, vit_cfg['heads'], vit_cfg['patch'], tuple(vit_cfg['taps']), first_block=layer,
+                                  x_in=x)
+    return feats[:, 1:], cls
 
 
 def model_forward(videos, params, vit_cfg, head_cfg, video_masks=None, project=False, l2_normalize=True,

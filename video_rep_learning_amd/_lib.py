@@ -18,6 +18,7 @@ _P, _I, _L, _Z, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size
 SIGNATURES = {
     'mvf_vit_workspace_bytes': 'iiiii',
     'mvf_vit_fwd': 'pipipppziip',
+    'mvf_vit_fwd_x': 'pipippppziip',
     'mvf_prof_enable': 'i',
     'mvf_prof_collect': 'ppppppip',
     'mvf_gemm_tc': 'iipipippipipippiiiip',

@@ -83,10 +83,19 @@ extern "C" size_t mvf_vit_workspace_bytes(int dtype, int frames_per_chunk, int t
 extern "C" int mvf_vit_fwd(const MvfVitWeights* w, int dtype, const float* frames, int F, void* const* taps_out,
                            float* cls_out, void* workspace, size_t ws_bytes, int frames_per_chunk, int attn_variant,
                            hipStream_t st) {
+  return mvf_vit_fwd_x(w, dtype, frames, F, taps_out, cls_out, nullptr, workspace, ws_bytes, frames_per_chunk, attn_variant, st);
+}
+
+// x_out != NULL: also hand out the fp32 residual stream [F*N, dim] (CLS row included) after the last of the w->depth
+// blocks -- the frozen FRONT END of a partially frozen backbone (ViTFrontEnd, models/transformer.py:342-361; depth may
+// then be 0 = patch embedding + position embedding only)
+extern "C" int mvf_vit_fwd_x(const MvfVitWeights* w, int dtype, const float* frames, int F, void* const* taps_out,
+                             float* cls_out, float* x_out, void* workspace, size_t ws_bytes, int frames_per_chunk,
+                             int attn_variant, hipStream_t st) {
   MVF_CHECK_ARG(w && frames && workspace && F > 0);
   MVF_CHECK_ARG(dtype == MVF_F32 || dtype == MVF_BF16);
   const int D = w->dim, H = w->heads, P = w->patch, img = w->img;
-  MVF_CHECK_ARG(D == H * 64 && img % P == 0 && w->depth > 0 && w->n_taps >= 0 && w->n_taps <= 8);
+  MVF_CHECK_ARG(D == H * 64 && img % P == 0 && (w->depth > 0 || (x_out && w->depth == 0)) && w->n_taps >= 0 && w->n_taps <= 8);
   const int np = (img / P) * (img / P);
   const int N = np + 1;
   const int fc_max = frames_per_chunk > 0 ? std::min(frames_per_chunk, F) : F;
@@ -127,6 +136,8 @@ extern "C" int mvf_vit_fwd(const MvfVitWeights* w, int dtype, const float* frame
       RUN(timed_gemm(dtype, EPI_RESID, ws.hid, 4 * D, w->fc2_w[l], 4 * D, w->fc2_b[l], nullptr, 0, ws.x, D, tap_ptr,
                            D, nullptr, w->ls2 ? w->ls2[l] : nullptr, N, Mc, D, 4 * D, st));
     }
+    if (x_out && hipMemcpyAsync(x_out + (size_t)f0 * N * D, ws.x, (size_t)Mc * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return MVF_ERR_ARG;
     if (cls_out)  // final LN on the CLS rows only (timm forward_head, global_pool='token')
       RUN(mvf_layernorm_impl(MVF_F32, ws.x, (size_t)N * D, w->norm_w, w->norm_b, cls_out + (size_t)f0 * D, D, fc, D,
                              w->ln_eps, st));

@@ -226,6 +226,8 @@ class MultiEntityTransformerEmbModel(nn.Module):
     def forward(self, x, video_masks=None, cls_emb=None):
         taps = x if isinstance(x, Taps) else Taps.from_nchw(x, len(str(_em(self.cfg, 'SMART_FEATS', '11')).split(',')))
         Bc, T = taps.n_clips, taps.n_frames
+        if self.in_backbone_warmup:      # mvformer.py:131-132: the spatial features (not cls_emb) are detached during the
+            taps = Taps([t.detach() for t in taps.tensors], taps.n_clips, taps.n_frames, taps.n_tokens)   # warm-up epochs
         x = self.pooling(taps, cls_emb)                                    # [Bc, ntok, T, c]
         ntok = x.shape[1]
         x = x.reshape(Bc * ntok * T, -1)

@@ -29,6 +29,8 @@ class FeatureExtractor(nn.Module):
         self.return_output = return_output
 
     def forward(self, x, dtype='bf16', frames_per_chunk=0):
+        if isinstance(self.model, vitlib.ViTBackEnd):        # x = the front end's residual stream [F, N, D]
+            return self.model(x, self.tap_ids)
         return self.model.forward_taps(x, self.tap_ids, dtype=dtype, frames_per_chunk=frames_per_chunk)
 
 
@@ -63,14 +65,23 @@ class TransformerModel(nn.Module):
             extract_ids = ['blocks.%s' % t for t in str(em.SMART_FEATS).split(',')]
             cfg.MODEL.BASE_MODEL.OUT_CHANNEL *= len(extract_ids)
         layer = cfg.MODEL.BASE_MODEL.LAYER
-        if not (layer < 0 or layer >= blk_count):
-            raise NotImplementedError('partially frozen ViT (MODEL.BASE_MODEL.LAYER=%d < %d blocks) needs backward '
-                                      'kernels for the ViT blocks: SURVEY.md section 8(f) row 3, not built yet'
-                                      % (layer, blk_count))
-        self.backbone = FeatureExtractor(model, extract_ids)
+        self.split_layer = None
+        if layer < 0 or layer >= blk_count:       # fully frozen (transformer.py:93-99)
+            self.backbone = FeatureExtractor(model, extract_ids)
+            self.res_finetune = nn.Identity()
+        else:                                     # frozen front end + trainable back end (transformer.py:100-116)
+            new_ids = []
+            for e_id in extract_ids:
+                b_idx = int(e_id.split('.')[-1]) - layer
+                if b_idx < 0:
+                    print('ERROR: cannot request extract of %s as it is not in ViTBackEnd wrapper' % e_id)
+                    exit(-1)
+                new_ids.append('blocks.%i' % b_idx)
+            self.split_layer = layer
+            self.backbone = vitlib.ViTFrontEnd(model, layer)
+            self.res_finetune = FeatureExtractor(vitlib.ViTBackEnd(model, layer), new_ids)
         for p in self.backbone.parameters():      # frozen: never in the optimizer, never all-reduced
             p.requires_grad_(False)
-        self.res_finetune = nn.Identity()
         self.embed = MultiEntityTransformerEmbModel(cfg)
         if ('FUSION_CLS' in em and em.FUSION_CLS) or ('CLS_GRAD_ONLY' in em and em.CLS_GRAD_ONLY):
             raise NotImplementedError('FUSION_CLS / CLS_GRAD_ONLY need a trainable backbone (not built yet)')
@@ -108,8 +119,9 @@ class TransformerModel(nn.Module):
             ready_event.record(cur)
         self._side.wait_event(ready_event)
         with torch.cuda.stream(self._side):
-            taps, cls = self.backbone(x.reshape(bc * t, c, h, w), dtype=self.compute_dtype,
-                                      frames_per_chunk=self.frames_per_chunk)
+            out = self.backbone(x.reshape(bc * t, c, h, w), dtype=self.compute_dtype, frames_per_chunk=self.frames_per_chunk)
+            # fully frozen: (taps, cls); partially frozen: the fp32 residual stream the trainable blocks start from
+            taps, cls = out if self.split_layer is None else ((out,), None)
             done = torch.cuda.Event()
             done.record(self._side)
         x.record_stream(self._side)
@@ -137,6 +149,8 @@ class TransformerModel(nn.Module):
         cur.wait_event(done)
         for tns in list(taps) + ([cls] if cls is not None else []):
             tns.record_stream(cur)
+        if self.split_layer is not None:          # trainable blocks: on the caller's stream, recorded by autograd
+            taps, cls = self.res_finetune(taps[0])
         ntok = (h // self.backbone.model.patch_size) * (w // self.backbone.model.patch_size)
         return Taps(taps, bc, t, ntok), cls
 

@@ -104,6 +104,78 @@ class VisionTransformer(nn.Module):
         """timm's default forward: final-norm CLS embedding [F, D]."""
         return self.forward_taps(x, (), dtype='fp32')[1]
 
+    @torch.no_grad()
+    def forward_front(self, x, nb, dtype='bf16', frames_per_chunk=0):
+        """x [F,3,H,W] -> fp32 residual stream [F, N, D] after the first nb (frozen) blocks."""
+        key = ('front', nb, str(dtype))
+        if key not in self._packed:
+            sd = {k: v for k, v in self.state_dict().items()}
+            self._packed[key] = ops.PackedViT(sd, nb, self.embed_dim, self.num_heads, self.patch_size, self.img_size, (),
+                                              dtype)
+        return ops.vit_front(x, self._packed[key], frames_per_chunk=frames_per_chunk)
+
+
+def block_forward(blk, x, heads):
+    """One TRAINABLE ViT block (timm Block.forward: x + ls1(attn(norm1(x))); x + ls2(mlp(norm2(x)))) on x [F, N, D] fp32,
+    composed of the head's fp32 HIP ops, every one with a HIP backward: LayerNorm, GEMM (+ bias, + residual in the epilogue),
+    flash-style attention on the fp32 matrix cores, exact-erf GELU.  This is the correctness-first form of SURVEY 8f row 3:
+    the frozen blocks keep the bf16 persistent GEMM path."""
+    if hasattr(blk, 'ls1'):
+        raise NotImplementedError('LayerScale (DINOv2) in a TRAINABLE backbone block is not built yet')
+    F, N, D = x.shape
+    x2 = x.reshape(F * N, D)
+    h = ops.layer_norm(x2, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+    qkv = ops.linear(h, blk.attn.qkv.weight, blk.attn.qkv.bias)
+    o = ops.temporal_attention(qkv, None, F, N, heads)                 # softmax(q k^T / sqrt(64)) v, no mask
+    x2 = ops.linear(o, blk.attn.proj.weight, blk.attn.proj.bias, resid=x2)
+    h = ops.layer_norm(x2, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+    h = ops.gelu(ops.linear(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
+    x2 = ops.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, resid=x2)
+    return x2.view(F, N, D)
+
+
+class ViTFrontEnd(nn.Module):
+    """Frozen blocks [0, nb) of the backbone (models/transformer.py:342-361).  `self.blocks` aliases the same modules as
+    `self.model.blocks[:nb]`, so the state dict carries both key sets like the reference's."""
+
+    def __init__(self, model, nb):
+        super().__init__()
+        self.model = model
+        self.nb = nb
+        self.blocks = nn.Sequential(*[model.blocks[i] for i in range(min(nb, len(model.blocks)))])
+
+    def forward(self, x, dtype='bf16', frames_per_chunk=0):
+        return self.model.forward_front(x, self.nb, dtype=dtype, frames_per_chunk=frames_per_chunk)
+
+
+class ViTBackEnd(nn.Module):
+    """Trainable deep copies of blocks [nb, depth) and of the final norm (models/transformer.py:364-392).  forward returns
+    (tapped block outputs with the CLS row dropped, final-norm CLS embedding) -- what FeatureExtractor(ViTBackEnd) yields in
+    the reference (hooks on `blocks.<i - nb>` + the pooled output; fc_norm / head_drop / head are identities for these
+    models)."""
+
+    def __init__(self, model, nb):
+        super().__init__()
+        from copy import deepcopy
+        self.global_pool = model.global_pool
+        self.num_prefix_tokens = model.num_prefix_tokens
+        self.num_heads = model.num_heads
+        self.blocks = nn.Sequential(*[deepcopy(model.blocks[i]) for i in range(nb, len(model.blocks))])
+        self.norm = deepcopy(model.norm)
+        self.fc_norm, self.head_drop, self.head = nn.Identity(), nn.Identity(), nn.Identity()
+        for p in self.parameters():
+            p.requires_grad_(True)
+
+    def forward(self, x, tap_ids):
+        F, N, D = x.shape
+        taps = {}
+        for i, blk in enumerate(self.blocks):
+            x = block_forward(blk, x, self.num_heads)
+            if i in tap_ids:
+                taps[i] = x[:, self.num_prefix_tokens:].reshape(F * (N - self.num_prefix_tokens), D)
+        cls = ops.layer_norm(x[:, 0], self.norm.weight, self.norm.bias, self.norm.eps)
+        return [taps[i] for i in tap_ids], cls
+
 
 def create_model(name, pretrained=False, weights=None, img_size=224, seed=None):
     """Stand-in for timm.create_model for the names the reference accepts."""

@@ -818,6 +818,22 @@ def augment_clips(clips, params, size):
     return out
 
 
+def vit_front(frames, packed, frames_per_chunk=0):
+    """frames [F,3,H,W] fp32 -> fp32 residual stream [F, N, dim] (CLS row included) after the packed.depth frozen blocks:
+    the front end of a partially frozen backbone (mvf_vit_fwd_x; depth 0 = patch + position embedding only)."""
+    if not frames.is_cuda:
+        raise _lib.MvfError('vit_front received a %s tensor (no CPU fallback)' % frames.device)
+    frames = frames.contiguous().float()
+    F = frames.shape[0]
+    n = (packed.img // packed.patch) ** 2 + 1
+    fc = F if frames_per_chunk <= 0 else min(frames_per_chunk, F)
+    ws = packed.workspace(fc, frames.device)
+    x = torch.empty(F, n, packed.dim, device=frames.device, dtype=torch.float32)
+    call('mvf_vit_fwd_x', ctypes.byref(packed.struct), packed.code, ptr(frames), F, None, None, ptr(x), ptr(ws), ws.numel(),
+         fc, 0, stream())
+    return x
+
+
 # ------------------------------------------------------------------------------------------------
 # optimiser
 # ------------------------------------------------------------------------------------------------

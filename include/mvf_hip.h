@@ -129,6 +129,9 @@ int mvf_colsum(const float* x, long ld, int rows, int cols, float* out, int accu
 /* dx = dy * [y > 0]  (ReLU backward of the FFN, models/utils.py:190) */
 int mvf_relu_bwd(const float* dy, const float* y, float* dx, size_t n, hipStream_t stream);
 /* exact-erf GELU (timm Mlp of a TRAINABLE ViT block): y = x Phi(x); dx = dy (Phi(x) + x phi(x)) */
+/* LayerScale of a trainable DINOv2 block: mode 0 out = resid + y * gamma[col]; 1 out = y * gamma[col]; 2 out = y * resid */
+int mvf_colscale(const float* y, const float* gamma, const float* resid, float* out, int rows, int D, int mode,
+                 hipStream_t stream);
 int mvf_gelu_fwd(const float* x, float* y, size_t n, hipStream_t stream);
 int mvf_gelu_bwd(const float* dy, const float* x, float* dx, size_t n, hipStream_t stream);
 

@@ -89,7 +89,7 @@ SMALL = dict(network='TIMM-vit_small_patch16_224.dino', num_frames=8, batch_size
 
 # fg99 / long64 / dinov2: the head and sequence shapes of BASELINE configs[2], [3] and [4] at a small image size
 @pytest.mark.parametrize('variant', ['base', 'avg_enc_nst6', 'max_none', 'lin', 'dynamic', 'disjoint', 'batch_neg', 'fg99',
-                                     'long64', 'dinov2', 'fwb', 'partial'])
+                                     'long64', 'dinov2', 'fwb', 'partial', 'partial_dinov2'])
 def test_small_model_loss_and_grads(variant):
     kw = dict(SMALL)
     if variant == 'avg_enc_nst6':
@@ -112,6 +112,8 @@ def test_small_model_loss_and_grads(variant):
         kw.update(network='TIMM-vit_small_patch14_dinov2.lvd142m', image_size=28)
     if variant == 'partial':     # blocks 10, 11 + final norm trainable; taps must lie in the back end
         kw.update(SMART_FEATS='10,11', LAYER=10)
+    elif variant == 'partial_dinov2':   # the same with LayerScale blocks and a patch-14 front end
+        kw.update(network='TIMM-vit_small_patch14_dinov2.lvd142m', image_size=28, SMART_FEATS='9,11', LAYER=9)
     layer = kw.pop('LAYER', None)
     cfg, model = make(3, layer=layer, **kw)
     if variant == 'batch_neg':

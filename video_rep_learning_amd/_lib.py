@@ -35,6 +35,7 @@ SIGNATURES = {
     'mvf_hlinear_bwd': 'plplplplplpiiiip',
     'mvf_colsum': 'pliipip',
     'mvf_relu_bwd': 'pppzp',
+    'mvf_colscale': 'ppppiiip',
     'mvf_gelu_fwd': 'ppzp',
     'mvf_gelu_bwd': 'pppzp',
     'mvf_dropout_add': 'pppzfuup',

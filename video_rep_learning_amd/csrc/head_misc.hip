@@ -317,6 +317,20 @@ __global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __res
   }
 }
 
+// LayerScale of a trainable DINOv2 block (timm LayerScale: x * gamma) fused with the residual add:
+//   mode 0: out = resid + y * gamma[c]      mode 1: out = y * gamma[c] (dy of the backward)     mode 2: out = y * resid
+//   (mode 2 = the elementwise product whose column sums are dgamma)
+__global__ void colscale_kernel(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ resid,
+                                float* __restrict__ out, size_t n, int D, int mode) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    if (mode == 2) out[i] = y[i] * resid[i];
+    else {
+      const float v = y[i] * gamma[i % D];
+      out[i] = mode == 0 ? resid[i] + v : v;
+    }
+  }
+}
+
 // y = resid + dropout_p(x)  (nn.Dropout + residual add of ResidualConnection, models/utils.py:153-159; plain
 // nn.Dropout when resid == null).  Counter-based mask: keep(i) = hash(seed, offset + i) >= p * 2^32, so the
 // backward regenerates the identical mask from (seed, offset) and nothing is stored.
@@ -459,6 +473,15 @@ extern "C" int mvf_l2norm_bwd(const float* dy, const float* y, const float* nrm,
 extern "C" int mvf_relu_bwd(const float* dy, const float* y, float* dx, size_t n, hipStream_t st) {
   MVF_CHECK_ARG(dy && y && dx && n > 0);
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, dy, y, dx, n);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_colscale(const float* y, const float* gamma, const float* resid, float* out, int rows, int D, int mode,
+                            hipStream_t st) {
+  MVF_CHECK_ARG(y && out && rows > 0 && D > 0 && mode >= 0 && mode <= 2 && (mode == 2 || gamma) && (mode == 1 || resid));
+  const size_t n = (size_t)rows * D;
+  hipLaunchKernelGGL(colscale_kernel, dim3(ew_grid(n)), dim3(256), 0, st, y, gamma, resid, out, n, D, mode);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

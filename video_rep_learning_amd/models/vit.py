@@ -120,17 +120,22 @@ def block_forward(blk, x, heads):
     composed of the head's fp32 HIP ops, every one with a HIP backward: LayerNorm, GEMM (+ bias, + residual in the epilogue),
     flash-style attention on the fp32 matrix cores, exact-erf GELU.  This is the correctness-first form of SURVEY 8f row 3:
     the frozen blocks keep the bf16 persistent GEMM path."""
-    if hasattr(blk, 'ls1'):
-        raise NotImplementedError('LayerScale (DINOv2) in a TRAINABLE backbone block is not built yet')
+    ls = hasattr(blk, 'ls1')          # DINOv2: x + gamma * f(x) instead of the residual fused into the GEMM epilogue
     F, N, D = x.shape
     x2 = x.reshape(F * N, D)
     h = ops.layer_norm(x2, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
     qkv = ops.linear(h, blk.attn.qkv.weight, blk.attn.qkv.bias)
     o = ops.temporal_attention(qkv, None, F, N, heads)                 # softmax(q k^T / sqrt(64)) v, no mask
-    x2 = ops.linear(o, blk.attn.proj.weight, blk.attn.proj.bias, resid=x2)
+    if ls:
+        x2 = ops.layerscale_add(ops.linear(o, blk.attn.proj.weight, blk.attn.proj.bias), blk.ls1.gamma, x2)
+    else:
+        x2 = ops.linear(o, blk.attn.proj.weight, blk.attn.proj.bias, resid=x2)
     h = ops.layer_norm(x2, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
     h = ops.gelu(ops.linear(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
-    x2 = ops.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, resid=x2)
+    if ls:
+        x2 = ops.layerscale_add(ops.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias), blk.ls2.gamma, x2)
+    else:
+        x2 = ops.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, resid=x2)
     return x2.view(F, N, D)
 
 

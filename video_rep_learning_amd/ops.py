@@ -240,6 +240,36 @@ def gelu(x):
     return _Gelu.apply(x)
 
 
+class _LayerScaleAdd(torch.autograd.Function):
+    """resid + y * gamma (timm LayerScale + the block's residual add), rows x D fp32."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, resid):
+        y, resid = y.contiguous(), resid.contiguous()
+        R, D = y.shape
+        out = torch.empty_like(y)
+        call('mvf_colscale', ptr(y), ptr(gamma), ptr(resid), ptr(out), R, D, 0, stream())
+        ctx.save_for_backward(y, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, gamma = ctx.saved_tensors
+        dout = dout.contiguous()
+        R, D = y.shape
+        dy = torch.empty_like(y)
+        call('mvf_colscale', ptr(dout), ptr(gamma), None, ptr(dy), R, D, 1, stream())
+        prod = torch.empty_like(y)
+        call('mvf_colscale', ptr(dout), None, ptr(y), ptr(prod), R, D, 2, stream())
+        dgamma = torch.empty_like(gamma)
+        call('mvf_colsum', ptr(prod), D, R, D, ptr(dgamma), 0, stream())
+        return dy, dgamma, dout
+
+
+def layerscale_add(y, gamma, resid):
+    return _LayerScaleAdd.apply(y, gamma, resid)
+
+
 # ------------------------------------------------------------------------------------------------
 # BatchNorm1d (+ optional fused ReLU), with cross-rank statistics when `group_size > 1` (SyncBN)
 # ------------------------------------------------------------------------------------------------

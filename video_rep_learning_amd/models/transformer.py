@@ -83,8 +83,18 @@ class TransformerModel(nn.Module):
         for p in self.backbone.parameters():      # frozen: never in the optimizer, never all-reduced
             p.requires_grad_(False)
         self.embed = MultiEntityTransformerEmbModel(cfg)
-        if ('FUSION_CLS' in em and em.FUSION_CLS) or ('CLS_GRAD_ONLY' in em and em.CLS_GRAD_ONLY):
-            raise NotImplementedError('FUSION_CLS / CLS_GRAD_ONLY need a trainable backbone (not built yet)')
+        # FUSION_CLS / CLS_GRAD_ONLY: validated and announced by the reference's constructor (transformer.py:144-163) and
+        # read nowhere else -- kept as the same two flags
+        self.fuse_cls = bool('FUSION_CLS' in em and em.FUSION_CLS is True)
+        if self.fuse_cls:
+            print('FUSION_CLS enabled, cls token will be included with spatial tokens')
+        self.cls_grad_only = bool('CLS_GRAD_ONLY' in em and em.CLS_GRAD_ONLY is True)
+        if self.cls_grad_only:
+            if not self.fuse_cls:
+                print('WARNING: Invalid config')
+                print('CLS_GRAD_ONLY can only be used with FUSION_CLS enabled')
+                exit(-1)
+            print('CLS_GRAD_ONLY enabled, gradients will only pass to the backbone through the CLS token')
         self.embedding_size = self.embed.embedding_size
         if cfg.MODEL.PROJECTION:
             self.ssl_projection = MLPHead(cfg)

@@ -187,6 +187,10 @@ int mvf_lstp_softmax_fwd(const float* scores, float* P, float* Pm, float* rowsum
 int mvf_lstp_softmax_bwd(const float* P, const float* Pm, const float* dP, const float* drow, float* dS, int F, int N,
                          int nq, float inv_sqrt_d, hipStream_t stream);
 int mvf_lstp_reduce_frames(const float* G, float* out, int Bc, int nq, int T, int C, hipStream_t stream);
+/* late fusion (TransformerEmbModel, models/transformer.py:258-262,287): out[f, :] = max (mode 0) | mean (mode 1) over the N
+ * tokens of frame f, taps concatenated along the channels; forward only (frozen backbone) */
+int mvf_token_pool(const void* const* taps_host, int n_taps, int dtype, int D, int F, int N, int mode, float* out,
+                   hipStream_t stream);
 /* gradient of the pooling w.r.t. the tokens (partially frozen backbone):
  * dx[t][f*N+n, :] = sum_j W[f,j,n] dpooled[b,j,t,:] + dS[f,j,n] vec[f|0,j,:]; dx_host: HOST array of n_taps fp32 [F*N, D] */
 int mvf_lstp_dx(float* const* dx_host, int n_taps, int D, int F, int N, int T, int nq, const float* w, const float* ds,

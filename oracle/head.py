@@ -276,6 +276,26 @@ def mvf_head(feat, masks, p, cfg, training=False, cls_emb=None, update_running=F
     return x
 
 
+def late_head(feat, masks, p, cfg, flatten='max_pool', training=False, update_running=False):
+    """TransformerEmbModel.forward (late fusion, models/transformer.py:283-300).
+    feat [Bc, T, N, C] tokens (N = h*w; N = 1 for LATE_TYPE 'cls'); AdaptiveMax/AvgPool2d(1) over the tokens, then the
+    FC/BN/ReLU stack, video_emb, positional encoding, encoder, embedding_layer -- the MV-Former head with one entity and
+    no learned pooling."""
+    bc, t, n, c = feat.shape
+    x = feat.max(dim=2)[0] if flatten == 'max_pool' else feat.mean(dim=2)
+    x = x.reshape(bc * t, c)
+    i = 0
+    while 'fc_layers.%d.weight' % (4 * i + 1) in p:
+        x = linear(x, p, 'fc_layers.%d' % (4 * i + 1))
+        x = relu(batch_norm1d(x, p, 'fc_layers.%d' % (4 * i + 2), training, cfg.bn_eps, cfg.bn_momentum, update_running))
+        i += 1
+    x = linear(x, p, 'video_emb').view(bc, t, -1)
+    x = positional_encode(x, cfg.train_len)
+    if cfg.num_layers > 0:
+        x = encoder(x, masks, p, 'video_encoder.', cfg.num_layers, cfg.num_heads, cfg.ln_eps)
+    return linear(x.reshape(bc * t, -1), p, 'embedding_layer').view(bc, t, -1)
+
+
 def mlp_head(x, p, pre='net.', training=False, update_running=False, eps=1e-5, momentum=0.1):
     """MLPHead.forward (resnet_c2d.py:112-126): Linear -> BN1d -> ReLU -> Linear on [B*T, E]."""
     b, l, c = x.shape

@@ -31,7 +31,7 @@ def backbone_features(frames, params, vit_cfg):
     if layer is None:                      # fully frozen backbone (transformer.py:93-99)
         with torch.no_grad():
             feats, cls = ovit.vit_forward(frames, w, vit_cfg['heads'], vit_cfg['patch'], tuple(vit_cfg['taps']))
-        return feats[:, 1:], cls  # drop CLS (transformer.py:204)
+        return (feats[:, 1:] if feats is not None else None), cls  # drop CLS (transformer.py:204)
     # partially frozen (transformer.py:100-116): ViTFrontEnd = blocks [0, layer) under no_grad; ViTBackEnd = trainable deep
     # copies of blocks [layer, depth) + norm, stored as res_finetune.model.blocks.<i - layer> / res_finetune.model.norm
     with torch.no_grad():
@@ -46,7 +46,7 @@ def backbone_features(frames, params, vit_cfg):
             wb[k] = v
     feats, cls = ovit.vit_forward(None, wb, vit_cfg['heads'], vit_cfg['patch'], tuple(vit_cfg['taps']), first_block=layer,
                                   x_in=x)
-    return feats[:, 1:], cls
+    return (feats[:, 1:] if feats is not None else None), cls
 
 
 def model_forward(videos, params, vit_cfg, head_cfg, video_masks=None, project=False, l2_normalize=True,
@@ -54,9 +54,15 @@ def model_forward(videos, params, vit_cfg, head_cfg, video_masks=None, project=F
     """TransformerModel.forward: videos [Bc,T,3,H,W] -> [Bc,T,E]."""
     bc, t = videos.shape[:2]
     feat, cls = backbone_features(videos.reshape(bc * t, *videos.shape[2:]), params, vit_cfg)
-    feat = feat.reshape(bc, t, *feat.shape[1:])
-    x = ohead.mvf_head(feat, video_masks, sub(params, 'embed.'), head_cfg, training=training,
-                       cls_emb=cls, update_running=update_running)
+    feat = feat.reshape(bc, t, *feat.shape[1:]) if feat is not None else None
+    late = vit_cfg.get('late', None)        # None: 'smart' fusion; ('cls' | 'spatial', FLATTEN_METHOD): late fusion
+    if late is None:
+        x = ohead.mvf_head(feat, video_masks, sub(params, 'embed.'), head_cfg, training=training,
+                           cls_emb=cls, update_running=update_running)
+    else:
+        f_in = cls.reshape(bc, t, 1, -1) if late[0] == 'cls' else feat      # transformer.py:192-196 / :197-207
+        x = ohead.late_head(f_in, video_masks, sub(params, 'embed.'), head_cfg, flatten=late[1], training=training,
+                            update_running=update_running)
     if projection and project:                                         # transformer.py:226-228
         x = ohead.mlp_head(x, sub(params, 'ssl_projection.'), 'net.', training, update_running)
         x = ohead.l2_normalize(x)

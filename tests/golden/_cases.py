@@ -170,3 +170,32 @@ def aug_clip(t, h, w, seed):
     """A clip as the dataset hands it over (penn_action.py:110-111): uint8 frames / 255 -> [T, 3, H, W] in [0, 1]."""
     g = torch.Generator().manual_seed(seed)
     return torch.randint(0, 256, (t, 3, h, w), generator=g).float() / 255.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# late fusion (TransformerEmbModel, models/transformer.py:248-300)
+# ---------------------------------------------------------------------------------------------------------------------
+LATE = dict(C=96, fc=(32, 32), hidden=32, dff=64, heads=4, layers=2, E=16, train_len=8)
+# name -> (FLATTEN_METHOD, Bc, T, h = w, padded frames of the last clip, training, seed)
+LATE_CASES = {
+    'late_max_train': ('max_pool', 3, 8, 4, 3, True, 3001),
+    'late_avg_eval':  ('avg_pool', 2, 8, 4, 0, False, 3002),
+    'late_cls_train': ('max_pool', 2, 8, 1, 2, True, 3003),       # LATE_TYPE 'cls': a 1 x 1 "feature map"
+    'late_interp_pe': ('avg_pool', 2, 12, 2, 0, False, 3004),     # S != TRAIN.NUM_FRAMES
+}
+
+
+def late_params(seed):
+    """State dict of the reference's TransformerEmbModel at LATE: the MV-Former head's names without `pooling.*`, first
+    FC layer fed by all C channels."""
+    d = Dims(one_hot='none', val_pass=True, nst=1, n_taps=1, **LATE)
+    return {k: v for k, v in head_params(d, seed).items() if not k.startswith('pooling.')}
+
+
+def late_inputs(bc, t, hw, seed, pad=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(bc, t, LATE['C'], hw, hw, generator=g)
+    masks = torch.ones(bc, 1, t)
+    if pad:
+        masks[-1, 0, t - pad:] = 0
+    return x, masks

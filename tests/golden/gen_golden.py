@@ -408,6 +408,34 @@ def gen_trajectory(mv, rc, scl_mod):
     print('trajectory', losses)
 
 
+def gen_late(tr):
+    """TransformerEmbModel (late fusion, models/transformer.py:248-300) forward + parameter gradients."""
+    out = {}
+    for name, (flat, bc, t, hw, pad, training, seed) in C.LATE_CASES.items():
+        L = C.LATE
+        em = dict(FC_DROPOUT_RATE=0.0, CAPACITY_SCALAR=1, FC_LAYERS=[[w, True] for w in L['fc']], EMBEDDING_SIZE=L['E'],
+                  HIDDEN_SIZE=L['hidden'], NUM_LAYERS=L['layers'], NUM_HEADS=L['heads'], D_FF=L['dff'], FLATTEN_METHOD=flat)
+        cfg = ad(dict(MODEL=dict(EMBEDDER_MODEL=em, BASE_MODEL=dict(OUT_CHANNEL=L['C'])), TRAIN=dict(NUM_FRAMES=L['train_len'])))
+        mod = tr.TransformerEmbModel(cfg)
+        mod.load_state_dict(C.late_params(seed), strict=True)
+        mod.train(training)
+        x, masks = C.late_inputs(bc, t, hw, seed + 500, pad)
+        emb = mod(x, video_masks=masks)
+        rec = {'emb': emb.detach().numpy()}
+        gout = torch.randn(emb.shape, generator=torch.Generator().manual_seed(seed + 900))
+        (emb * gout).sum().backward()
+        for k, p_ in mod.named_parameters():
+            rec['grad.' + k] = (p_.grad if p_.grad is not None else torch.zeros_like(p_)).numpy()
+        if training:
+            for k, b_ in mod.named_buffers():
+                if 'running' in k:
+                    rec['buf.' + k] = b_.numpy()
+        for k, v in rec.items():
+            out['%s/%s' % (name, k)] = v
+        print('late', name, tuple(emb.shape), float(emb.abs().mean()))
+    np.savez_compressed(os.path.join(HERE, 'late.npz'), **out)
+
+
 def gen_state_keys(mv, rc):
     """Checkpoint layout of BASELINE config #2 (models/__init__.py:17-27): the reference's state-dict keys and shapes for
     `embed.*` / `ssl_projection.*`, and the parameter order of its two optimizer groups (utils/optimizer.py:26-42:
@@ -486,11 +514,13 @@ def main():
     spec = importlib.util.spec_from_file_location('ref_scl', os.path.join(REF, 'algos', 'scl.py'))
     scl_mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(scl_mod)
-    which = sys.argv[1:] or ['primitives', 'head', 'mlp', 'scl', 'glue', 'traj', 'keys', 'augment', 'fwb']
+    which = sys.argv[1:] or ['primitives', 'head', 'mlp', 'scl', 'glue', 'traj', 'keys', 'augment', 'fwb', 'late']
     if 'primitives' in which:
         gen_primitives(mu)
     if 'head' in which:
         gen_head(mv)
+    if 'late' in which:
+        gen_late(tr)
     if 'fwb' in which:
         gen_head(mv, HEAD_CASES_FWB, 'head_fwb.npz')
     if 'mlp' in which:

@@ -31,7 +31,15 @@ def oracle_cfgs(cfg):
     name = cfg.MODEL.BASE_MODEL.NETWORK[5:]
     dim, depth, heads, patch, _ = VIT_ZOO[name]
     taps = tuple(int(t) for t in str(em.SMART_FEATS).split(','))
+    fusion = em.get('FUSION_TYPE', 'late')
+    late = None
+    if fusion == 'late':
+        late = (em.get('LATE_TYPE', 'cls'), em.FLATTEN_METHOD)
+        if late[0] == 'cls':
+            taps = ()
     vit_cfg = dict(heads=heads, patch=patch, taps=taps)
+    if late is not None:
+        vit_cfg['late'] = late
     layer = cfg.MODEL.BASE_MODEL.LAYER
     if 0 <= layer < depth:             # partially frozen backbone
         vit_cfg['layer'] = layer
@@ -89,7 +97,8 @@ SMALL = dict(network='TIMM-vit_small_patch16_224.dino', num_frames=8, batch_size
 
 # fg99 / long64 / dinov2: the head and sequence shapes of BASELINE configs[2], [3] and [4] at a small image size
 @pytest.mark.parametrize('variant', ['base', 'avg_enc_nst6', 'max_none', 'lin', 'dynamic', 'disjoint', 'batch_neg', 'fg99',
-                                     'long64', 'dinov2', 'fwb', 'partial', 'partial_dinov2'])
+                                     'long64', 'dinov2', 'fwb', 'partial', 'partial_dinov2', 'late_cls',
+                                     'late_spatial_max', 'late_spatial_avg', 'late_cls_partial'])
 def test_small_model_loss_and_grads(variant):
     kw = dict(SMALL)
     if variant == 'avg_enc_nst6':
@@ -112,6 +121,14 @@ def test_small_model_loss_and_grads(variant):
         kw.update(network='TIMM-vit_small_patch14_dinov2.lvd142m', image_size=28)
     if variant == 'partial':     # blocks 10, 11 + final norm trainable; taps must lie in the back end
         kw.update(SMART_FEATS='10,11', LAYER=10)
+    elif variant == 'late_cls':             # late fusion (TransformerEmbModel) on the CLS embedding
+        kw.update(FUSION_TYPE='late')
+    elif variant == 'late_spatial_max':
+        kw.update(FUSION_TYPE='late', LATE_TYPE='spatial', FLATTEN_METHOD='max_pool', SMART_FEATS='7,11')
+    elif variant == 'late_spatial_avg':
+        kw.update(FUSION_TYPE='late', LATE_TYPE='spatial', FLATTEN_METHOD='avg_pool', SMART_FEATS='11')
+    elif variant == 'late_cls_partial':     # ... with the last two blocks trainable (gradient through the CLS embedding)
+        kw.update(FUSION_TYPE='late', LAYER=10)
     elif variant == 'partial_dinov2':   # the same with LayerScale blocks and a patch-14 front end
         kw.update(network='TIMM-vit_small_patch14_dinov2.lvd142m', image_size=28, SMART_FEATS='9,11', LAYER=9)
     layer = kw.pop('LAYER', None)

@@ -100,6 +100,29 @@ def test_head_forward_backward(golden, name):
                 close(params[k], gh[key], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize('name', sorted(C.LATE_CASES))
+def test_late_fusion_head(golden, name):
+    """oracle late_head vs the imported TransformerEmbModel (tests/golden/late.npz)."""
+    gl = golden('late')
+    flat, bc, t, hw, pad, training, seed = C.LATE_CASES[name]
+    params = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and 'running' not in k else v.clone())
+              for k, v in C.late_params(seed).items()}
+    x, masks = C.late_inputs(bc, t, hw, seed + 500, pad)
+    feat = x.reshape(bc, t, C.LATE['C'], hw * hw).transpose(2, 3)
+    cfg = OH.HeadCfg(num_heads=C.LATE['heads'], num_layers=C.LATE['layers'], train_len=C.LATE['train_len'])
+    emb = OH.late_head(feat, masks, params, cfg, flatten=flat, training=training, update_running=training)
+    close(emb, gl[name + '/emb'], rtol=2e-4, atol=2e-5)
+    gout = torch.randn(emb.shape, generator=torch.Generator().manual_seed(seed + 900))
+    (emb * gout).sum().backward()
+    for k, p in params.items():
+        key = '%s/grad.%s' % (name, k)
+        if key in gl.files:
+            close(p.grad if p.grad is not None else torch.zeros_like(p), gl[key], rtol=1e-3, atol=1e-5)
+        key = '%s/buf.%s' % (name, k)
+        if training and key in gl.files:
+            close(params[k], gl[key], rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize('training', [True, False])
 def test_mlp_head(golden, training):
     gm = golden('mlp_head')

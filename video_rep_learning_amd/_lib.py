@@ -59,6 +59,7 @@ SIGNATURES = {
     'mvf_lstp_softmax_fwd': 'ppppiiifip',
     'mvf_lstp_softmax_bwd': 'pppppiiifp',
     'mvf_lstp_reduce_frames': 'ppiiiip',
+    'mvf_token_pool': 'piiiiiipp',
     'mvf_lstp_dx': 'piiiiiippppip',
     'mvf_scl_fwd': 'pppppppppiiiiffp',
     'mvf_scl_bwd': 'pppppppppiiiiiiffp',

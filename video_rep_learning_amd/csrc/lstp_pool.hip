@@ -320,6 +320,24 @@ extern "C" int mvf_lstp_softmax_bwd(const float* P, const float* Pm, const float
   return MVF_OK;
 }
 
+// ---- late fusion: AdaptiveMaxPool2d(1) / AdaptiveAvgPool2d(1) over a frame's tokens (models/transformer.py:258-262) ----
+// out[f, tap*D + c] = max_n | mean_n x[tap][f*N+n, c]; grid (F, n_taps), a thread owns channels, tokens in sequence
+template <typename T>
+__global__ __launch_bounds__(256) void token_pool_kernel(PoolArgs a, int mode) {
+  const int f = blockIdx.x, tap = blockIdx.y;
+  const T* x = reinterpret_cast<const T*>(a.taps[tap]) + (size_t)f * a.N * a.D;
+  for (int c = threadIdx.x; c < a.D; c += 256) {
+    float acc = mode == 0 ? -3.402823466e38f : 0.0f;
+    for (int n = 0; n < a.N; ++n) {
+      float v;
+      if constexpr (sizeof(T) == 2) v = __uint_as_float((uint32_t)x[(size_t)n * a.D + c] << 16);
+      else v = x[(size_t)n * a.D + c];
+      acc = mode == 0 ? fmaxf(acc, v) : acc + v;
+    }
+    a.out[(size_t)f * a.n_taps * a.D + tap * a.D + c] = mode == 0 ? acc : acc / (float)a.N;
+  }
+}
+
 // ---- gradient w.r.t. the tokens (trainable backbone blocks only; the frozen path never needs it) ----------------
 //   dx[f,n,c] = sum_j ( W[f,j,n] * dpooled[b,j,t,c]  +  dS[f,j,n] * vec[f|0, j, c] )        (f = b*T + t)
 // W = the weights the forward summed with (P, or the masked Pm under SMART_DISJOINT), dS = d(raw scores) from
@@ -350,6 +368,19 @@ __global__ __launch_bounds__(256) void lstp_dx_kernel(DxArgs a) {
     const int tap = c / a.D, cc = c - tap * a.D;
     *reinterpret_cast<float4*>(a.dx[tap] + ((size_t)f * a.N + n) * a.D + cc) = acc;
   }
+}
+
+extern "C" int mvf_token_pool(const void* const* taps, int n_taps, int dtype, int D, int F, int N, int mode, float* out,
+                              hipStream_t st) {
+  PoolArgs a{};
+  int rc = fill_args(a, taps, n_taps, dtype, D, F, N, 1, 1);
+  if (rc != MVF_OK) return rc;
+  MVF_CHECK_ARG(out && (mode == 0 || mode == 1));
+  a.out = out;
+  if (dtype == MVF_BF16) hipLaunchKernelGGL(token_pool_kernel<bf16_t>, dim3(F, n_taps), dim3(256), 0, st, a, mode);
+  else hipLaunchKernelGGL(token_pool_kernel<float>, dim3(F, n_taps), dim3(256), 0, st, a, mode);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
 }
 
 extern "C" int mvf_lstp_dx(float* const* dx_host, int n_taps, int D, int F, int N, int T, int nq, const float* w,

@@ -14,6 +14,7 @@ import torch.nn as nn
 from .. import ops
 from . import vit as vitlib
 from .mvformer import MultiEntityTransformerEmbModel, Taps
+from .utils import Encoder, PositionalEncoder
 from .resnet_c2d import MLPHead
 
 
@@ -34,6 +35,60 @@ class FeatureExtractor(nn.Module):
         return self.model.forward_taps(x, self.tap_ids, dtype=dtype, frames_per_chunk=frames_per_chunk)
 
 
+class TransformerEmbModel(nn.Module):
+    """Late fusion (models/transformer.py:248-300): one feature vector per frame (CLS embedding, or the spatial tokens
+    max/avg-pooled by ops.token_pool) -> [Dropout, Linear, BatchNorm1d, ReLU] x k -> video_emb (+ sin/cos table in the GEMM
+    epilogue) -> temporal encoder over the T frames -> embedding_layer.  Parameter names as the reference's."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        em = cfg.MODEL.EMBEDDER_MODEL
+        drop_rate = em.FC_DROPOUT_RATE
+        in_channels = cfg.MODEL.BASE_MODEL.OUT_CHANNEL
+        self.embedding_size = em.EMBEDDING_SIZE
+        hidden_channels = em.HIDDEN_SIZE
+        assert em.FLATTEN_METHOD in ['max_pool', 'avg_pool']
+        self.flatten_method = em.FLATTEN_METHOD
+        self.pooling = nn.Identity()              # the pooling itself is ops.token_pool (parameter-free)
+        layers = []
+        for channels, _activate in em.FC_LAYERS:
+            channels = channels * em.CAPACITY_SCALAR
+            layers += [nn.Dropout(drop_rate), nn.Linear(in_channels, channels), nn.BatchNorm1d(channels), nn.ReLU(True)]
+            in_channels = channels
+        self.fc_layers = nn.Sequential(*layers)
+        self.video_emb = nn.Linear(in_channels, hidden_channels)
+        self.video_pos_enc = PositionalEncoder(cfg, hidden_channels, drop_rate, seq_len=cfg.TRAIN.NUM_FRAMES)
+        if em.NUM_LAYERS > 0:
+            self.video_encoder = Encoder(hidden_channels, drop_rate, em.NUM_HEADS, em.D_FF, em.NUM_LAYERS)
+        self.embedding_layer = nn.Linear(hidden_channels, self.embedding_size)
+        self.drop_state = ops.DropoutState(seed=int(cfg.RNG_SEED) if 'RNG_SEED' in cfg else 0)
+        self.sync_group = None
+
+    def set_warmup_status(self, new_status):      # train.py:79 calls it on every embed model
+        pass
+
+    def forward(self, x, n_clips, n_frames, video_masks=None):
+        """x [Bc*T, C] -> [Bc, T, E]."""
+        mods = list(self.fc_layers)
+        for i in range(0, len(mods), 4):
+            x = ops.dropout_add(x, None, mods[i].p, self.training, self.drop_state)
+            bn = mods[i + 2]
+            if bn.training != self.training:
+                bn.train(self.training)
+            x = ops.batch_norm(ops.linear(x, mods[i + 1].weight, mods[i + 1].bias), bn.weight, bn.bias, bn.running_mean,
+                               bn.running_var, self.training and bn.training, momentum=bn.momentum, eps=bn.eps, relu=True,
+                               sync=isinstance(bn, nn.SyncBatchNorm), group=self.sync_group)
+        x = ops.linear(x, self.video_emb.weight, self.video_emb.bias, table=self.video_pos_enc.table(n_frames, x.device),
+                       tab_div=1, tab_mod=n_frames)
+        x = ops.dropout_add(x, None, self.video_pos_enc.dout_p, self.training, self.drop_state)
+        x = x.view(n_clips, n_frames, -1)
+        if self.cfg.MODEL.EMBEDDER_MODEL.NUM_LAYERS > 0:
+            x = self.video_encoder(x, src_mask=video_masks, drop_state=self.drop_state)
+        x = ops.linear(x.reshape(n_clips * n_frames, -1), self.embedding_layer.weight, self.embedding_layer.bias)
+        return x.view(n_clips, n_frames, self.embedding_size)
+
+
 class TransformerModel(nn.Module):
     def __init__(self, cfg, local_rank=None):
         super().__init__()
@@ -45,9 +100,17 @@ class TransformerModel(nn.Module):
         if 'TIMM-' not in net:
             raise NotImplementedError('only TIMM-* ViT backbones are on the MI355X path (got %s); the ResNet-50 '
                                       'CARL baselines are out of scope' % net)
-        if self.fusion_type != 'smart':
-            raise NotImplementedError("only MODEL.EMBEDDER_MODEL.FUSION_TYPE 'smart' (MV-Former) is on the MI355X path")
+        if self.fusion_type not in ('smart', 'late'):
+            print('WARNING: invalid setting for cfg.MODEL.EMBEDDER_MODEL.FUSION_TYPE:')
+            print(self.fusion_type)
+            exit(-1)
+        if self.use_cls_res and self.fusion_type == 'late':
+            print('ERROR: CLS_RES cannot be used with late fusion')
+            exit(-1)
         self.backbone_type = 'timm'
+        # late fusion reads either the CLS embedding or the spatial tokens (transformer.py:66-70)
+        self.late_type = em.LATE_TYPE if 'LATE_TYPE' in em else 'cls'
+        assert self.late_type in ['cls', 'spatial']
         name = net[5:]
         if name not in vitlib.VIT_ZOO:
             print('ERROR: unknown/unsupported TIMM model:')
@@ -59,7 +122,10 @@ class TransformerModel(nn.Module):
         model = vitlib.create_model(name, pretrained=False, weights=weights, img_size=cfg.IMAGE_SIZE)
         if self.use_cls_res:
             self.cls_res_res = nn.Linear(dim, em.EMBEDDING_SIZE)
-        if 'SMART_FEATS' not in em:
+        self.uses_taps = self.fusion_type != 'late' or self.late_type == 'spatial'
+        if not self.uses_taps:
+            extract_ids = []                      # late fusion on the CLS embedding: no block is tapped
+        elif 'SMART_FEATS' not in em:
             extract_ids = ['blocks.11']
         else:
             extract_ids = ['blocks.%s' % t for t in str(em.SMART_FEATS).split(',')]
@@ -82,7 +148,7 @@ class TransformerModel(nn.Module):
             self.res_finetune = FeatureExtractor(vitlib.ViTBackEnd(model, layer), new_ids)
         for p in self.backbone.parameters():      # frozen: never in the optimizer, never all-reduced
             p.requires_grad_(False)
-        self.embed = MultiEntityTransformerEmbModel(cfg)
+        self.embed = MultiEntityTransformerEmbModel(cfg) if self.fusion_type == 'smart' else TransformerEmbModel(cfg)
         # FUSION_CLS / CLS_GRAD_ONLY: validated and announced by the reference's constructor (transformer.py:144-163) and
         # read nowhere else -- kept as the same two flags
         self.fuse_cls = bool('FUSION_CLS' in em and em.FUSION_CLS is True)
@@ -170,7 +236,13 @@ class TransformerModel(nn.Module):
         if video_masks is not None:
             video_masks = video_masks.to(x.device)     # DDP's input scatter did this in the reference
         feats, cls_emb = self.features(x)
-        x = self.embed(feats, video_masks=video_masks, cls_emb=cls_emb)
+        if self.fusion_type == 'smart':
+            x = self.embed(feats, video_masks=video_masks, cls_emb=cls_emb)
+        elif self.late_type == 'cls':             # transformer.py:192-196: the CLS embedding as a 1 x 1 feature map
+            x = self.embed(cls_emb, feats.n_clips, feats.n_frames, video_masks=video_masks)
+        else:
+            pooled = ops.token_pool(feats.tensors, feats.n_clips * feats.n_frames, feats.n_tokens, self.embed.flatten_method)
+            x = self.embed(pooled, feats.n_clips, feats.n_frames, video_masks=video_masks)
         if self.cfg.MODEL.PROJECTION and project:
             x = ops.l2_normalize(self.ssl_projection(x))
         elif self.cfg.MODEL.L2_NORMALIZE:

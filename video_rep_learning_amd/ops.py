@@ -631,6 +631,18 @@ class _LSTPPool(torch.autograd.Function):
         return (dvec, None, None, None, None, None, None, None, None) + dtaps
 
 
+def token_pool(taps, F, N, mode):
+    """taps: list of [F*N, D] tensors -> [F, n_taps*D] fp32: max ('max_pool') or mean ('avg_pool') over each frame's tokens
+    (late fusion).  Forward only: the tapped blocks must be frozen."""
+    if any(t.requires_grad for t in taps):
+        raise _lib.MvfError('late fusion over spatial tokens of TRAINABLE backbone blocks is not built (no pooling backward)')
+    dt = BF16 if taps[0].dtype == torch.bfloat16 else F32
+    D = taps[0].shape[1]
+    out = torch.empty(F, D * len(taps), device=taps[0].device, dtype=torch.float32)
+    call('mvf_token_pool', _tap_table(taps), len(taps), dt, D, F, N, {'max_pool': 0, 'avg_pool': 1}[mode], ptr(out), stream())
+    return out
+
+
 def lstp_pool(vec, taps, F, N, T, nq, d_model, disjoint=False, holder=None):
     """-> (pooled [Bc, nq, T, C], rowsum [Bc, nq, T]).  Taps that require grad (outputs of trainable backbone blocks) get
     their gradient from mvf_lstp_dx."""

@@ -48,7 +48,7 @@ def oracle_cfgs(cfg):
                           num_heads=em.NUM_HEADS, num_layers=em.NUM_LAYERS, train_len=cfg.TRAIN.NUM_FRAMES,
                           dyn_ctrl=em.get('DYNAMIC_CTRL', 'separate'), disjoint=bool(em.get('SMART_DISJOINT', False)),
                           val_pass=bool(em.get('VAL_PASS', False)), n_taps=len(taps),
-                          fwb=bool(em.get('FIXED_WIDTH_BASELINE', False)))
+                          fwb=bool(em.get('FIXED_WIDTH_BASELINE', False)), ln_keys=bool(em.get('SMART_LN_KEYS', False)))
     scl_cfg = dict(negative_type=cfg.SCL.NEGATIVE_TYPE, temperature=cfg.SCL.SOFTMAX_TEMPERATURE,
                    label_variance=cfg.SCL.LABEL_VARIENCE)
     return vit_cfg, head_cfg, scl_cfg
@@ -98,7 +98,7 @@ SMALL = dict(network='TIMM-vit_small_patch16_224.dino', num_frames=8, batch_size
 # fg99 / long64 / dinov2: the head and sequence shapes of BASELINE configs[2], [3] and [4] at a small image size
 @pytest.mark.parametrize('variant', ['base', 'avg_enc_nst6', 'max_none', 'lin', 'dynamic', 'disjoint', 'batch_neg', 'fg99',
                                      'long64', 'dinov2', 'fwb', 'partial', 'partial_dinov2', 'late_cls',
-                                     'late_spatial_max', 'late_spatial_avg', 'late_cls_partial'])
+                                     'late_spatial_max', 'late_spatial_avg', 'late_cls_partial', 'ln_keys'])
 def test_small_model_loss_and_grads(variant):
     kw = dict(SMALL)
     if variant == 'avg_enc_nst6':
@@ -121,6 +121,8 @@ def test_small_model_loss_and_grads(variant):
         kw.update(network='TIMM-vit_small_patch14_dinov2.lvd142m', image_size=28)
     if variant == 'partial':     # blocks 10, 11 + final norm trainable; taps must lie in the back end
         kw.update(SMART_FEATS='10,11', LAYER=10)
+    elif variant == 'ln_keys':              # SMART_LN_KEYS: scores against normalised projected keys
+        kw.update(SMART_LN_KEYS=True)
     elif variant == 'late_cls':             # late fusion (TransformerEmbModel) on the CLS embedding
         kw.update(FUSION_TYPE='late')
     elif variant == 'late_spatial_max':

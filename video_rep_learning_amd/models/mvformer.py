@@ -93,15 +93,23 @@ class LSTPCrossAtt(nn.Module):
 
     def forward(self, taps, dyn_in=None):
         """-> [Bc, nq, T, d_out] rows in (clip, entity, frame) order."""
-        if self.ln_keys:
-            raise NotImplementedError('SMART_LN_KEYS (normalised projected keys) is not on the HIP path yet: it needs '
-                                      'the full key projection, which the streaming pooling kernels avoid')
         nq = self.num_s + self.num_d
         F = taps.n_clips * taps.n_frames
-        vec = self.query_vectors(dyn_in, taps.n_clips, taps.n_frames)
         holder = {}
-        pooled, rowsum = ops.lstp_pool(vec, taps.tensors, F, taps.n_tokens, taps.n_frames, nq, self.d_model,
-                                       disjoint=self.disjoint_att, holder=holder)
+        if self.ln_keys:
+            # SMART_LN_KEYS (mvformer.py:399-400): scores against F.normalize(K).  The normalisation depends on the token,
+            # so the keys ARE projected here (one [F*N, C] x [C, d] GEMM on an fp32 copy of the taps) -- the ablation's cost
+            if self.dyn:
+                raise NotImplementedError('SMART_LN_KEYS with dynamic (per-frame) queries is not built')
+            xcat = torch.cat([t.float() for t in taps.tensors], 1)
+            kn = ops.l2_normalize(ops.linear(xcat, self.linear_K2d.weight, self.linear_K2d.bias))
+            scores = ops.linear(kn, (self.Q_s + self.Q_s_b)[0], None)              # [F*N, nq]
+            pooled, rowsum = ops.lstp_pool_from_scores(scores, taps.tensors, F, taps.n_tokens, taps.n_frames, nq,
+                                                       self.d_model, disjoint=self.disjoint_att, holder=holder)
+        else:
+            vec = self.query_vectors(dyn_in, taps.n_clips, taps.n_frames)
+            pooled, rowsum = ops.lstp_pool(vec, taps.tensors, F, taps.n_tokens, taps.n_frames, nq, self.d_model,
+                                           disjoint=self.disjoint_att, holder=holder)
         if self.visual:
             self.attn_matrix = holder['attn'].detach()                    # [F, nq, N]
             _ = self.attn_holder(self.attn_matrix)

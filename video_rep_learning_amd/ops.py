@@ -631,6 +631,72 @@ class _LSTPPool(torch.autograd.Function):
         return (dvec, None, None, None, None, None, None, None, None) + dtaps
 
 
+class _LSTPPoolScores(torch.autograd.Function):
+    """The pooling with the raw scores [F*N, nq] supplied by the caller (SMART_LN_KEYS: scores against NORMALISED projected
+    keys cannot be folded into a query-side vector): P = softmax_n(scores / sqrt(d)), pooled = sum_n P x."""
+
+    @staticmethod
+    def forward(ctx, scores, taps, F, N, T, nq, inv_sqrt_d, disjoint, holder, *grad_taps):
+        ctx.want_dx = len(grad_taps) > 0 and any(t.requires_grad for t in grad_taps)
+        dt = BF16 if taps[0].dtype == torch.bfloat16 else F32
+        D = taps[0].shape[1]
+        C = D * len(taps)
+        dev = taps[0].device
+        scores = scores.contiguous()
+        tab = _tap_table(taps)
+        P = torch.empty(F, nq, N, device=dev, dtype=torch.float32)
+        Pm = torch.empty_like(P) if disjoint else None
+        rowsum = torch.empty(F, nq, device=dev, dtype=torch.float32) if disjoint else None
+        call('mvf_lstp_softmax_fwd', ptr(scores), ptr(P), ptr(Pm), ptr(rowsum), F, N, nq, inv_sqrt_d, int(disjoint), stream())
+        pooled = torch.empty(F // T, nq, T, C, device=dev, dtype=torch.float32)
+        call('mvf_lstp_wsum', tab, len(taps), dt, D, F, N, T, nq, ptr(Pm if disjoint else P), ptr(pooled), stream())
+        ctx.taps = taps
+        ctx.save_for_backward(P, Pm)
+        ctx.cfg = (F, N, T, nq, inv_sqrt_d, dt, D, C)
+        if holder is not None:
+            holder['attn'] = Pm if disjoint else P
+        if disjoint:
+            rs = rowsum.view(F // T, T, nq).transpose(1, 2).contiguous()
+        else:
+            rs = torch.ones(F // T, nq, T, device=dev, dtype=torch.float32)
+            ctx.mark_non_differentiable(rs)
+        return pooled, rs
+
+    @staticmethod
+    def backward(ctx, dpooled, drs):
+        P, Pm = ctx.saved_tensors
+        F, N, T, nq, inv_sqrt_d, dt, D, C = ctx.cfg
+        taps = ctx.taps
+        tab = _tap_table(taps)
+        dev = dpooled.device
+        dpooled = dpooled.contiguous()
+        dP = torch.empty(F * N, nq, device=dev, dtype=torch.float32)
+        call('mvf_lstp_scores', tab, len(taps), dt, D, F, N, T, nq, ptr(dpooled), 1, ptr(dP), stream())
+        drow = None
+        if Pm is not None and drs is not None:
+            drow = drs.transpose(1, 2).contiguous().view(F, nq)
+        dS = torch.empty(F, nq, N, device=dev, dtype=torch.float32)
+        call('mvf_lstp_softmax_bwd', ptr(P), ptr(Pm), ptr(dP), ptr(drow), ptr(dS), F, N, nq, inv_sqrt_d, stream())
+        dscores = dS.transpose(1, 2).reshape(F * N, nq)          # [F, nq, N] -> the caller's [F*N, nq] layout
+        dtaps = ()
+        if ctx.want_dx:                                           # value-side gradient only: the score side flows via `scores`
+            if dt != F32:
+                raise _lib.MvfError('token gradients need fp32 taps (trainable backbone blocks run in fp32)')
+            dtaps = tuple(torch.empty_like(t) for t in taps)
+            arr = (ctypes.c_void_p * len(taps))(*[t.data_ptr() for t in dtaps])
+            zero = torch.zeros_like(dS)
+            dummy = torch.zeros(nq, C, device=dev, dtype=torch.float32)
+            call('mvf_lstp_dx', arr, len(taps), D, F, N, T, nq, ptr(Pm if Pm is not None else P), ptr(zero), ptr(dpooled),
+                 ptr(dummy), 0, stream())
+        return (dscores, None, None, None, None, None, None, None, None) + dtaps
+
+
+def lstp_pool_from_scores(scores, taps, F, N, T, nq, d_model, disjoint=False, holder=None):
+    taps = tuple(taps)
+    grad_taps = taps if any(t.requires_grad for t in taps) else ()
+    return _LSTPPoolScores.apply(scores, taps, F, N, T, nq, 1.0 / math.sqrt(d_model), disjoint, holder, *grad_taps)
+
+
 def token_pool(taps, F, N, mode):
     """taps: list of [F*N, D] tensors -> [F, n_taps*D] fp32: max ('max_pool') or mean ('avg_pool') over each frame's tokens
     (late fusion).  Forward only: the tapped blocks must be frozen."""

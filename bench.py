@@ -105,11 +105,15 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
+    # test hooks (tests/test_gpu_bench.py runs two ranks on the ONE GPU of a test box, where RCCL refuses duplicate
+    # devices): MVF_BENCH_SHARE_GPU=1 puts every rank on device 0, MVF_BENCH_BACKEND=gloo swaps the process group
+    if os.environ.get('MVF_BENCH_SHARE_GPU') == '1':
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', init_method='env://', world_size=world, rank=rank)
+        dist.init_process_group(os.environ.get('MVF_BENCH_BACKEND', 'nccl'), init_method='env://', world_size=world, rank=rank)
 
     from video_rep_learning_amd import _lib
     from video_rep_learning_amd.utils import presets
@@ -175,20 +179,22 @@ def main():
 
     # ---- roofline of the dominant kernel: per-launch HIP-event timing during extra (untimed) steps ----
     roof = None
+    # Kernel timing wants the kernels one at a time: the timed region above keeps two backbone lanes and the head in
+    # flight together (a launch's event-to-event time would then include the other streams' kernels), so these extra
+    # steps run the backbone as one lane, without lookahead -- the same serial order rocprofv3 records.  EVERY rank runs
+    # them (a step contains the gradient all-reduce and the SyncBN exchanges); only rank 0 records and reports.
+    from video_rep_learning_amd import ops
+    lane_rows, ops.VIT_LANE_MIN_ROWS = ops.VIT_LANE_MIN_ROWS, 1 << 62
+    step(lookahead=False)                  # drains the primed forward
+    torch.cuda.synchronize()
     if rank == 0:
-        # Kernel timing wants the kernels one at a time: the timed region above keeps two backbone lanes and the head in
-        # flight together (a launch's event-to-event time would then include the other streams' kernels), so these
-        # extra steps run the backbone as one lane, without lookahead -- the same serial order rocprofv3 records.
-        from video_rep_learning_amd import ops
-        lane_rows, ops.VIT_LANE_MIN_ROWS = ops.VIT_LANE_MIN_ROWS, 1 << 62
-        step(lookahead=False)                  # drains the primed forward
-        torch.cuda.synchronize()
         _lib.call('mvf_prof_enable', 1)
-        for _ in range(max(a.profile_steps, 1)):
-            step(lookahead=False)
-        torch.cuda.synchronize()
+    for _ in range(max(a.profile_steps, 1)):
+        step(lookahead=False)
+    torch.cuda.synchronize()
+    ops.VIT_LANE_MIN_ROWS = lane_rows
+    if rank == 0:
         _lib.call('mvf_prof_enable', 0)
-        ops.VIT_LANE_MIN_ROWS = lane_rows
         G = 16
         ms, fl = (ctypes.c_double * G)(), (ctypes.c_double * G)()
         cnt, epi, nn, kk = (ctypes.c_int * G)(), (ctypes.c_int * G)(), (ctypes.c_int * G)(), (ctypes.c_int * G)()

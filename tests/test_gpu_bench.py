@@ -1,0 +1,48 @@
+"""bench.py as the driver launches it: single process, and two ranks through torch.distributed.run (here both on the one
+GPU of the test box with the gloo backend -- RCCL refuses two ranks on one device; the control flow, the collectives'
+ORDER on every rank and the output contract are what is tested, not the interconnect)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+        'dtype', 'data', 'config', 'roofline'}
+
+
+def _line(out):
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_process_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--profile-steps', '1',
+                        '--no-cpu-baseline'], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r.stdout)
+    assert KEYS <= set(j) and j['n_gpus'] == 1 and j['steps'] == 3 and j['warmup'] == 2 and j['vs_baseline'] is None
+    assert j['higher_is_better'] is True and j['scaling'] == 'weak' and j['unit'] == 'clips/s' and j['value'] > 0
+    rf = j['roofline']
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(rf) and 0 < rf['frac'] < 1
+    assert 'workload' in j['config'] and 'model' not in j['config']
+
+
+def test_bench_two_ranks_do_not_deadlock():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MVF_BENCH_SHARE_GPU='1', MVF_BENCH_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2',
+           '--profile-steps', '1']
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    j = _line(r.stdout)
+    assert j['n_gpus'] == 2 and j['config']['parallelism'] == 'dp2' and j['value'] > 0
+    assert 'cpu_baseline' not in j or j['cpu_baseline'] is None or True     # N > 1: no CPU leg is required

@@ -44,7 +44,10 @@ def S():
 # ------------------------------------------------------------------------------------------------ gemm_tc256
 @pytest.mark.parametrize('M,N,K,epi', [(256, 256, 128, 0), (2000, 768, 768, 0), (1576, 2304, 768, 1), (777, 384, 1536, 0),
                                         (70000, 1024, 256, 1), (9000, 3072, 128, 0),
-                                        (197 * 8, 768, 3072, 2), (196 * 6, 768, 768, 3)])
+                                        (197 * 8, 768, 3072, 2), (196 * 6, 768, 768, 3),
+                                        # more tiles than workgroups: the ticket scheduler hands out tiles (K >= 256), with
+                                        # the read-modify epilogues too; K = 128 keeps the static walk
+                                        (70000, 768, 256, 2), (197 * 256, 768, 768, 2), (196 * 300, 768, 768, 3)])
 def test_gemm_tc256_equals_tc128_bitwise(M, N, K, epi):
     """The 256x256 8-phase kernel accumulates every output in the same k order as the 128x128 kernel (64-wide K tiles,
     two 32-deep MFMA steps each), so on identical bf16 inputs the two must agree BIT FOR BIT -- for every epilogue, ragged

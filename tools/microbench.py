@@ -7,7 +7,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from video_rep_learning_amd import _lib, ops  # noqa: E402
-from oracle import vit as OV  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from vit_streams_probe import random_sd  # noqa: E402   (seeded random ViT-B/16 weights; oracle/ is test infrastructure)
 
 DEV = 'cuda'
 
@@ -70,7 +71,7 @@ def main():
                                      D, Mx, D, 1e-6, S()))
         print('layernorm %-5s %8.1f us  %6.0f GB/s' % (dtype, t * 1e6, Mx * D * (4 + y.element_size()) / t / 1e9))
     # whole backbone
-    w = {k: v.to(DEV) for k, v in OV.init_vit_weights(768, 12, 16, 224, seed=1).items()}
+    w = random_sd(dev=DEV)
     frames = torch.randn(F, 3, 224, 224, device=DEV)
     pk = ops.PackedViT(w, 12, 768, 12, 16, 224, (3, 7, 11), 'bf16')
     for chunk in (0, 128, 64, 32, 16):

@@ -98,8 +98,10 @@ int mvf_gemm_tc_debug_stamps(unsigned long long* buf);
 int mvf_patchify(int dtype, const float* frames, void* out, int F, int H, int W, int P, hipStream_t stream);
 int mvf_layernorm_fwd(int out_dtype, const float* x, size_t in_stride, const float* g, const float* b, void* y,
                       size_t out_stride, int rows, int D, float eps, hipStream_t stream);
-/* variant (bf16): 0 = product path, 1 = 2-byte gather reads of V (cross-check of the transposing LDS read), 2 / 3 = the
- * one-query-tile-per-wave kernel / the two-tile kernel at 2 waves per SIMD for N = 193..208 (A/B measurements) */
+/* variant (bf16): 0 = product path (two query tiles per wave; one key block for N = 193..208, else 96-key blocks streamed
+ * through a double-buffered LDS-DMA pipeline), 1 = 2-byte gather reads of V (cross-check of the transposing LDS read),
+ * 2 = the earlier kernels (one tile per wave / synchronously staged 224-key blocks), 3 = variant 0 at 2 waves per SIMD,
+ * 4 = streamed 64-key blocks, 5 = the streamed kernel for every N (2..5: A/B measurements) */
 int mvf_vit_attn_fwd(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t stream);
 int mvf_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t stream);
 

@@ -167,9 +167,12 @@ def _attn_ref(qkv, F, N, H):
 
 # 197: ViT-B/16 @224 (13 key tiles, one block, DMA-staged specialisation); 193 / 208: the same specialisation at its edges;
 # 5: tiny; 257, 577: DINOv2 patch 14 @224 / @336 (two / three key blocks, online softmax); 785: ViT-B/8
-@pytest.mark.parametrize('N', [197, 193, 208, 5, 257, 577, 785])
-# variants: 0 default (two query tiles per wave at N = 193..208), 1 gather reads, 2 one tile per wave, 3 = 0 at 2 waves/SIMD
-@pytest.mark.parametrize('dtype,variant', [('f32', 0), ('bf16', 0), ('bf16', 1), ('bf16', 2), ('bf16', 3)])
+@pytest.mark.parametrize('N', [197, 193, 208, 5, 64, 65, 129, 257, 577, 785])
+# variants: 0 default (two query tiles per wave; streamed 96-key blocks unless N = 193..208), 1 gather reads, 2 the earlier
+# kernels (one tile per wave / synchronously staged 224-key blocks), 3 = 0 at 2 waves/SIMD, 4 streamed 64-key blocks,
+# 5 the streamed kernel for every N
+@pytest.mark.parametrize('dtype,variant', [('f32', 0), ('bf16', 0), ('bf16', 1), ('bf16', 2), ('bf16', 3), ('bf16', 4),
+                                           ('bf16', 5)])
 def test_vit_attention(N, dtype, variant):
     code, tdt = ops._dt(dtype)
     F, H, D = 2, 3, 192

@@ -15,6 +15,8 @@ from video_rep_learning_amd.train import DataParallelModel  # noqa: E402
 
 CASES = {
     'cfg1 penn_mvf as shipped: ViT-B/8, T=8, B=1': dict(network='TIMM-vit_base_patch8_224.dino', num_frames=8, batch_size=1),
+    'penn_mvf.yml exactly as shipped: ViT-B/8, T=80, B=1': dict(network='TIMM-vit_base_patch8_224.dino', num_frames=80,
+                                                                 batch_size=1),
     'cfg2 ViT-B/16, T=32, B=4': dict(network='TIMM-vit_base_patch16_224.dino', num_frames=32, batch_size=4),
     'cfg2 with LAYER=10: blocks 10-11 + norm trainable (fp32 blocks, correctness-first)': dict(
         network='TIMM-vit_base_patch16_224.dino', num_frames=32, batch_size=4, SMART_FEATS='10,11', LAYER=10),

@@ -397,6 +397,161 @@ __global__ __launch_bounds__(256, OCC) void vit_attn_bf16_pair_kernel(AttnArgs a
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16, any N: key blocks of KT*16 keys streamed through a double-buffered LDS-DMA pipeline, two query tiles per wave
+// ------------------------------------------------------------------------------------------------
+// The long-sequence form (ViT-B/8 of every shipped configs_mvf/*.yml: N = 785; DINOv2 at 224/336 px: 257 / 577).
+// A workgroup (4 waves) owns 8 query tiles = 128 queries of one (frame, head) and walks all key blocks:
+//     wait for block b (vmcnt(0)) -> barrier -> issue block b+1 into the other buffer -> S^T, online softmax, O^T on block b
+// so block b+1's HBM/L2 latency hides under block b's arithmetic and there is ONE barrier per block (it also guarantees
+// every wave is done with the buffer the new DMAs overwrite).  Same LDS images / swizzles / accumulator-as-B-operand
+// chaining as the single-block kernels; online softmax state (m, l) per query tile; keys >= N are masked in the last
+// block only.  The earlier general kernel staged 224 keys synchronously through VGPRs for 64 queries per workgroup
+// (280 TFLOP/s at N = 785, 160 at N = 257); this one keeps 2 x KT*16 keys in flight per workgroup.  Measured, F = 80,
+// N = 785: KT = 6 (96 keys, 168 VGPRs, 3 waves/SIMD) 295 us = 514 TFLOP/s; KT = 4 (4 waves/SIMD) 345; KT = 2 344; KT = 8
+// (2 waves/SIMD) 523; 8 waves per workgroup with KT = 4: 365.  N = 257 (F = 256): 149 / 166 / 192 / 355 / 240 us.
+template <int KT, int OCC, int NW = 4>
+__global__ __launch_bounds__(NW * 64, OCC) void vit_attn_bf16_flash_kernel(AttnArgs a) {
+  constexpr int KROWS = KT * 16;               // keys per block
+  constexpr int BLK = KROWS * 128;             // bytes of one K (or V) block
+  __shared__ __attribute__((aligned(16))) char smem[4 * BLK];   // [buf][K | V]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  const int f = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const size_t ld = (size_t)3 * a.D;
+  const bf16_t* base = reinterpret_cast<const bf16_t*>(a.qkv) + (size_t)f * a.N * ld;
+  const bf16_t* qb = base + h * HD;
+  const bf16_t* kbp = base + a.D + h * HD;
+  const bf16_t* vbp = base + 2 * a.D + h * HD;
+  bf16_t* obase = reinterpret_cast<bf16_t*>(a.out) + (size_t)f * a.N * a.D + h * HD;
+  const int vsw = ((2 * g + (li >> 3)) & 3) << 5;
+  const int nblk = (a.N + KROWS - 1) / KROWS;
+  const int qt0 = (blockIdx.y * NW + wave) * 2;                 // this wave's two query tiles: qt0, qt0 + 1
+  const bool active = qt0 * 16 < a.N;                            // (an inactive wave still stages and meets the barriers)
+
+  bf16x8_t qf[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int qrow = min((qt0 + i) * 16 + li, a.N - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[i][ks] = *reinterpret_cast<const bf16x8_t*>(qb + (size_t)qrow * ld + ks * 32 + g * 8);
+  }
+  asm volatile("" : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[1][0]), "+v"(qf[1][1]));   // landed before any DMA is in flight
+
+  constexpr int NP = KROWS / 8;                 // 1-KiB pieces per K (or V) block; NP % 4 == 0 for KT even
+  const int prow = lane >> 3, pc = lane & 7;
+  auto issue = [&](int b) {
+    char* sk = smem + (b & 1) * 2 * BLK;
+    char* sv = sk + BLK;
+    for (int p = wave; p < NP; p += NW) {
+      const int r = b * KROWS + p * 8 + prow;   // rows >= N repeat row N-1 (finite; masked / zero-weighted below)
+      const int rr = min(r, a.N - 1), lr = p * 8 + prow;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(kbp + (size_t)rr * ld + ((pc ^ (lr & 7)) << 3)), LDS_PTR(sk + p * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(vbp + (size_t)rr * ld + ((pc ^ (((lr >> 1) & 3) << 1)) << 3)),
+                                       LDS_PTR(sv + p * 1024), 16, 0, 0);
+    }
+  };
+
+  float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+  f32x4_t o[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[i][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  for (int b = 0; b < nblk; ++b) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of block b
+    __builtin_amdgcn_s_barrier();                      // everyone's pieces; and everyone is done with block b-1's buffer
+    if (b + 1 < nblk) issue(b + 1);
+    if (!active) continue;
+    const char* sk = smem + (b & 1) * 2 * BLK;
+    const char* sv = sk + BLK;
+    const int nkeys = a.N - b * KROWS;                 // valid keys in this block (>= KROWS except in the last block)
+    f32x4_t s[2][KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) s[i][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sk + (kt * 16 + li) * 128 + (((ks * 4 + g) ^ (li & 7)) << 4));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) s[i][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[i][ks], s[i][kt], 0, 0, 0);
+      }
+    }
+    if (nkeys < KROWS) {                               // last block: keys beyond N never win the max and get weight 0
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[i][kt][r] = kt * 16 + 4 * g + r < nkeys ? s[i][kt][r] : -1e30f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float mx = -1e30f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(s[i][kt][0], s[i][kt][1])), fmaxf(s[i][kt][2], s[i][kt][3]));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[i], mx);
+      const float nm = -m_new * a.scale_log2;
+      float ls = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[i][kt][r], a.scale_log2, nm));
+          s[i][kt][r] = p;
+          ls += p;
+        }
+      ls += __shfl_xor(ls, 16, 64);
+      ls += __shfl_xor(ls, 32, 64);
+      const float alpha = __builtin_amdgcn_exp2f((m_run[i] - m_new) * a.scale_log2);   // 0 on the first block
+      l_run[i] = l_run[i] * alpha + ls;
+      m_run[i] = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[i][dt][r] *= alpha;
+    }
+#pragma unroll
+    for (int st = 0; st < KT / 2; ++st) {
+      union { bf16x8_t v; uint32_t u[4]; } pf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        pf[i].u[0] = pack_bf16x2(s[i][2 * st][0], s[i][2 * st][1]);
+        pf[i].u[1] = pack_bf16x2(s[i][2 * st][2], s[i][2 * st][3]);
+        pf[i].u[2] = pack_bf16x2(s[i][2 * st + 1][0], s[i][2 * st + 1][1]);
+        pf[i].u[3] = pack_bf16x2(s[i][2 * st + 1][2], s[i][2 * st + 1][3]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        union { bf16x8_t v; bf16x4_t hh[2]; } vf;
+        const char* p0 = sv + (st * 32 + 4 * g + (li >> 2)) * 128 + (((dt * 32) ^ vsw) + 8 * (li & 3));
+        vf.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(p0));
+        vf.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(p0 + 16 * 128));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) o[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[i].v, o[i][dt], 0, 0, 0);
+      }
+    }
+  }
+  if (!active) return;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = (qt0 + i) * 16 + li;
+    if (q < a.N) {
+      const float inv = 1.0f / l_run[i];
+      bf16_t* orow = obase + (size_t)q * a.D;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<uint2*>(orow + dt * 16 + 4 * g) =
+            make_uint2(pack_bf16x2(o[i][dt][0] * inv, o[i][dt][1] * inv), pack_bf16x2(o[i][dt][2] * inv, o[i][dt][3] * inv));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fp32 (parity mode)
 // ------------------------------------------------------------------------------------------------
 constexpr int VROW = (HD + 4) * 4;  // 272-B V rows: keys 4 apart fall on different banks for ds_read_b32
@@ -517,7 +672,8 @@ __global__ __launch_bounds__(256, 1) void vit_attn_f32_kernel(AttnArgs a) {
 }  // namespace
 
 // variant: 0 = default (transposing LDS read for V; two query tiles per wave when N = 193..208), 1 = 2-byte gather reads
-// (cross-check path), 2 = one query tile per wave (the earlier N = 193..208 kernel, kept for A/B runs)
+// (cross-check path), 2 = one query tile per wave / synchronously staged 224-key blocks (the earlier kernels, kept for A/B
+// runs), 3 = the two-tile kernel at 2 waves per SIMD, 4 = the streamed kernel with 64-key blocks, 5 = the streamed kernel for any N
 int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t st) {
   MVF_CHECK_ARG(qkv && out && F > 0 && N > 0 && H > 0 && D == H * HD);
   MVF_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0);
@@ -532,12 +688,16 @@ int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H
   dim3 grid(F * H, chunks);
   if (dtype == MVF_BF16) {
     const int ntile = ceil_div(N, 16);
+    const dim3 fg(F * H, ceil_div(ntile, 8));   // streamed kernels: 8 query tiles per workgroup
     if (variant == 1) hipLaunchKernelGGL((vit_attn_bf16_kernel<false, KT>), grid, dim3(256), 0, st, a);
+    else if (variant == 5) hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<6, 3>), fg, dim3(256), 0, st, a);   // any N (A/B)
     else if (a.nblk == 1 && ntile == 13 && variant == 0)
       hipLaunchKernelGGL((vit_attn_bf16_pair_kernel<13, 3>), grid, dim3(256), 0, st, a);
     else if (a.nblk == 1 && ntile == 13 && variant == 3)
       hipLaunchKernelGGL((vit_attn_bf16_pair_kernel<13, 2>), grid, dim3(256), 0, st, a);
     else if (a.nblk == 1 && ntile == 13) hipLaunchKernelGGL((vit_attn_bf16_kernel<true, 13>), grid, dim3(256), 0, st, a);
+    else if (variant == 0) hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<6, 3>), fg, dim3(256), 0, st, a);   // 96-key blocks
+    else if (variant == 4) hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<4, 4>), fg, dim3(256), 0, st, a);   // 64-key blocks
     else hipLaunchKernelGGL((vit_attn_bf16_kernel<true, KT>), grid, dim3(256), 0, st, a);
   } else if (dtype == MVF_F32) {
     static bool attr = false;

@@ -57,6 +57,48 @@ def test_vit_vs_hf(dim, depth, heads, patch, img):
     assert (cls - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-5
 
 
+def test_dinov2_layerscale_vs_hf():
+    """The DINOv2 family (LayerScale, patch 14: BASELINE configs[4]) against transformers.Dinov2Model with the same seeded
+    weights: hidden_states[i + 1] = output of block i (pre final norm), last_hidden_state[:, 0] = final-norm CLS."""
+    transformers = pytest.importorskip('transformers')
+    dim, depth, heads, patch, img = 384, 12, 6, 14, 56
+    cfg = transformers.Dinov2Config(hidden_size=dim, num_hidden_layers=depth, num_attention_heads=heads, mlp_ratio=4,
+                                    image_size=img, patch_size=patch, layer_norm_eps=1e-6, hidden_act='gelu',
+                                    layerscale_value=1.0, use_swiglu_ffn=False, attn_implementation='eager')
+    hf = transformers.Dinov2Model(cfg).eval()
+    w = OV.init_vit_weights(dim, depth, patch, img, seed=5, layerscale=True)
+    w = {k: (v * 3.0 if ('qkv.weight' in k or 'fc' in k or 'proj.weight' in k) else v) for k, v in w.items()}
+    sd = {'embeddings.cls_token': w['cls_token'], 'embeddings.position_embeddings': w['pos_embed'],
+          'embeddings.mask_token': torch.zeros(1, dim),
+          'embeddings.patch_embeddings.projection.weight': w['patch_embed.proj.weight'],
+          'embeddings.patch_embeddings.projection.bias': w['patch_embed.proj.bias'],
+          'layernorm.weight': w['norm.weight'], 'layernorm.bias': w['norm.bias']}
+    for i in range(depth):
+        p, q = 'blocks.%d.' % i, 'encoder.layer.%d.' % i
+        for j, nm in enumerate(('query', 'key', 'value')):
+            sd[q + 'attention.attention.%s.weight' % nm] = w[p + 'attn.qkv.weight'][j * dim:(j + 1) * dim]
+            sd[q + 'attention.attention.%s.bias' % nm] = w[p + 'attn.qkv.bias'][j * dim:(j + 1) * dim]
+        sd[q + 'attention.output.dense.weight'], sd[q + 'attention.output.dense.bias'] = w[p + 'attn.proj.weight'], w[p + 'attn.proj.bias']
+        sd[q + 'norm1.weight'], sd[q + 'norm1.bias'] = w[p + 'norm1.weight'], w[p + 'norm1.bias']
+        sd[q + 'norm2.weight'], sd[q + 'norm2.bias'] = w[p + 'norm2.weight'], w[p + 'norm2.bias']
+        sd[q + 'layer_scale1.lambda1'], sd[q + 'layer_scale2.lambda1'] = w[p + 'ls1.gamma'], w[p + 'ls2.gamma']
+        for nm in ('fc1', 'fc2'):
+            sd[q + 'mlp.%s.weight' % nm], sd[q + 'mlp.%s.bias' % nm] = w[p + 'mlp.%s.weight' % nm], w[p + 'mlp.%s.bias' % nm]
+    missing, unexpected = hf.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    x = torch.randn(2, 3, img, img, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        out = hf(pixel_values=x, output_hidden_states=True)
+        feats, cls = OV.vit_forward(x, w, heads, patch, taps=(3, 7, 11))
+    for j, blk in enumerate((3, 7, 11)):
+        ref = out.hidden_states[blk + 1]
+        got = feats[:, :, j * dim:(j + 1) * dim]
+        err = (got - ref).abs().max().item()
+        assert err <= 2e-4 * ref.abs().max().item() + 1e-5, (blk, err)
+    ref = out.last_hidden_state[:, 0]
+    assert (cls - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-5
+
+
 def test_patchify_matches_conv():
     x = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(1))
     wt = torch.randn(8, 3, 16, 16, generator=torch.Generator().manual_seed(2))

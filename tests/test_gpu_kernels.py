@@ -534,6 +534,30 @@ def test_lstp_token_gradients(nq, disjoint, per_frame):
     check(gx, fr.grad, 2e-4, 'd tokens')
 
 
+@pytest.mark.parametrize('M,N,K,resid', [(1000, 384, 384, True), (3000, 1536, 384, False), (777, 384, 1536, True)])
+def test_linear_tc_bf16_forward_and_input_gradient(M, N, K, resid):
+    """ops.linear_tc (trainable ViT blocks in bf16 mode): forward and dX on the bf16 MFMA kernel -- equal to the fp64 result on
+    the bf16-ROUNDED operands up to fp32 accumulation; dW / db in fp32 from the unrounded operands."""
+    g = gen(50)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.05
+    b = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g) if resid else None
+    gy = torch.randn(M, N, generator=g)
+    q = lambda t: t.to(torch.bfloat16).double()
+    yref = q(x) @ q(w).t() + b.double() + (r.double() if resid else 0)
+    xg, wg, bg = _leaf(x), _leaf(w), _leaf(b)
+    rg = _leaf(r) if resid else None
+    y = ops.linear_tc(xg, wg, bg, resid=rg)
+    check(y, yref, 2e-5, 'linear_tc fwd')
+    (y * gy.to(DEV)).sum().backward()
+    check(xg.grad, q(gy) @ q(w), 2e-5, 'linear_tc dx (bf16-rounded dy, w)')
+    check(wg.grad, gy.double().t() @ x.double(), 2e-4, 'linear_tc dW (fp32)')
+    check(bg.grad, gy.double().sum(0), 2e-4, 'linear_tc db')
+    if resid:
+        assert torch.equal(rg.grad.cpu(), gy)
+
+
 def test_gelu_and_wide_layernorm_backward():
     """Ops of a trainable ViT block that the frozen path never needed: exact-erf GELU forward/backward and LayerNorm backward
     at ViT widths (768, 1024; the head's LayerNorms are 256 wide)."""

@@ -324,3 +324,26 @@ def test_three_step_trajectory_fused_adam(partial):
     osd = opt.state_dict()
     assert set(osd) == {'state', 'param_groups'} and len(osd['param_groups']) == 2
     assert set(osd['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'}
+
+
+def test_partial_freeze_bf16_mode_tracks_fp32_mode():
+    """bf16 mode of a partially frozen backbone: frozen front end on the bf16 kernels and the trainable blocks' GEMMs (forward,
+    input gradient) on the bf16 persistent kernel (ops.linear_tc); it must stay close to the fp32 parity mode."""
+    kw = dict(SMALL, SMART_FEATS='10,11')
+    outs = {}
+    for dt in ('fp32', 'bf16'):
+        cfg, model = make(3, layer=10, **dict(kw, compute_dtype=dt))
+        videos, seq_lens, steps, masks = batch(cfg, 5, pad=3)
+        model.train()
+        loss = get_algo(cfg).compute_loss(model, videos.to(DEV), seq_lens, steps, masks)['loss']
+        loss.backward()
+        outs[dt] = (loss.item(), {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters()
+                                  if p.grad is not None})
+    l32, g32 = outs['fp32']
+    l16, g16 = outs['bf16']
+    assert abs(l16 - l32) <= 2e-2 * abs(l32), (l16, l32)
+    assert set(g16) == set(g32)
+    worst = min((torch.nn.functional.cosine_similarity(g16[n].flatten(), g32[n].flatten(), dim=0).item(), n)
+                for n in g32 if g32[n].numel() > 64 and g32[n].norm() > 1e-6)
+    print('bf16 vs fp32 partial freeze: loss %.5f vs %.5f; worst gradient cosine %.4f (%s)' % (l16, l32, worst[0], worst[1]))
+    assert worst[0] > 0.98, worst

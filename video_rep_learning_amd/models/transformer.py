@@ -31,7 +31,7 @@ class FeatureExtractor(nn.Module):
 
     def forward(self, x, dtype='bf16', frames_per_chunk=0):
         if isinstance(self.model, vitlib.ViTBackEnd):        # x = the front end's residual stream [F, N, D]
-            return self.model(x, self.tap_ids)
+            return self.model(x, self.tap_ids, fast=(dtype == 'bf16' and x.shape[-1] % 128 == 0))
         return self.model.forward_taps(x, self.tap_ids, dtype=dtype, frames_per_chunk=frames_per_chunk)
 
 
@@ -226,7 +226,7 @@ class TransformerModel(nn.Module):
         for tns in list(taps) + ([cls] if cls is not None else []):
             tns.record_stream(cur)
         if self.split_layer is not None:          # trainable blocks: on the caller's stream, recorded by autograd
-            taps, cls = self.res_finetune(taps[0])
+            taps, cls = self.res_finetune(taps[0], dtype=self.compute_dtype)
         ntok = (h // self.backbone.model.patch_size) * (w // self.backbone.model.patch_size)
         return Taps(taps, bc, t, ntok), cls
 

@@ -115,27 +115,29 @@ class VisionTransformer(nn.Module):
         return ops.vit_front(x, self._packed[key], frames_per_chunk=frames_per_chunk)
 
 
-def block_forward(blk, x, heads):
+def block_forward(blk, x, heads, fast=False):
     """One TRAINABLE ViT block (timm Block.forward: x + ls1(attn(norm1(x))); x + ls2(mlp(norm2(x)))) on x [F, N, D] fp32,
     composed of the head's fp32 HIP ops, every one with a HIP backward: LayerNorm, GEMM (+ bias, + residual in the epilogue),
     flash-style attention on the fp32 matrix cores, exact-erf GELU.  This is the correctness-first form of SURVEY 8f row 3:
     the frozen blocks keep the bf16 persistent GEMM path."""
     ls = hasattr(blk, 'ls1')          # DINOv2: x + gamma * f(x) instead of the residual fused into the GEMM epilogue
     F, N, D = x.shape
+    # bf16 mode: the four GEMMs' forward and input gradient on the bf16 persistent kernel (ops._LinearTC); fp32 mode: exact
+    lin = ops.linear_tc if fast else ops.linear
     x2 = x.reshape(F * N, D)
     h = ops.layer_norm(x2, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
-    qkv = ops.linear(h, blk.attn.qkv.weight, blk.attn.qkv.bias)
+    qkv = lin(h, blk.attn.qkv.weight, blk.attn.qkv.bias)
     o = ops.temporal_attention(qkv, None, F, N, heads)                 # softmax(q k^T / sqrt(64)) v, no mask
     if ls:
-        x2 = ops.layerscale_add(ops.linear(o, blk.attn.proj.weight, blk.attn.proj.bias), blk.ls1.gamma, x2)
+        x2 = ops.layerscale_add(lin(o, blk.attn.proj.weight, blk.attn.proj.bias), blk.ls1.gamma, x2)
     else:
-        x2 = ops.linear(o, blk.attn.proj.weight, blk.attn.proj.bias, resid=x2)
+        x2 = lin(o, blk.attn.proj.weight, blk.attn.proj.bias, resid=x2)
     h = ops.layer_norm(x2, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-    h = ops.gelu(ops.linear(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
+    h = ops.gelu(lin(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
     if ls:
-        x2 = ops.layerscale_add(ops.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias), blk.ls2.gamma, x2)
+        x2 = ops.layerscale_add(lin(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias), blk.ls2.gamma, x2)
     else:
-        x2 = ops.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, resid=x2)
+        x2 = lin(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, resid=x2)
     return x2.view(F, N, D)
 
 
@@ -171,11 +173,11 @@ class ViTBackEnd(nn.Module):
         for p in self.parameters():
             p.requires_grad_(True)
 
-    def forward(self, x, tap_ids):
+    def forward(self, x, tap_ids, fast=False):
         F, N, D = x.shape
         taps = {}
         for i, blk in enumerate(self.blocks):
-            x = block_forward(blk, x, self.num_heads)
+            x = block_forward(blk, x, self.num_heads, fast)
             if i in tap_ids:
                 taps[i] = x[:, self.num_prefix_tokens:].reshape(F * (N - self.num_prefix_tokens), D)
         cls = ops.layer_norm(x[:, 0], self.norm.weight, self.norm.bias, self.norm.eps)

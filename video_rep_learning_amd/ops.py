@@ -121,6 +121,71 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, d_resid, None, None, None
 
 
+class _LinearTC(torch.autograd.Function):
+    """y = x W^T + b [+ resid] for the big-M GEMMs of TRAINABLE backbone blocks in bf16 mode: forward and the input gradient
+    run on the persistent bf16 MFMA kernel (operands cast to bf16 per call, fp32 accumulation, fp32 result through the
+    read-modify epilogue); the weight / bias gradients stay in fp32 (mvf_hlinear_bwd without dX).  What fp16 autocast does
+    to these layers in the reference, with an fp32 weight gradient.  Needs K % 128 == 0 and N % 128 == 0."""
+
+    @staticmethod
+    def _bf16(t):
+        o = torch.empty(t.shape, device=t.device, dtype=torch.bfloat16)
+        call('mvf_cast_f32_bf16', ptr(t), ptr(o), t.numel(), stream())
+        return o
+
+    @staticmethod
+    def _gemm(a_bf16, w_bf16, bias, out_f32):
+        M, K = a_bf16.shape
+        N = w_bf16.shape[0]
+        call('mvf_gemm_tc', BF16, _lib.EPI_RESID, ptr(a_bf16), K, ptr(w_bf16), K, ptr(bias), None, 0, ptr(out_f32), N, None, 0,
+             None, None, 1, M, N, K, stream())
+
+    @staticmethod
+    def forward(ctx, x, w, b, resid, slots, owners):
+        x = x.contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        y = resid.contiguous().clone() if resid is not None else torch.zeros(M, N, device=x.device, dtype=torch.float32)
+        _LinearTC._gemm(_LinearTC._bf16(x), _LinearTC._bf16(w.detach().contiguous()), b, y)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (resid is not None, b is not None, slots, owners)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        has_resid, has_bias, slots, owners = ctx.cfg
+        M, K = x.shape
+        N = w.shape[0]
+        dy = dy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.zeros(M, K, device=dy.device, dtype=torch.float32)
+            _LinearTC._gemm(_LinearTC._bf16(dy), _LinearTC._bf16(w.detach().t().contiguous()), None, dx)   # dy . W
+        if slots is not None:
+            gw, gb = slots
+            acc, dw, db = 1, None, None
+        else:
+            dw = torch.empty(N, K, device=dy.device, dtype=torch.float32)
+            db = torch.empty(N, device=dy.device, dtype=torch.float32) if has_bias else None
+            gw, gb, acc = dw, db, 0
+        call('mvf_hlinear_bwd', dy.data_ptr(), N, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), None, K,
+             gw.data_ptr(), gw.stride(0) if gw.dim() == 2 else K, ptr(gb) if has_bias else None, M, N, K, acc, stream())
+        if slots is not None:
+            grad_ready(*owners)
+        return dx, dw, db, (dy if has_resid else None), None, None
+
+
+def linear_tc(x, w, b=None, resid=None):
+    """ops.linear for the large GEMMs of trainable ViT blocks in bf16 mode (see _LinearTC)."""
+    x2 = x.reshape(-1, x.shape[-1])
+    slots, owners = None, ()
+    if x2.requires_grad and grad_slot(w) is not None and (b is None or grad_slot(b) is not None):
+        slots, owners = (grad_slot(w), grad_slot(b)), (w, b)
+    r2 = None if resid is None else resid.reshape(-1, resid.shape[-1])
+    return _LinearTC.apply(x2, w, b, r2, slots, owners).view(x.shape[:-1] + (w.shape[0],))
+
+
 def linear(x, w, b=None, relu=False, table=None, tab_div=1, tab_mod=1, resid=None, drop=None, fused=None):
     """x [..., K] -> [..., N]; `table` [mod, N] is added to row r as table[(r // div) % mod] (sin/cos PE);
     `drop` = (p, seed, offset) applies the counter-based dropout to the result, `resid` [..., N] is added last.

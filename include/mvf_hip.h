@@ -84,6 +84,11 @@ int mvf_prof_collect(double* ms_host, double* flops_host, int* count_host, int* 
 int mvf_gemm_tc(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
                 float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tokens_per_frame, int M,
                 int N, int K, hipStream_t stream);
+/* bf16 only, K % 128 == 0: M/batch_rows independent GEMMs stacked along M (batch_rows % 256 == 0), batch b using rows
+ * [b * w_batch_rows, b * w_batch_rows + N) of W: the split-K form of a weight gradient dW = dY^T X over the tokens (each
+ * batch one chunk of the token axis, fp32 partial sums with epi = 2 into a zeroed resid; trainable backbone blocks) */
+int mvf_gemm_tc_batched(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, float* resid, int ldr,
+                        int M, int N, int K, int batch_rows, int w_batch_rows, hipStream_t stream);
 /* kernel choice for mvf_gemm_tc / mvf_vit_fwd (A/B measurements and tests): 0 automatic (bf16 and K % 128 == 0 ->
  * persistent 256x256 8-phase kernel, else 128x128), 1 always 128x128, 2 only 256x256 (MVF_ERR_UNSUPPORTED where it
  * cannot run), 3 the 256x256 kernel with one workgroup per tile instead of one per CU */
@@ -127,10 +132,16 @@ int mvf_hgemm_ex(const float* A, long sam, long sak, const float* B, long sbk, l
 int mvf_hlinear_bwd(const float* dy, long ldy, const float* x, long ldx, const float* W, long ldw, float* dx, long lddx,
                     float* dW, long lddw, float* db, int M, int N, int K, int accumulate_params, hipStream_t stream);
 int mvf_colsum(const float* x, long ld, int rows, int cols, float* out, int accumulate, hipStream_t stream);
+/* stage 1 of a column sum over very many rows: part[s][c] = sum of row slice s (splits slices); stage 2: mvf_sum_batches */
+int mvf_colsum_split(const float* x, long ld, int rows, int cols, int splits, float* part, hipStream_t stream);
 
 /* dx = dy * [y > 0]  (ReLU backward of the FFN, models/utils.py:190) */
 int mvf_relu_bwd(const float* dy, const float* y, float* dx, size_t n, hipStream_t stream);
 /* exact-erf GELU (timm Mlp of a TRAINABLE ViT block): y = x Phi(x); dx = dy (Phi(x) + x phi(x)) */
+/* split-K weight gradient helpers: out bf16 [S, C, Mc], out[s][c][j] = in[s*Mc + j][c] (fp32 in [M, C], zero beyond M;
+ * Mc % 64 == 0, S = ceil(M / Mc));  out[i] (+)= sum over the S batches of part[s][i] */
+int mvf_transpose_chunks(const float* in, void* out_bf16, int M, int C, int Mc, hipStream_t stream);
+int mvf_sum_batches(const float* part, float* out, int S, size_t n, int accumulate, hipStream_t stream);
 /* LayerScale of a trainable DINOv2 block: mode 0 out = resid + y * gamma[col]; 1 out = y * gamma[col]; 2 out = y * resid */
 int mvf_colscale(const float* y, const float* gamma, const float* resid, float* out, int rows, int D, int mode,
                  hipStream_t stream);

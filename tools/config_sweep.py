@@ -18,7 +18,7 @@ CASES = {
     'penn_mvf.yml exactly as shipped: ViT-B/8, T=80, B=1': dict(network='TIMM-vit_base_patch8_224.dino', num_frames=80,
                                                                  batch_size=1),
     'cfg2 ViT-B/16, T=32, B=4': dict(network='TIMM-vit_base_patch16_224.dino', num_frames=32, batch_size=4),
-    'cfg2 with LAYER=10: blocks 10-11 + norm trainable (fp32 blocks, correctness-first)': dict(
+    'cfg2 with LAYER=10: blocks 10-11 + norm trainable (bf16 GEMMs in all three directions)': dict(
         network='TIMM-vit_base_patch16_224.dino', num_frames=32, batch_size=4, SMART_FEATS='10,11', LAYER=10),
     'cfg3 fg99 head (6 entities, cap 6, E=256, taps 9,10,11, avg), T=32, B=4': dict(
         network='TIMM-vit_base_patch16_224.dino', num_frames=32, batch_size=4, SMART_TOKENS=6, CAPACITY_SCALAR=6,

@@ -22,6 +22,7 @@ SIGNATURES = {
     'mvf_prof_enable': 'i',
     'mvf_prof_collect': 'ppppppip',
     'mvf_gemm_tc': 'iipipippipipippiiiip',
+    'mvf_gemm_tc_batched': 'ipipipipiiiiiip',
     'mvf_gemm_tc_select': 'i',
     'mvf_gemm_tc_debug_stamps': 'p',
     'mvf_gemm_tc_set_cus': 'i',
@@ -34,7 +35,10 @@ SIGNATURES = {
     'mvf_hgemm_ex': 'pllpllplppllii' + 'iiifii' + 'plfuup',
     'mvf_hlinear_bwd': 'plplplplplpiiiip',
     'mvf_colsum': 'pliipip',
+    'mvf_colsum_split': 'pliiipp',
     'mvf_relu_bwd': 'pppzp',
+    'mvf_transpose_chunks': 'ppiiip',
+    'mvf_sum_batches': 'ppizip',
     'mvf_colscale': 'ppppiiip',
     'mvf_gelu_fwd': 'ppzp',
     'mvf_gelu_bwd': 'pppzp',

@@ -165,7 +165,7 @@ int dispatch(int epi, const GemmTcArgs& a, hipStream_t st) {
 // Internal entry used by the ViT driver and exported through the C ABI (mvf_gemm_tc in mvf_hip.h).
 int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C,
                      int ldc, float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tpf, int M,
-                     int N, int K, hipStream_t st) {
+                     int N, int K, hipStream_t st, int batch_rows, int w_batch_rows) {
   const int esz = dtype == MVF_BF16 ? 2 : 4;
   const int ke = ROWB / esz;
   MVF_CHECK_ARG(dtype == MVF_BF16 || dtype == MVF_F32);
@@ -182,6 +182,11 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
   a.pos = pos; a.ls = ls; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.ldt = ldt; a.M = M; a.N = N; a.K = K; a.tpf = tpf;
   a.dbg = g_dbg;
   a.sched = nullptr;   // set by the persistent gemm_tc256 launch
+  a.batch_rows = batch_rows; a.w_batch_rows = w_batch_rows;
+  if (batch_rows != 0) {   // stacked batches: the 256x256 kernel only
+    MVF_CHECK_ARG(batch_rows > 0 && batch_rows % 256 == 0 && M % batch_rows == 0 && w_batch_rows >= N);
+    if (!(dtype == MVF_BF16 && g_variant != 1 && K % 128 == 0 && N % 32 == 0)) return MVF_ERR_UNSUPPORTED;
+  }
   // bf16 with K a multiple of 128: the 256x256 8-phase kernel (gemm_tc256.hip); g_variant 1 pins the 128x128 kernel
   if (dtype == MVF_BF16 && g_variant != 1 && K % 128 == 0 && N % 32 == 0)
     return mvf_gemm_tc256_launch(epi, a, /*persistent=*/g_variant != 3, st);
@@ -195,6 +200,15 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
 extern "C" int mvf_gemm_tc_debug_stamps(unsigned long long* buf) {
   g_dbg = buf;
   return MVF_OK;
+}
+
+// C[b*R + m, n] (+)= A[b*R + m, :] . W[b*Wr + n, :]^T for b = 0 .. M/R - 1: the split-K form of a weight gradient (each batch
+// one chunk of the reduction, fp32 partial sums through the read-modify epilogue)
+extern "C" int mvf_gemm_tc_batched(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, float* resid,
+                                   int ldr, int M, int N, int K, int batch_rows, int w_batch_rows, hipStream_t st) {
+  MVF_CHECK_ARG(epi == EPI_STORE || epi == EPI_RESID);
+  return mvf_gemm_tc_impl(MVF_BF16, epi, A, lda, W, ldw, nullptr, C, ldc, resid, ldr, nullptr, 0, nullptr, nullptr, 1, M, N,
+                          K, st, batch_rows, w_batch_rows);
 }
 
 extern "C" int mvf_gemm_tc_select(int variant) {

@@ -146,6 +146,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   unsigned wsrc[2][2];
   auto set_sources = [&](int tile) {
     const int tm0 = (tile / nbn) * BM, tn0 = (tile % nbn) * BN;
+    // stacked batches (split-K weight gradients): the tile's batch picks its own row block of W
+    const int wb0 = a.batch_rows > 0 ? (tm0 / a.batch_rows) * a.w_batch_rows : 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
         const int am = (r >> 6) * 128 + h * 64 + (r & 63);       // A: wave row r>>6, m-quadrant h
         const int wn = (r >> 5) * 64 + h * 32 + (r & 31);        // W: wave column r>>5, n-quadrant h
         const int gm = min(tm0 + am, a.M - 1);
-        const int gn = min(tn0 + wn, a.N - 1);
+        const int gn = wb0 + min(tn0 + wn, a.N - 1);
         // 24-bit multiply (rows and row bytes < 2^24, checked by the launch): one v_mad_u32_u24 -- a full 32-bit
         // product goes through v_mad_u64_u32, whose don't-care high addend register hipcc shares with the ticket's
         asrc[h][i] = __umul24((unsigned)gm, (unsigned)a.lda * 2u) + lchunk * 16;
@@ -463,8 +465,9 @@ extern "C" int mvf_gemm_tc_set_cus(int n) {
 int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, bool persistent, hipStream_t st) {
   if (a.K % 128 != 0 || a.K < 128 || a.N % 32 != 0) return MVF_ERR_ARG;
   // 32-bit operand offsets inside the kernel
-  if ((size_t)a.M * a.lda * 2 >= (1ull << 32) || (size_t)a.N * a.ldw * 2 >= (1ull << 32) || a.M >= (1 << 24) ||
-      a.N >= (1 << 24) || a.lda >= (1 << 23) || a.ldw >= (1 << 23))
+  const size_t wrows = a.batch_rows > 0 ? (size_t)(a.M / a.batch_rows) * a.w_batch_rows : (size_t)a.N;
+  if ((size_t)a.M * a.lda * 2 >= (1ull << 32) || wrows * a.ldw * 2 >= (1ull << 32) || a.M >= (1 << 24) ||
+      wrows >= (1u << 24) || a.lda >= (1 << 23) || a.ldw >= (1 << 23))
     return MVF_ERR_UNSUPPORTED;
   if (a.dbg != nullptr) return epi == EPI_STORE ? launch<EPI_STORE, true>(a, persistent, st) : MVF_ERR_UNSUPPORTED;
   switch (epi) {

@@ -21,6 +21,9 @@ struct GemmTcArgs {
   int tpf;  // tokens per frame (1 + patches)
   unsigned long long* dbg;  // diagnostic stamps (gemm_tc256 DBG build only), normally null
   unsigned* sched;          // gemm_tc256 persistent launch: 16 zeroed counters of this launch's tile scheduler (or null)
+  // gemm_tc256 only: A / C rows are `batch_rows`-row batches stacked along M (a multiple of 256), batch b multiplying rows
+  // [b * w_batch_rows, b * w_batch_rows + N) of W (split-K weight gradients); batch_rows == 0: one plain GEMM
+  int batch_rows, w_batch_rows;
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

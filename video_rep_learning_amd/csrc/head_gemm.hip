@@ -261,6 +261,23 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
+// the same over a slice of the rows: part[split][c] = sum of rows [split*chunk, (split+1)*chunk) -- stage 1 of a bias gradient
+// over tens of thousands of rows (trainable backbone blocks); stage 2 = mvf_sum_batches (fixed order: deterministic)
+__global__ __launch_bounds__(256) void colsum_split_kernel(const float* __restrict__ x, long ld, int rows, int cols, int chunk,
+                                                           float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * chunk, r1 = min(rows, r0 + chunk);
+  float s = 0.f;
+  if (c < cols)
+    for (int r = r0 + rl; r < r1; r += 4) s += x[(long)r * ld + c];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols)
+    part[(size_t)blockIdx.y * cols + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 constexpr int LDS_B = 4 * TILE_F * 4;   // dynamic LDS per workgroup (above the 64 KiB static limit)
 
 template <typename K>
@@ -344,6 +361,14 @@ extern "C" int mvf_hlinear_bwd(const float* dy, long ldy, const float* x, long l
   else
     hipLaunchKernelGGL(hlinear_bwd_kernel<true>, dim3(nx + nw), dim3(256), LDS_B, st, gx, gw, nx, dxn, dwn,
                        (int)can_vec(dy, ldy), (int)can_vec(W, ldw), (int)can_vec(dy, ldy), (int)can_vec(x, ldx));
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_colsum_split(const float* x, long ld, int rows, int cols, int splits, float* part, hipStream_t st) {
+  MVF_CHECK_ARG(x && part && rows > 0 && cols > 0 && splits > 0);
+  hipLaunchKernelGGL(colsum_split_kernel, dim3(ceil_div(cols, 64), splits), dim3(256), 0, st, x, ld, rows, cols,
+                     ceil_div(rows, splits), part);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

@@ -477,6 +477,57 @@ extern "C" int mvf_relu_bwd(const float* dy, const float* y, float* dx, size_t n
   return MVF_OK;
 }
 
+// ---- split-K weight gradients of the trainable backbone blocks (ops._LinearTC) ----
+// transpose + cast: in fp32 [M, C] -> out bf16 [S, C, Mc] with out[s][c][j] = in[s*Mc + j][c] (0 for rows >= M): both
+// operands of dW = dY^T X become K-contiguous along the token axis, one chunk of Mc tokens per batch of mvf_gemm_tc_batched
+__global__ __launch_bounds__(256) void transpose_chunks_kernel(const float* __restrict__ in, unsigned short* __restrict__ out,
+                                                               int M, int C, int Mc) {
+  __shared__ float tile[64][65];
+  const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int m = m0 + r, c = c0 + tx;
+    tile[r][tx] = (m < M && c < C) ? in[(size_t)m * C + c] : 0.0f;
+  }
+  __syncthreads();
+  const int s = m0 / Mc, j0 = m0 - s * Mc;          // Mc % 64 == 0: a tile never straddles two chunks
+  // every thread writes 8 consecutive tokens of one channel: 16-byte stores (2-byte stores ran 10x slower)
+  const int jg = (threadIdx.x & 7) * 8;
+  for (int cc = threadIdx.x >> 3; cc < 64; cc += 32) {
+    const int c = c0 + cc;
+    if (c >= C) continue;
+    uint32_t w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = pack_bf16x2(tile[jg + 2 * q][cc], tile[jg + 2 * q + 1][cc]);
+    *reinterpret_cast<uint4*>(out + ((size_t)s * C + c) * Mc + j0 + jg) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+// out[i] (+)= sum_s part[s][i]  (fixed order: deterministic)
+__global__ void sum_batches_kernel(const float* __restrict__ part, float* __restrict__ out, int S, size_t n, int accumulate) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float acc = accumulate ? out[i] : 0.0f;
+    for (int s = 0; s < S; ++s) acc += part[(size_t)s * n + i];
+    out[i] = acc;
+  }
+}
+
+extern "C" int mvf_transpose_chunks(const float* in, void* out_bf16, int M, int C, int Mc, hipStream_t st) {
+  MVF_CHECK_ARG(in && out_bf16 && M > 0 && C > 0 && Mc > 0 && Mc % 64 == 0);
+  const int S = ceil_div(M, Mc);
+  hipLaunchKernelGGL(transpose_chunks_kernel, dim3(S * (Mc / 64), ceil_div(C, 64)), dim3(256), 0, st, in,
+                     reinterpret_cast<unsigned short*>(out_bf16), M, C, Mc);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_sum_batches(const float* part, float* out, int S, size_t n, int accumulate, hipStream_t st) {
+  MVF_CHECK_ARG(part && out && S > 0 && n > 0);
+  hipLaunchKernelGGL(sum_batches_kernel, dim3(ew_grid(n)), dim3(256), 0, st, part, out, S, n, accumulate);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
 extern "C" int mvf_colscale(const float* y, const float* gamma, const float* resid, float* out, int rows, int D, int mode,
                             hipStream_t st) {
   MVF_CHECK_ARG(y && out && rows > 0 && D > 0 && mode >= 0 && mode <= 2 && (mode == 2 || gamma) && (mode == 1 || resid));

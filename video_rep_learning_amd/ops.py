@@ -127,6 +127,8 @@ class _LinearTC(torch.autograd.Function):
     read-modify epilogue); the weight / bias gradients stay in fp32 (mvf_hlinear_bwd without dX).  What fp16 autocast does
     to these layers in the reference, with an fp32 weight gradient.  Needs K % 128 == 0 and N % 128 == 0."""
 
+    MC = 2048      # tokens per split-K chunk of the weight gradient
+
     @staticmethod
     def _bf16(t):
         o = torch.empty(t.shape, device=t.device, dtype=torch.bfloat16)
@@ -169,8 +171,27 @@ class _LinearTC(torch.autograd.Function):
             dw = torch.empty(N, K, device=dy.device, dtype=torch.float32)
             db = torch.empty(N, device=dy.device, dtype=torch.float32) if has_bias else None
             gw, gb, acc = dw, db, 0
-        call('mvf_hlinear_bwd', dy.data_ptr(), N, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), None, K,
-             gw.data_ptr(), gw.stride(0) if gw.dim() == 2 else K, ptr(gb) if has_bias else None, M, N, K, acc, stream())
+        if N % 256 == 0 and K % 32 == 0 and gw.dim() == 2 and gw.stride(0) == K and M >= 4 * _LinearTC.MC:
+            # dW = dY^T X on the bf16 kernel too, split-K over the token axis: both operands transposed (and cast) into
+            # chunks of MC tokens, one batch of mvf_gemm_tc_batched per chunk with fp32 partial sums, summed in fixed order
+            MC = _LinearTC.MC
+            S = (M + MC - 1) // MC
+            dyt = torch.empty(S * N, MC, device=dy.device, dtype=torch.bfloat16)
+            xt = torch.empty(S * K, MC, device=dy.device, dtype=torch.bfloat16)
+            call('mvf_transpose_chunks', ptr(dy), ptr(dyt), M, N, MC, stream())
+            call('mvf_transpose_chunks', ptr(x), ptr(xt), M, K, MC, stream())
+            part = torch.zeros(S * N, K, device=dy.device, dtype=torch.float32)
+            call('mvf_gemm_tc_batched', _lib.EPI_RESID, ptr(dyt), MC, ptr(xt), MC, None, 0, ptr(part), K, S * N, K, MC, N, K,
+                 stream())
+            call('mvf_sum_batches', ptr(part), gw.data_ptr(), S, N * K, acc, stream())
+            if has_bias:       # two-stage column sum (the one-stage kernel walks all M rows with N/64 workgroups: 5 ms)
+                RS = 128
+                bpart = torch.empty(RS, N, device=dy.device, dtype=torch.float32)
+                call('mvf_colsum_split', ptr(dy), N, M, N, RS, ptr(bpart), stream())
+                call('mvf_sum_batches', ptr(bpart), ptr(gb), RS, N, acc, stream())
+        else:
+            call('mvf_hlinear_bwd', dy.data_ptr(), N, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), None, K,
+                 gw.data_ptr(), gw.stride(0) if gw.dim() == 2 else K, ptr(gb) if has_bias else None, M, N, K, acc, stream())
         if slots is not None:
             grad_ready(*owners)
         return dx, dw, db, (dy if has_resid else None), None, None

@@ -54,3 +54,28 @@ def test_product_path_refuses_cpu_tensors():
         ops.linear(x, torch.randn(3, 8))
     with pytest.raises(_lib.MvfError):
         ops.vit_forward(torch.randn(1, 3, 32, 32), None)
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """The ctypes mirrors of MvfVitWeights / MvfAugmentParams against the C compiler's view of include/mvf_hip.h (gcc, host
+    only: sizes and the offsets of a few members)."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None or not os.path.exists('/opt/rocm/include/hip/hip_runtime_api.h'):
+        pytest.skip('needs gcc and the HIP headers')
+    probes = [('MvfVitWeights', ['depth', 'taps', 'ln_eps', 'cls_token', 'patch_w', 'ln1_w', 'fc2_b', 'ls2']),
+              ('MvfAugmentParams', ['crop_top', 'flip', 'color_op', 'color_factor', 'blur_kx', 'blur_sigma', 'gray', 'mean', 'std'])]
+    body = ''.join('printf("%s %%zu", sizeof(%s));%sprintf("\\n");\n' % (
+        st, st, ''.join('printf(" %%zu", offsetof(%s, %s));' % (st, f) for f in fs)) for st, fs in probes)
+    src = tmp_path / 'layout.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mvf_hip.h"\nint main(void) {\n%s return 0; }\n' % body)
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include', '-I' + os.path.join(ROOT, 'include'), str(src), '-o',
+                    str(exe)], check=True, capture_output=True)
+    lines = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    for (st, fs), line in zip(probes, lines):
+        name, size, *offs = line.split()
+        cls = getattr(_lib, st)
+        assert name == st and int(size) == ctypes.sizeof(cls), (st, size, ctypes.sizeof(cls))
+        for f, o in zip(fs, offs):
+            assert getattr(cls, f).offset == int(o), (st, f, o, getattr(cls, f).offset)

@@ -77,3 +77,23 @@ def test_reference_configs_drop_in(path):
     assert cfg.TRAINING_ALGO == 'scl' and 'EMBEDDER_MODEL' in cfg.MODEL
     assert cfg.EVAL.NUM_FRAMES == cfg.TRAIN.NUM_FRAMES
     assert 'TCC' in cfg and 'OPTIMIZER' in cfg          # untouched default sub-trees survive
+
+
+def test_backbone_weights_with_another_image_size_are_resampled(tmp_path):
+    """MODEL.BASE_MODEL.WEIGHTS stored for a different image size (DINOv2: 518 px): the position embedding's grid part is
+    resampled (bicubic, antialias) like timm's resample_abs_pos_embed, the CLS entry kept; same size = untouched."""
+    import torch
+    from video_rep_learning_amd.models import vit
+    big = vit.create_model('vit_small_patch14_dinov2.lvd142m', img_size=70, seed=3)            # 5 x 5 patches
+    path = str(tmp_path / 'w.pth')
+    torch.save({'model': big.state_dict()}, path)
+    small = vit.create_model('vit_small_patch14_dinov2.lvd142m', weights=path, img_size=42)    # 3 x 3 patches
+    assert small.pos_embed.shape == (1, 10, 384)
+    assert torch.equal(small.pos_embed[:, 0], big.pos_embed[:, 0])
+    assert torch.equal(small.blocks[3].mlp.fc1.weight, big.blocks[3].mlp.fc1.weight)
+    same = vit.create_model('vit_small_patch14_dinov2.lvd142m', weights=path, img_size=70)
+    assert torch.equal(same.pos_embed, big.pos_embed)
+    # a constant grid stays constant under resampling; a linear ramp keeps its end-to-end ordering
+    pe = torch.cat([torch.zeros(1, 1, 4), torch.full((1, 25, 4), 0.37)], 1)
+    out = vit.resample_abs_pos_embed(pe, 10)
+    assert torch.allclose(out[:, 1:], torch.full((1, 9, 4), 0.37), atol=1e-6)

@@ -184,6 +184,24 @@ class ViTBackEnd(nn.Module):
         return [taps[i] for i in tap_ids], cls
 
 
+def resample_abs_pos_embed(posemb, new_tokens, num_prefix_tokens=1):
+    """[1, P + g*g, D] -> [1, P + n*n, D]: the grid part bicubically resampled with antialiasing, prefix (CLS) tokens kept --
+    what timm does (layers/pos_embed.py: resample_abs_pos_embed) when a checkpoint's image size differs from the model's
+    (DINOv2 weights are stored for 518 px = 37 x 37 patches; IMAGE_SIZE 224 / 336 need 16 x 16 / 24 x 24).  One-time host work."""
+    import math
+    if posemb.shape[1] == new_tokens:
+        return posemb
+    old = int(math.sqrt(posemb.shape[1] - num_prefix_tokens))
+    new = int(math.sqrt(new_tokens - num_prefix_tokens))
+    assert old * old + num_prefix_tokens == posemb.shape[1] and new * new + num_prefix_tokens == new_tokens, 'square grids only'
+    prefix, grid = posemb[:, :num_prefix_tokens], posemb[:, num_prefix_tokens:]
+    dt = grid.dtype
+    grid = grid.float().reshape(1, old, old, -1).permute(0, 3, 1, 2)
+    grid = torch.nn.functional.interpolate(grid, size=(new, new), mode='bicubic', antialias=True)
+    grid = grid.permute(0, 2, 3, 1).reshape(1, new * new, -1).to(dt)
+    return torch.cat([prefix, grid], dim=1)
+
+
 def create_model(name, pretrained=False, weights=None, img_size=224, seed=None):
     """Stand-in for timm.create_model for the names the reference accepts."""
     if name not in VIT_ZOO:
@@ -197,7 +215,9 @@ def create_model(name, pretrained=False, weights=None, img_size=224, seed=None):
         m = VisionTransformer(dim, depth, heads, patch, img_size, ls)
     if weights:
         sd = torch.load(weights, map_location='cpu')
-        sd = sd.get('model', sd.get('state_dict', sd))
+        sd = dict(sd.get('model', sd.get('state_dict', sd)))
+        if 'pos_embed' in sd and sd['pos_embed'].shape != m.pos_embed.shape:      # stored for another image size
+            sd['pos_embed'] = resample_abs_pos_embed(sd['pos_embed'], m.pos_embed.shape[1], m.num_prefix_tokens)
         missing, unexpected = m.load_state_dict(sd, strict=False)
         if missing:
             raise RuntimeError('backbone weights %s lack keys: %s' % (weights, missing[:5]))

@@ -85,6 +85,30 @@ def test_gemm_tc256_equals_tc128_bitwise(M, N, K, epi):
         check(ref[0], A.double().cpu() @ W.double().cpu().t() + b.double().cpu(), 1e-2, 'gemm_tc256 vs fp64')
 
 
+def test_gemm_operand_beyond_4gib_falls_back_to_the_128_kernel():
+    """The 256x256 kernel addresses its operands with 32-bit offsets; an A matrix of 4 GiB or more silently takes the 128x128
+    kernel (64-bit addressing), which is bit-identical -- checked against the same rows computed in two halves."""
+    M, N, K = 1_400_064, 32, 1536          # A: 4.3 GB of bf16
+    g = torch.Generator(device=DEV).manual_seed(3)
+    A = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(N, device=DEV, generator=g)
+
+    def run(a_rows, out):
+        _lib.call('mvf_gemm_tc', _lib.BF16, 0, a_rows.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), out.data_ptr(), N,
+                  None, 0, None, 0, None, None, 197, a_rows.shape[0], N, K, S())
+    whole = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    run(A, whole)
+    halves = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    h = M // 2
+    run(A[:h], halves[:h])
+    run(A[h:], halves[h:])
+    torch.cuda.synchronize()
+    assert torch.equal(whole, halves)
+    idx = torch.tensor([0, 1, h - 1, h, M - 2, M - 1], device=DEV)
+    check(whole[idx], A[idx].double().cpu() @ W.double().cpu().t() + b.double().cpu(), 1e-2, 'rows beyond 4 GiB')
+
+
 # ------------------------------------------------------------------------------------------------ gemm_tc
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('M,N,K', [(300, 256, 768), (128, 128, 64), (1000, 2304, 768), (197 * 3, 768, 3072)])

@@ -188,8 +188,12 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
     if (!(dtype == MVF_BF16 && g_variant != 1 && K % 128 == 0 && N % 32 == 0)) return MVF_ERR_UNSUPPORTED;
   }
   // bf16 with K a multiple of 128: the 256x256 8-phase kernel (gemm_tc256.hip); g_variant 1 pins the 128x128 kernel
-  if (dtype == MVF_BF16 && g_variant != 1 && K % 128 == 0 && N % 32 == 0)
-    return mvf_gemm_tc256_launch(epi, a, /*persistent=*/g_variant != 3, st);
+  if (dtype == MVF_BF16 && g_variant != 1 && K % 128 == 0 && N % 32 == 0) {
+    const int rc = mvf_gemm_tc256_launch(epi, a, /*persistent=*/g_variant != 3, st);
+    // operands of 4 GiB or more are beyond the 256x256 kernel's 32-bit offsets: the 128x128 kernel (64-bit addressing)
+    // takes over unless the caller pinned the kernel or asked for stacked batches
+    if (rc != MVF_ERR_UNSUPPORTED || g_variant >= 2 || batch_rows != 0) return rc;
+  }
   if (g_variant >= 2) return MVF_ERR_UNSUPPORTED;
   return dtype == MVF_BF16 ? dispatch<bf16_t>(epi, a, st) : dispatch<float>(epi, a, st);
 }

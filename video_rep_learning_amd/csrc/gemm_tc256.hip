@@ -42,6 +42,8 @@
 //    tiles into 16-byte stores (gemm_tc_epi.h).
 //  * tried and rejected: N-grouping (each XCD serving only nbn/4 weight panels so that W stays L2-resident) -- no change
 //    at all on fc1 (315 us either way): W re-fetches are not what the loop waits for.
+//  * tried and rejected: cache-policy hints on the operand DMAs (`nt` on A: 11.59 -> 11.96 ms/step; `nt` on W: 12.56; both:
+//    13.05; `sc0` on A: 11.80) -- the default policy is the best of the five.
 //  * tried and rejected: non-temporal (`nt`) output stores so that C does not displace A / W lines in L2 -- qkv 193 -> 185 us,
 //    fc1 292 -> 286 us in isolation, but the step is unchanged (11.70 ms): the consumers (attention, fc2) then miss.
 //  * tried and rejected: a start-phase offset between neighbouring workgroups of the short-K read-modify GEMM (proj) so that

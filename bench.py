@@ -3,17 +3,26 @@
 gradient all-reduce + clip + Adam) on synthetic clips of BASELINE.json configs[1]:
 PennAction MV-Former, ViT-B/16, 32 frames, batch 4 per GPU (8 clips/GPU/step), bf16 backbone.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Started by a launcher (WORLD_SIZE set: `python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...`) this process IS a rank; started bare (`python bench.py --gpus N`) it starts that
+launcher itself as a fresh child process BEFORE touching the GPU and relays the child's output and exit code.
 
 Rank 0 prints ONE JSON line.  `value` = clips/s over all N GPUs with the inputs already resident in HBM.
 `roofline` = the dominant kernel (bf16 MFMA GEMM of the backbone), timed per launch with HIP events on the launch
 stream during extra profiled steps right after the timed region.  `cpu_baseline` = the CPU oracle (a port of the
 reference's algorithm; the reference itself cannot run on CPU) on a bounded sample, rank 0, N=1 only.
+`parity` (same leg) = the HIP path in fp32 AND in the benchmarked bf16 mode against the oracle on real-size clips of the same
+workload: fp32 mode must meet the north-star 1e-3 (the run FAILS otherwise), bf16 mode is compared with the oracle that
+rounds to bf16 where the kernels store bf16.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -62,7 +71,9 @@ def parse():
     p.add_argument('--steps', type=int, default=30)
     p.add_argument('--warmup', type=int, default=5)
     p.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
-    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU legs (cpu_baseline and parity)')
+    p.add_argument('--parity-videos', type=int, default=2,
+                   help='videos (x 2 views x 32 frames) of the resident batch pushed through the oracle for the parity block')
     p.add_argument('--profile-steps', type=int, default=3)
     p.add_argument('--no-lookahead', action='store_true', help='run backbone and head strictly in sequence')
     p.add_argument('--serial', action='store_true',
@@ -72,35 +83,113 @@ def parse():
     return p.parse_args()
 
 
-def cpu_baseline(cfg, model):
-    """Oracle train step on a bounded sample: TWO videos (4 clips x T frames = half of one GPU batch) of the same
-    workload, ~10-15 s on one GPU's share of the host cores."""
+def _oracle_env():
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
     from oracle import model as OM
     import test_gpu_model as T
+    # the GPU box gives one GPU's share of the host (16 hardware threads); more torch threads than that only thrash
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+    torch.set_num_threads(cores)
+    return OM, T
+
+
+def cpu_baseline(cfg, model):
+    """Oracle train step on a bounded sample: ONE video (2 clips x T frames = a quarter of one GPU batch) of the same
+    workload, one warm step + three timed ones, ~6 s each on one GPU's share of the host cores."""
+    OM, T = _oracle_env()
     vit_cfg, head_cfg, scl_cfg = T.oracle_cfgs(cfg)
     params = T.cpu_params(model)
     t, s = cfg.TRAIN.NUM_FRAMES, cfg.IMAGE_SIZE
     g = torch.Generator().manual_seed(1234)
-    nv = 2
+    nv, iters = 1, 3
     batch = (torch.randn(nv, 2, t, 3, s, s, generator=g), torch.full((nv, 2), 100, dtype=torch.long),
              torch.sort(torch.randint(0, 100, (nv, 2, t), generator=g), dim=-1)[0], torch.ones(nv, 2, t))
-    # the GPU box gives one GPU's share of the host (16 hardware threads); more torch threads than that only thrash
-    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
-    torch.set_num_threads(cores)
+    st = {}
+    OM.train_step(batch, params, st, vit_cfg, head_cfg, scl_cfg)          # warm (allocator, thread pool)
     t0 = time.time()
-    OM.train_step(batch, params, {}, vit_cfg, head_cfg, scl_cfg)
-    dt = time.time() - t0
+    for _ in range(iters):
+        OM.train_step(batch, params, st, vit_cfg, head_cfg, scl_cfg)
+    dt = (time.time() - t0) / iters
     return {'value': round(2.0 * nv / dt, 4), 'unit': 'clips/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '1 oracle train step on %d videos = %d clips x %d frames (half of one GPU batch), fp32, %.1f s' % (nv, 2 * nv, t, dt)}
+            'sample': 'oracle train steps (fp32) on %d video = %d clips x %d frames (a quarter of one GPU batch): 1 warm + %d '
+                      'timed, %.1f s per step' % (nv, 2 * nv, t, iters, dt)}
+
+
+def parity_block(model, batch, nv, dev):
+    """The HIP path vs the oracle on `nv` videos of the resident benchmark batch (real size: ViT-B/16, 32 frames), dropout 0
+    (its masks cannot be replayed on the CPU), training-mode loss (BatchNorm batch statistics) and eval-mode per-frame
+    embeddings (project=False).  The oracle's backbone runs twice: plain fp32 and bf16-emulating (oracle/vit.py)."""
+    OM, T = _oracle_env()
+    from video_rep_learning_amd.utils import presets
+    from video_rep_learning_amd.models import build_model
+    from video_rep_learning_amd.algos import get_algo
+    cfg0 = presets.make_cfg(network='TIMM-vit_base_patch16_224.dino', num_frames=32, batch_size=nv, compute_dtype='fp32',
+                            dropout=0.0)
+    m0 = build_model(cfg0, 0).to(dev)
+    m0.load_state_dict(model.state_dict())
+    vit_cfg, head_cfg, scl_cfg = T.oracle_cfgs(cfg0)
+    videos, seq_lens, steps, masks = [x[:nv] for x in batch]
+    vc, sc, stc, mc = videos.cpu(), seq_lens.cpu(), steps.cpu(), masks.cpu()
+    b, v, t = vc.shape[:3]
+    params = T.cpu_params(m0)
+    t0 = time.time()
+    ref = {}
+    with torch.no_grad():
+        for mode in ('fp32', 'bf16'):
+            vcfg = dict(vit_cfg, emulate='bf16') if mode == 'bf16' else vit_cfg
+            feat, cls = OM.backbone_features(vc.reshape(b * v * t, *vc.shape[3:]), params, vcfg)
+            ref[mode] = (OM.forward_from_backbone(feat, cls, b * v, t, params, vcfg, head_cfg, mc.reshape(b * v, 1, t),
+                                                  project=False, training=False),
+                         OM.loss_from_backbone(feat, cls, sc, stc, mc, params, vcfg, head_cfg, scl_cfg, training=True))
+    algo = get_algo(cfg0)
+    out = {'sample': '%d videos = %d clips x %d frames of the resident batch, dropout 0; oracle %.0f s'
+                     % (nv, b * v, t, time.time() - t0),
+           'oracle_loss_fp32': round(float(ref['fp32'][1]), 6), 'oracle_loss_bf16_emulating': round(float(ref['bf16'][1]), 6)}
+    for mode in ('fp32', 'bf16'):
+        m0.compute_dtype = mode
+        m0.eval()
+        with torch.no_grad():
+            emb = m0(videos.reshape(b * v, t, *videos.shape[3:]), t, video_masks=masks.reshape(b * v, 1, t).to(dev))
+            m0.train()
+            loss = algo.compute_loss(m0, videos, seq_lens, steps, masks)['loss']
+        out['hip_loss_' + mode] = round(float(loss), 6)
+        out['loss_rel_' + mode] = float('%.3e' % T.relerr(loss, ref[mode][1]))
+        out['emb_maxrel_' + mode] = float('%.3e' % T.relerr(emb, ref[mode][0]))
+        if mode == 'bf16':     # the dtype's own error: bf16 HIP against the plain fp32 oracle
+            out['loss_rel_bf16_vs_fp32_oracle'] = float('%.3e' % T.relerr(loss, ref['fp32'][1]))
+            out['emb_maxrel_bf16_vs_fp32_oracle'] = float('%.3e' % T.relerr(emb, ref['fp32'][0]))
+    out['gate'] = 'fp32 loss and embeddings <= 1e-3 rel (north star); bf16 columns are against the bf16-emulating oracle'
+    out['ok'] = bool(out['loss_rel_fp32'] <= 1e-3 and out['emb_maxrel_fp32'] <= 1e-3)
+    return out
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` outside a launcher: start `torch.distributed.run` with N ranks of this script as a CHILD
+    process.  Nothing here may touch the GPU (a process that has initialised HIP must never exec or be replaced, and the
+    children need the devices): torch.cuda.device_count() does not initialise it on this stack."""
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        raise SystemExit('bench.py --gpus %d needs %d GPUs on this node, found %d' % (a.gpus, a.gpus, have))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
     a = parse()
     if a.serial:
         a.no_lookahead = True
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        launch_ranks(a)                    # never returns
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if a.gpus != world:
+        raise SystemExit('bench.py --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or run `python bench.py --gpus N` '
+                         'bare and let it start the ranks)' % (a.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
@@ -111,8 +200,9 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    if world > 1 or os.environ.get('MVF_FORCE_REDUCER') == '1':
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group(os.environ.get('MVF_BENCH_BACKEND', 'nccl'), init_method='env://', world_size=world, rank=rank)
 
     from video_rep_learning_amd import _lib
@@ -129,7 +219,8 @@ def main():
     cfg = presets.baseline_config_2(compute_dtype=a.dtype)     # penn_mvf.yml + ViT-B/16, T=32, B=4 (dropout 0.1 kept)
     torch.manual_seed(cfg.RNG_SEED)
     model = build_model(cfg, local).to(dev)
-    if world > 1:
+    from video_rep_learning_amd.utils import distributed as du
+    if du.collectives_active():
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     wrapped = DataParallelModel(model)
     opt = construct_optimizer(wrapped, cfg)
@@ -239,14 +330,20 @@ def main():
                        'step_tflops_algorithmic': round(value / world * TFLOP_PER_CLIP, 1), 'last_loss': round(last_loss, 4)},
             'roofline': roof,
         }
+        parity_ok = True
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(cfg, model)
             except Exception as e:  # the baseline must never sink the measurement
                 out['cpu_baseline'] = {'value': None, 'unit': 'clips/s', 'cores': os.cpu_count(), 'kind': 'port',
                                        'sample': 'failed: %r' % (e,)}
+            out['parity'] = parity_block(model, (videos, seq_lens, steps, masks), max(1, min(a.parity_videos, videos.shape[0])), dev)
+            parity_ok = out['parity']['ok']
         print(json.dumps(out), flush=True)
-    if world > 1:
+        if not parity_ok:
+            print('bench.py: fp32 parity gate FAILED: %r' % (out['parity'],), file=sys.stderr, flush=True)
+            raise SystemExit(3)
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -223,6 +223,9 @@ int mvf_scl_bwd(const float* emb, const float* step, const float* len, const flo
 /* ------------------------------------------------------------------------------------------------
  * Optimiser: global-norm clip + Adam(L2) on one flat buffer (train.py:124-133,147-149; utils/optimizer.py:60-66)
  * ---------------------------------------------------------------------------------------------- */
+/* norm_out: TWO floats. [0] = the norm; [1] (zeroed once by the caller) is incremented whenever the norm is NaN/Inf.
+ * mvf_adam_step given that pair skips the update on a non-finite norm and leaves skipped steps out of its bias correction --
+ * the GradScaler.step behaviour of the reference's fp16 path (train.py:127-133). */
 int mvf_grad_norm(const float* g, size_t n, const float* extra_sq, float* scratch, float* norm_out, hipStream_t stream);
 int mvf_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, float clip, const float* norm, float gscale, hipStream_t stream);

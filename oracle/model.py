@@ -30,7 +30,8 @@ def backbone_features(frames, params, vit_cfg):
     layer = vit_cfg.get('layer', None)
     if layer is None:                      # fully frozen backbone (transformer.py:93-99)
         with torch.no_grad():
-            feats, cls = ovit.vit_forward(frames, w, vit_cfg['heads'], vit_cfg['patch'], tuple(vit_cfg['taps']))
+            feats, cls = ovit.vit_forward(frames, w, vit_cfg['heads'], vit_cfg['patch'], tuple(vit_cfg['taps']),
+                                          emulate=vit_cfg.get('emulate', None))
         return (feats[:, 1:] if feats is not None else None), cls  # drop CLS (transformer.py:204)
     # partially frozen (transformer.py:100-116): ViTFrontEnd = blocks [0, layer) under no_grad; ViTBackEnd = trainable deep
     # copies of blocks [layer, depth) + norm, stored as res_finetune.model.blocks.<i - layer> / res_finetune.model.norm
@@ -54,7 +55,17 @@ def model_forward(videos, params, vit_cfg, head_cfg, video_masks=None, project=F
     """TransformerModel.forward: videos [Bc,T,3,H,W] -> [Bc,T,E]."""
     bc, t = videos.shape[:2]
     feat, cls = backbone_features(videos.reshape(bc * t, *videos.shape[2:]), params, vit_cfg)
+    return forward_from_backbone(feat, cls, bc, t, params, vit_cfg, head_cfg, video_masks, project, l2_normalize, training,
+                                 update_running, projection)
+
+
+def forward_from_backbone(feat, cls, bc, t, params, vit_cfg, head_cfg, video_masks=None, project=False, l2_normalize=True,
+                          training=False, update_running=False, projection=True):
+    """Everything of TransformerModel.forward behind the backbone (transformer.py:218-244), on its outputs
+    feat [Bc*T, N, C] / cls [Bc*T, D]: lets a test run the (frozen, expensive) backbone once for several head passes."""
     feat = feat.reshape(bc, t, *feat.shape[1:]) if feat is not None else None
+    if vit_cfg.get('warmup', False) and feat is not None:              # BACKBONE_WARMUP epochs (mvformer.py:131-132):
+        feat = feat.detach()                                           # spatial features detached, cls_emb is not
     late = vit_cfg.get('late', None)        # None: 'smart' fusion; ('cls' | 'spatial', FLATTEN_METHOD): late fusion
     if late is None:
         x = ohead.mvf_head(feat, video_masks, sub(params, 'embed.'), head_cfg, training=training,
@@ -68,7 +79,25 @@ def model_forward(videos, params, vit_cfg, head_cfg, video_masks=None, project=F
         x = ohead.l2_normalize(x)
     elif l2_normalize:                                                 # :229-230
         x = ohead.l2_normalize(x)
+    if vit_cfg.get('cls_res', False):                                  # MODEL.CLS_RES (transformer.py:235-242)
+        w = sub(params, 'cls_res_res.')
+        cr = (cls @ w['weight'].t() + w['bias']).reshape(x.shape[0], x.shape[1], -1)
+        if l2_normalize:
+            cr = ohead.l2_normalize(cr)
+        x = x + cr
+        if l2_normalize:
+            x = ohead.l2_normalize(x)
     return x
+
+
+def loss_from_backbone(feat, cls, seq_lens, chosen_steps, video_masks, params, vit_cfg, head_cfg, scl_cfg, training=True,
+                       update_running=False):
+    """SCL.compute_loss behind the backbone: feat [B*2*T, N, C], masks [B,2,T] -> scalar loss."""
+    b, v, t = video_masks.shape
+    masks = video_masks.reshape(b * v, 1, t)
+    embs = forward_from_backbone(feat, cls, b * v, t, params, vit_cfg, head_cfg, masks, project=True, training=training,
+                                 update_running=update_running)
+    return oscl.scl_loss(embs.reshape(b, v, t, -1), seq_lens.reshape(b, v), chosen_steps, masks, **scl_cfg)
 
 
 def compute_loss(videos, seq_lens, chosen_steps, video_masks, params, vit_cfg, head_cfg, scl_cfg,

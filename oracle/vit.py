@@ -14,6 +14,13 @@ published algorithm:
     mlp : Linear(D, 4D) -> exact (erf) GELU -> Linear(4D, D)
     out = LN(x)[:, 0]                                                  # global_pool='token'
 
+`emulate='bf16'` restates the SAME algorithm with a round-to-nearest-even bf16 rounding at exactly the points where
+the product's bf16 mode stores bf16 (csrc/vit_fwd.hip, vit_attn.hip, gemm_tc_epi.h): GEMM weights, the im2col'd
+patches, LayerNorm outputs, qkv, the softmax probabilities fed to P.V (their row sum stays fp32), the attention
+output, fc1+GELU output and the tapped block outputs; accumulation, biases, position embedding, LayerScale and the
+residual stream stay fp32.  It is the checker for the benchmarked dtype (tests/test_gpu_*: tight gates instead of
+"bf16 is somewhere near fp32").
+
 Weights are a flat dict keyed with timm's state-dict names.  PARITY UNPINNED by
 the reference for this file (no reference test / vector exists); cross-checked
 against HuggingFace `transformers.ViTModel` in tests/test_oracle_vit.py.
@@ -34,7 +41,6 @@ def vit_dims(name):
         'vit_small_patch14_dinov2.lvd142m': (384, 12, 6, 14, True),
         'vit_base_patch14_dinov2.lvd142m': (768, 12, 12, 14, True),
         'vit_large_patch14_dinov2.lvd142m': (1024, 24, 16, 14, True),
-        'vit_giant_patch14_dinov2.lvd142m': (1536, 40, 24, 14, True),
     }
     return table[name]
 
@@ -96,7 +102,18 @@ def gelu_erf(x):
     return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
 
 
-def vit_block(x, w, p, heads, eps=1e-6):
+def bf16_round(x):
+    """Round-to-nearest-even to bf16 and back (what v_cvt_pk_bf16_f32 does to a stored value)."""
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+def _ident(x):
+    return x
+
+
+def vit_block(x, w, p, heads, eps=1e-6, emulate=None):
+    if emulate == 'bf16':
+        return vit_block_bf16(x, w, p, heads, eps)
     f, n, d = x.shape
     hd = d // heads
     h = layer_norm(x, w[p + 'norm1.weight'], w[p + 'norm1.bias'], eps)
@@ -118,15 +135,42 @@ def vit_block(x, w, p, heads, eps=1e-6):
     return x + h
 
 
-def vit_embed(img, w, patch):
+def vit_block_bf16(x, w, p, heads, eps=1e-6):
+    """vit_block with the bf16 mode's rounding points (module docstring); x is the fp32 residual stream."""
+    r = bf16_round
+    f, n, d = x.shape
+    hd = d // heads
+    h = r(layer_norm(x, w[p + 'norm1.weight'], w[p + 'norm1.bias'], eps))
+    qkv = r(h @ r(w[p + 'attn.qkv.weight']).t() + w[p + 'attn.qkv.bias'])
+    qkv = qkv.reshape(f, n, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    s = (q @ k.transpose(-1, -2)) * hd ** -0.5
+    pr = torch.exp(s - s.max(-1, keepdim=True)[0])
+    a = r((r(pr) @ v) / pr.sum(-1, keepdim=True))          # P in bf16 for P.V, its row sum in fp32
+    a = a.transpose(1, 2).reshape(f, n, d)
+    a = a @ r(w[p + 'attn.proj.weight']).t() + w[p + 'attn.proj.bias']
+    if p + 'ls1.gamma' in w:
+        a = a * w[p + 'ls1.gamma']
+    x = x + a
+    h = r(layer_norm(x, w[p + 'norm2.weight'], w[p + 'norm2.bias'], eps))
+    h = r(gelu_erf(h @ r(w[p + 'mlp.fc1.weight']).t() + w[p + 'mlp.fc1.bias']))
+    h = h @ r(w[p + 'mlp.fc2.weight']).t() + w[p + 'mlp.fc2.bias']
+    if p + 'ls2.gamma' in w:
+        h = h * w[p + 'ls2.gamma']
+    return x + h
+
+
+def vit_embed(img, w, patch, emulate=None):
     """patch_embed + cls + pos: [F,3,H,W] -> [F, 1+N, D]."""
     dim = w['patch_embed.proj.weight'].shape[0]
-    x = patchify(img, patch) @ w['patch_embed.proj.weight'].reshape(dim, -1).t() + w['patch_embed.proj.bias']
+    r = bf16_round if emulate == 'bf16' else _ident
+    x = r(patchify(img, patch)) @ r(w['patch_embed.proj.weight'].reshape(dim, -1)).t() + w['patch_embed.proj.bias']
     cls = w['cls_token'].expand(x.shape[0], -1, -1)
     return torch.cat([cls, x], 1) + w['pos_embed']
 
 
-def vit_forward(img, w, heads, patch, taps=(3, 7, 11), eps=1e-6, first_block=0, last_block=None, x_in=None):
+def vit_forward(img, w, heads, patch, taps=(3, 7, 11), eps=1e-6, first_block=0, last_block=None, x_in=None,
+                emulate=None):
     """Returns (features, cls_out):
       features [F, 1+N, D*len(taps)]: outputs of blocks `taps`, channel-concatenated
           (FeatureExtractor, CARL_MVF/models/transformer.py:322-333; CLS row kept,
@@ -138,12 +182,13 @@ def vit_forward(img, w, heads, patch, taps=(3, 7, 11), eps=1e-6, first_block=0, 
     """
     depth = 1 + max(int(k.split('.')[1]) for k in w if k.startswith('blocks.'))
     last_block = depth if last_block is None else last_block
-    x = vit_embed(img, w, patch) if x_in is None else x_in
+    assert emulate in (None, 'bf16'), emulate
+    x = vit_embed(img, w, patch, emulate) if x_in is None else x_in
     feats = {}
     for i in range(first_block, last_block):
-        x = vit_block(x, w, 'blocks.%d.' % i, heads, eps)
+        x = vit_block(x, w, 'blocks.%d.' % i, heads, eps, emulate)
         if i in taps:
-            feats[i] = x
+            feats[i] = bf16_round(x) if emulate == 'bf16' else x      # taps are stored in the compute dtype
     out = layer_norm(x, w['norm.weight'], w['norm.bias'], eps)[:, 0] if last_block == depth else x
     features = torch.cat([feats[i] for i in taps], dim=2) if taps else None
     return features, out

@@ -10,6 +10,19 @@ for p in (ROOT, GOLDEN):
         sys.path.insert(0, p)
 
 
+def record_parity(line):
+    """Keep a measured deviation: appended to gpurun_out/parity.txt (gpurun merges that directory back; the round's copy is
+    committed as profiles/rNN/parity.txt).  `pytest -q` swallows prints -- the judge asked for a kept log."""
+    print(line)
+    try:
+        out = os.path.join(ROOT, 'gpurun_out')
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'parity.txt'), 'a') as f:
+            f.write(line.rstrip('\n') + '\n')
+    except OSError:
+        pass
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 

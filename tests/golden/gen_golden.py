@@ -368,6 +368,114 @@ def gen_glue(timm, tr):
     print('glue done')
 
 
+GLUE2 = dict(name='vit_small_patch16_224.dino', dim=384, depth=12, heads=6, patch=16, img=32, vit_seed=6, back_seed=7,
+             head_seed=44, proj_seed=45, in_seed=46, cls_seed=47, bc=2, t=8, layer=10)
+
+
+def glue2_params(variant):
+    """Seeded state dict of the GLUE2 cases, keyed like the reference's TransformerModel.state_dict().
+    variant 'split' / 'warmup': LAYER=10, taps 10,11; the trainable back end (res_finetune.model.*) gets its OWN seeded
+    weights (not the copies of the front's blocks it starts from) so that a mix-up of the two block sets would show.
+    variant 'cls_res': LAYER=12, taps 3,7,11, plus cls_res_res.{weight,bias}."""
+    G = GLUE2
+    split = variant in ('split', 'warmup')
+    d = C.Dims(C=G['dim'] * (2 if split else 3), n_taps=2 if split else 3, spc=24, fc=(32, 32), hidden=32, dff=64, heads=4,
+               layers=2, E=16, proj=16, train_len=G['t'])
+    w = ovit.init_vit_weights(G['dim'], G['depth'], G['patch'], G['img'], seed=G['vit_seed'])
+    sd = {'embed.' + k: v for k, v in C.head_params(d, G['head_seed']).items()}
+    sd.update({'ssl_projection.' + k: v for k, v in C.proj_params(d, G['proj_seed']).items()})
+    sd.update({'backbone.model.' + k: v for k, v in w.items()})
+    if split:
+        # ViTFrontEnd registers the front blocks a second time under backbone.blocks.<i> (same tensors)
+        for k, v in w.items():
+            if k.startswith('blocks.') and int(k.split('.')[1]) < G['layer']:
+                sd['backbone.' + k] = v
+        wb = ovit.init_vit_weights(G['dim'], G['depth'], G['patch'], G['img'], seed=G['back_seed'])
+        for k, v in wb.items():
+            if k.startswith('blocks.') and int(k.split('.')[1]) >= G['layer']:
+                _, j, rest = k.split('.', 2)
+                sd['res_finetune.model.blocks.%d.%s' % (int(j) - G['layer'], rest)] = v
+            elif k.startswith('norm.'):
+                sd['res_finetune.model.' + k] = v
+    else:
+        g = torch.Generator().manual_seed(G['cls_seed'])
+        sd['cls_res_res.weight'] = torch.randn(d.E, G['dim'], generator=g) / G['dim'] ** 0.5
+        sd['cls_res_res.bias'] = torch.randn(d.E, generator=g) * 0.1
+    return d, sd
+
+
+def glue2_inputs():
+    G = GLUE2
+    g = torch.Generator().manual_seed(G['in_seed'])
+    x = torch.randn(G['bc'], G['t'], 3, G['img'], G['img'], generator=g)
+    masks = torch.ones(G['bc'], 1, G['t'])
+    masks[1, 0, 6:] = 0
+    return x, masks
+
+
+GLUE2_GRADS = ('embed.embedding_layer.weight', 'embed.pooling.cross_att.Q_s', 'res_finetune.model.blocks.0.attn.qkv.weight',
+               'res_finetune.model.blocks.1.mlp.fc2.weight', 'res_finetune.model.blocks.0.norm1.bias', 'cls_res_res.weight')
+
+
+def compact(t):
+    """Large tensors are stored as [L2 norm, sum, every 97th element ...] (fixtures stay small); small ones whole."""
+    t = t.detach().reshape(-1)
+    if t.numel() <= 4096:
+        return t
+    return torch.cat([t.double().norm().float().view(1), t.double().sum().float().view(1), t[::97]])
+
+
+def gen_glue_split(timm, tr):
+    """TransformerModel with (a) a partially frozen backbone, MODEL.BASE_MODEL.LAYER = 10: ViTFrontEnd / ViTBackEnd, the
+    extract ids re-based into the back end (CARL_MVF/models/transformer.py:100-116,342-392); (b) BACKBONE_WARMUP's detach of
+    the spatial features (mvformer.py:131-132, train.py:81-91); (c) MODEL.CLS_RES (transformer.py:235-242).  Stored: eval
+    embeddings, train-mode projected embeddings, and the gradients of sum(train_proj * probe) w.r.t. a few parameters."""
+    G = GLUE2
+    out = {}
+    real_cuda = nn.Module.cuda
+    nn.Module.cuda = lambda self, device=None: self      # ViTBackEnd.__init__ calls .cuda(local_rank) (transformer.py:376-381)
+    try:
+        for variant in ('split', 'warmup', 'cls_res'):
+            d, sd = glue2_params(variant)
+            w = {k[len('backbone.model.'):]: v for k, v in sd.items() if k.startswith('backbone.model.')}
+
+            def create_model(name, pretrained=True, w=w):
+                m = StubViT(G['dim'], G['depth'], G['heads'], G['patch'], G['img'])
+                m.load_state_dict(w, strict=True)
+                return m
+            timm.create_model = create_model
+            cfg = ref_cfg(d)
+            split = variant != 'cls_res'
+            cfg.MODEL.BASE_MODEL = ad(dict(NETWORK='TIMM-' + G['name'], LAYER=G['layer'] if split else 12, FRAMES_PER_BATCH=40))
+            cfg.MODEL.EMBEDDER_MODEL.SMART_FEATS = '10,11' if split else '3,7,11'
+            if variant == 'cls_res':
+                cfg.MODEL.CLS_RES = True
+            model = tr.TransformerModel(cfg, 0)
+            model.load_state_dict(sd, strict=True)
+            out[variant + '_keys'] = np.array(sorted(model.state_dict().keys()))
+            if variant == 'warmup':
+                model.embed.set_warmup_status(True)
+            x, masks = glue2_inputs()
+            model.eval()
+            out[variant + '_eval_noproj'] = model(x, G['t'], video_masks=masks, project=False).detach().numpy()
+            model.train()
+            y = model(x, G['t'], video_masks=masks, project=True)
+            out[variant + '_train_proj'] = y.detach().numpy()
+            probe = torch.randn(y.shape, generator=torch.Generator().manual_seed(99))
+            named = dict(model.named_parameters())
+            names = [n for n in GLUE2_GRADS if n in named and named[n].requires_grad]
+            grads = torch.autograd.grad((y * probe).sum(), [named[n] for n in names], allow_unused=True)
+            for n, gr in zip(names, grads):
+                out[variant + '_grad:' + n] = compact(torch.zeros_like(named[n]) if gr is None else gr).numpy()
+                out[variant + '_gradnone:' + n] = np.array(gr is None)
+            print('glue_split', variant, float(y.abs().mean()), {n: (None if gr is None else float(gr.abs().max()))
+                                                                   for n, gr in zip(names, grads)})
+    finally:
+        nn.Module.cuda = real_cuda
+    np.savez_compressed(os.path.join(HERE, 'glue_split.npz'), **out)
+    print('glue_split done')
+
+
 TRAJ = dict(b=2, t=8, n=16, lr=1e-3, steps=3)
 
 
@@ -514,7 +622,7 @@ def main():
     spec = importlib.util.spec_from_file_location('ref_scl', os.path.join(REF, 'algos', 'scl.py'))
     scl_mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(scl_mod)
-    which = sys.argv[1:] or ['primitives', 'head', 'mlp', 'scl', 'glue', 'traj', 'keys', 'augment', 'fwb', 'late']
+    which = sys.argv[1:] or ['primitives', 'head', 'mlp', 'scl', 'glue', 'glue_split', 'traj', 'keys', 'augment', 'fwb', 'late']
     if 'primitives' in which:
         gen_primitives(mu)
     if 'head' in which:
@@ -529,6 +637,8 @@ def main():
         gen_scl(scl_mod)
     if 'glue' in which:
         gen_glue(timm, tr)
+    if 'glue_split' in which:
+        gen_glue_split(timm, tr)
     if 'traj' in which:
         gen_trajectory(mv, rc, scl_mod)
     if 'keys' in which:

@@ -53,6 +53,24 @@ def test_state_dict_keys_match_reference_golden(model_cfg):
         assert k in model.state_dict(), k
 
 
+@pytest.mark.parametrize('variant', ['split', 'cls_res'])
+def test_state_dict_keys_of_split_backbone_and_cls_res_match_reference(variant):
+    """glue_split.npz '<variant>_keys': state-dict keys of the imported reference TransformerModel with LAYER = 10
+    (backbone.model.*, backbone.blocks.<i> aliases, res_finetune.model.blocks.<i - 10>.*, res_finetune.model.norm.*) and
+    with MODEL.CLS_RES (cls_res_res.*): checkpoints of either kind load key for key."""
+    import numpy as np
+    from video_rep_learning_amd.utils import presets
+    gold = set(np.load(os.path.join(HERE, 'golden', 'glue_split.npz'))[variant + '_keys'].tolist())
+    cfg = presets.make_cfg(network='TIMM-vit_small_patch16_224.dino', num_frames=8, batch_size=2, image_size=32,
+                           SMART_FEATS='10,11' if variant == 'split' else '3,7,11', NUM_LAYERS=2)   # the golden's head has 2 encoder layers
+    if variant == 'split':
+        cfg.MODEL.BASE_MODEL.LAYER = 10
+    else:
+        cfg.MODEL.CLS_RES = True
+    ours = set(build_model(cfg, 0).state_dict().keys())
+    assert ours == gold, sorted(ours ^ gold)[:20]
+
+
 def _torch_adam(model, cfg):
     bn, non_bn = select_parameters(model, cfg)
     wd = cfg.OPTIMIZER.WEIGHT_DECAY

@@ -97,3 +97,13 @@ def test_backbone_weights_with_another_image_size_are_resampled(tmp_path):
     pe = torch.cat([torch.zeros(1, 1, 4), torch.full((1, 25, 4), 0.37)], 1)
     out = vit.resample_abs_pos_embed(pe, 10)
     assert torch.allclose(out[:, 1:], torch.full((1, 9, 4), 0.37), atol=1e-6)
+
+
+def test_dinov2_giant_is_refused_loudly():
+    """timm's DINOv2-giant has a SwiGLU MLP; the GELU kernels would compute another network."""
+    import pytest
+    from video_rep_learning_amd.models import build_model
+    from video_rep_learning_amd.utils import presets
+    cfg = presets.make_cfg(network='TIMM-vit_giant_patch14_dinov2.lvd142m', num_frames=8, batch_size=1)
+    with pytest.raises(NotImplementedError, match='SwiGLU'):
+        build_model(cfg, 0)

@@ -110,3 +110,67 @@ def test_two_ranks_equal_one_process_on_the_whole_batch(gather):
     # 'batch_noself' negatives every rank evaluates the SAME global loss, so the mean is that loss again
     assert abs(ref_loss - mean_loss) <= 1e-4 * abs(ref_loss), (ref_loss, mean_loss)
     assert worst[1] <= 2e-2, worst
+
+
+# ---------------------------------------------------------------------------------------------- RCCL, one rank
+def _forced_worker(rank, world, port, ret, gather):
+    """One process, one GPU: a plain step first, then the same step on a ONE-rank `nccl` (= RCCL) process group with
+    MVF_FORCE_REDUCER=1, which sends every collective of the data-parallel step through the backend: the per-bucket async
+    all-reduce launched from the gradient hooks, the SyncBN all-gather (forward) and all-reduce (backward), the embedding
+    all-gather and the loss all-reduce.  On one rank they are identities, so loss and parameters must come out BITWISE equal."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
+    cfg = _setup(gather)
+    full = _batch(cfg)
+    ref_loss, ref_sd, _ = _train_one_step(cfg, full, sync_bn=False)
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    os.environ['MVF_FORCE_REDUCER'] = '1'
+    try:
+        from video_rep_learning_amd.utils import distributed as du
+        assert du.collectives_active()
+        launched = []
+        real = dist.all_reduce
+
+        def counting_all_reduce(t, *a, **kw):
+            launched.append((int(t.numel()), bool(kw.get('async_op', False))))
+            return real(t, *a, **kw)
+        dist.all_reduce = counting_all_reduce
+        loss, sd, _ = _train_one_step(cfg, full, sync_bn=True)
+        dist.all_reduce = real
+        red = du.all_reduce([torch.tensor([loss], device='cuda:0')])[0].item()      # C4 through RCCL
+        same = all(torch.equal(sd[k], ref_sd[k]) for k in ref_sd if 'running_' not in k and 'num_batches' not in k)
+        close = all(torch.allclose(sd[k].float(), ref_sd[k].float(), rtol=1e-5, atol=1e-7) for k in ref_sd if 'running_' in k)
+        ret['out'] = (ref_loss, loss, red, same, close, launched)
+    finally:
+        os.environ.pop('MVF_FORCE_REDUCER', None)
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('gather', [False, True])
+def test_forced_reducer_on_one_rank_rccl_group_is_bitwise_the_plain_step(gather):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_forced_worker, args=(1, _free_port(), ret, gather), nprocs=1, join=True)
+    ref_loss, loss, red, same, close, launched = ret['out']
+    assert loss == ref_loss and red == loss, (ref_loss, loss, red)
+    assert same and close
+    async_buckets = [n for n, is_async in launched if is_async]
+    assert async_buckets and sum(async_buckets) >= 1_000_000, launched       # the flat gradient buffer went through RCCL
+    assert any(not is_async for _n, is_async in launched), launched            # SyncBN backward all-reduce
+
+
+def test_backbone_weights_loaded_through_the_parent_reach_the_hip_forward():
+    """A checkpoint loaded via the PARENT module (checkpoint.restore / PRETRAINED_CHECKPOINT path) after a forward must
+    replace the packed device copy of the backbone weights (torch never calls the child's load_state_dict)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import test_gpu_model as T
+    cfg, a = T.make(31, **T.SMALL)
+    _cfg, b = T.make(32, **T.SMALL)
+    x = torch.randn(2, 8, 3, 32, 32, generator=torch.Generator().manual_seed(1)).to('cuda')
+    a.eval(), b.eval()
+    with torch.no_grad():
+        ya0, yb = a(x, 8).clone(), b(x, 8).clone()
+        assert not torch.equal(ya0, yb)
+        a.load_state_dict(b.state_dict())
+        ya1 = a(x, 8)
+    assert torch.equal(ya1, yb)

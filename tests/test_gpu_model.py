@@ -43,6 +43,10 @@ def oracle_cfgs(cfg):
     layer = cfg.MODEL.BASE_MODEL.LAYER
     if 0 <= layer < depth:             # partially frozen backbone
         vit_cfg['layer'] = layer
+    if 'CLS_RES' in cfg.MODEL and cfg.MODEL.CLS_RES:
+        vit_cfg['cls_res'] = True
+    if 'BACKBONE_WARMUP' in cfg.TRAIN:  # the model starts in warm-up (mvformer.py:113-115); train.train switches it per epoch
+        vit_cfg['warmup'] = True
     head_cfg = OH.HeadCfg(nst=em.SMART_TOKENS, nsdt=em.get('SMART_DYNAMIC_TOKENS', 0), spc=em.get('SMART_POOL_CHANNELS', 384),
                           one_hot=em.get('SMART_ONE_HOT', 'none'), smart_final=em.get('SMART_FINAL', 'max'),
                           num_heads=em.NUM_HEADS, num_layers=em.NUM_LAYERS, train_len=cfg.TRAIN.NUM_FRAMES,
@@ -54,10 +58,12 @@ def oracle_cfgs(cfg):
     return vit_cfg, head_cfg, scl_cfg
 
 
-def make(seed=0, layer=None, **kw):
+def make(seed=0, layer=None, edit=None, **kw):
     cfg = presets.make_cfg(**kw)
     if layer is not None:
         cfg.MODEL.BASE_MODEL.LAYER = layer
+    if edit is not None:
+        edit(cfg)
     torch.manual_seed(seed)
     model = build_model(cfg, 0)
     # de-trivialise: timm-style init leaves LN at identity and biases at 0; jitter everything a little
@@ -98,7 +104,8 @@ SMALL = dict(network='TIMM-vit_small_patch16_224.dino', num_frames=8, batch_size
 # fg99 / long64 / dinov2: the head and sequence shapes of BASELINE configs[2], [3] and [4] at a small image size
 @pytest.mark.parametrize('variant', ['base', 'avg_enc_nst6', 'max_none', 'lin', 'dynamic', 'disjoint', 'batch_neg', 'fg99',
                                      'long64', 'dinov2', 'fwb', 'partial', 'partial_dinov2', 'late_cls',
-                                     'late_spatial_max', 'late_spatial_avg', 'late_cls_partial', 'ln_keys'])
+                                     'late_spatial_max', 'late_spatial_avg', 'late_cls_partial', 'ln_keys', 'cls_res',
+                                     'warmup', 'cls_res_partial'])
 def test_small_model_loss_and_grads(variant):
     kw = dict(SMALL)
     if variant == 'avg_enc_nst6':
@@ -133,8 +140,22 @@ def test_small_model_loss_and_grads(variant):
         kw.update(FUSION_TYPE='late', LAYER=10)
     elif variant == 'partial_dinov2':   # the same with LayerScale blocks and a patch-14 front end
         kw.update(network='TIMM-vit_small_patch14_dinov2.lvd142m', image_size=28, SMART_FEATS='9,11', LAYER=9)
+    edit = None
+    if variant == 'cls_res':                # MODEL.CLS_RES (transformer.py:235-242): + normalize(Linear(cls_emb)), re-normalised
+        def edit(c):
+            c.MODEL.CLS_RES = True
+    elif variant == 'cls_res_partial':      # ... with trainable last blocks: the CLS embedding carries a gradient
+        kw.update(SMART_FEATS='10,11', LAYER=10)
+
+        def edit(c):
+            c.MODEL.CLS_RES = True
+    elif variant == 'warmup':               # TRAIN.BACKBONE_WARMUP (train.py:81-91, mvformer.py:131-132): spatial features
+        kw.update(SMART_FEATS='10,11', LAYER=10)      # detached -> no gradient reaches the trainable blocks
+
+        def edit(c):
+            c.TRAIN.BACKBONE_WARMUP = 5
     layer = kw.pop('LAYER', None)
-    cfg, model = make(3, layer=layer, **kw)
+    cfg, model = make(3, layer=layer, edit=edit, **kw)
     if variant == 'batch_neg':
         cfg.SCL.NEGATIVE_TYPE = 'batch_noself'
     vit_cfg, head_cfg, scl_cfg = oracle_cfgs(cfg)
@@ -257,14 +278,36 @@ def test_full_size_vitb16_fp32_and_bf16():
     e = relerr(loss, lref)
     print('ViT-B/16 fp32 SCL loss %.6f vs oracle %.6f (rel %.3e)' % (loss.item(), lref.item(), e))
     assert e <= 1e-3
-    # bf16 backbone: report (not gate) its deviation from the fp32 oracle
+    # bf16 backbone (the benchmarked dtype): gated against the oracle that rounds where the kernels store bf16; its deviation
+    # from the fp32 oracle is the dtype's own error and is reported
+    from conftest import record_parity
+    vc16 = dict(vit_cfg, emulate='bf16')
+    ref16 = OM.model_forward(x, cpu_params(model), vc16, head_cfg, masks.view(2, 1, 4), project=False, training=False)
+    p64 = cpu_params(model)
+    leaves = {k: p64[k].clone().requires_grad_(True) for k in OM.trainable_names(p64)}
+    pl = dict(p64)
+    pl.update(leaves)
+    lref16 = OM.compute_loss(videos, seq_lens, steps, masks, pl, vc16, head_cfg, scl_cfg, training=True)
+    lref16.backward()
     model.compute_dtype = 'bf16'
     model.eval()
     with torch.no_grad():
         emb16 = model(x.to(DEV), 4, video_masks=masks.view(2, 1, 4).to(DEV))
-    e16 = relerr(emb16, ref)
-    print('ViT-B/16 bf16 embeddings max-rel err vs fp32 oracle: %.3e' % e16)
-    assert e16 < 0.1
+    model.train()
+    model.zero_grad()
+    loss16 = get_algo(cfg).compute_loss(model, videos.to(DEV), seq_lens, steps, masks)['loss']
+    loss16.backward()
+    e16, e16o = relerr(emb16, ref16), relerr(emb16, ref)
+    el = relerr(loss16, lref16)
+    gscale = max(v.grad.abs().max().item() for v in leaves.values() if v.grad is not None)
+    worst = max((((p.grad.double().cpu() - leaves[n].grad.double()).abs().max().item()
+                  / max(leaves[n].grad.abs().max().item(), 1e-2 * gscale)), n)
+                for n, p in model.named_parameters() if n in leaves and leaves[n].grad is not None and p.grad is not None)
+    record_parity('ViT-B/16 T=4 B=1 HIP bf16: embeddings max-rel %.3e vs bf16-emulating oracle (%.3e vs fp32 oracle); SCL loss '
+                  '%.6f vs %.6f rel %.3e; worst head-gradient rel %.3e (%s)' % (e16, e16o, loss16.item(), lref16.item(), el,
+                                                                               worst[0], worst[1]))
+    assert e16 <= 2e-2 and el <= 5e-3 and worst[0] <= 5e-2, (e16, el, worst)
+    assert e16o < 0.1
 
 
 @pytest.mark.parametrize('partial', [False, True])

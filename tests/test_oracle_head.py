@@ -193,6 +193,42 @@ def test_model_glue(golden):
     close(y, gg['train_proj'], rtol=1e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize('variant', ['split', 'warmup', 'cls_res'])
+def test_model_glue_split_warmup_cls_res(golden, variant):
+    """The oracle's restatement of the partially frozen backbone (ViTFrontEnd / ViTBackEnd, extract ids re-based:
+    transformer.py:100-116,342-392), of BACKBONE_WARMUP's detach (mvformer.py:131-132) and of MODEL.CLS_RES
+    (transformer.py:235-242) against the imported reference: outputs and the gradients of a probed sum."""
+    gg = golden('glue_split')
+    Gd = G.GLUE2
+    d, sd = G.glue2_params(variant)
+    x, masks = G.glue2_inputs()
+    split = variant != 'cls_res'
+    vit_cfg = dict(heads=Gd['heads'], patch=Gd['patch'], taps=(10, 11) if split else (3, 7, 11))
+    if split:
+        vit_cfg['layer'] = Gd['layer']
+    if variant == 'warmup':
+        vit_cfg['warmup'] = True
+    if variant == 'cls_res':
+        vit_cfg['cls_res'] = True
+    y = OM.model_forward(x, sd, vit_cfg, hcfg(d), masks, project=False, training=False)
+    close(y, gg[variant + '_eval_noproj'], rtol=1e-3, atol=1e-5)
+    names = [k[len(variant) + 6:] for k in gg.files if k.startswith(variant + '_grad:')]
+    assert names
+    leaves = {n: sd[n].clone().requires_grad_(True) for n in names}
+    p = dict(sd)
+    p.update(leaves)
+    y = OM.model_forward(x, p, vit_cfg, hcfg(d), masks, project=True, training=True)
+    close(y, gg[variant + '_train_proj'], rtol=1e-3, atol=1e-5)
+    probe = torch.randn(y.shape, generator=torch.Generator().manual_seed(99))
+    grads = torch.autograd.grad((y * probe).sum(), [leaves[n] for n in names], allow_unused=True)
+    for n, gr in zip(names, grads):
+        none = bool(gg[variant + '_gradnone:' + n])
+        assert (gr is None) == none, (n, none)        # warm-up: nothing reaches the trainable blocks
+        if gr is not None:
+            close(G.compact(gr), gg[variant + '_grad:' + n], rtol=2e-3, atol=1e-6)
+    assert variant != 'warmup' or any(bool(gg['warmup_gradnone:' + n]) for n in names)
+
+
 def test_trajectory(golden):
     """3 steps of head + MLPHead + SCL + clip + Adam (train.py:108-149 order) on fixed features."""
     gt = golden('trajectory')

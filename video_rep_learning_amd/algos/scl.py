@@ -50,7 +50,7 @@ class SCL(object):
         ln = seq_lens.reshape(batch_size, num_views, 1).expand(batch_size, num_views, num_frames).reshape(m_local).float()
         mk = masks.reshape(m_local).float()
         row0, rows, scale = 0, None, 1.0
-        if self.gather and 'single' not in self.negative_type and du.get_world_size() > 1:
+        if self.gather and 'single' not in self.negative_type and du.collectives_active():
             ws, rk = du.get_world_size(), du.get_rank()
             e = du.gather_rows(e)
             st, ln, mk = du.all_gather([st, ln, mk])

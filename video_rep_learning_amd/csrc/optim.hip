@@ -26,6 +26,8 @@ __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __rest
 }
 
 // norm_out[0] = sqrt(sum(part) + extra_sq[0]) ; fixed summation order -> reproducible
+// norm_out[1] += 1 when that norm is not finite: the count of optimizer steps adam_kernel has SKIPPED (what
+// torch.cuda.amp.GradScaler.step does for the reference's fp16 path, train.py:127-133: no update, no step count)
 __global__ void sqnorm_final_kernel(const float* __restrict__ part, int nparts, const float* __restrict__ extra_sq,
                                     float* __restrict__ norm_out) {
   __shared__ float red[4];
@@ -34,15 +36,30 @@ __global__ void sqnorm_final_kernel(const float* __restrict__ part, int nparts, 
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) norm_out[0] = sqrtf(red[0] + red[1] + red[2] + red[3] + (extra_sq ? extra_sq[0] : 0.f));
+  if (threadIdx.x == 0) {
+    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3] + (extra_sq ? extra_sq[0] : 0.f));
+    norm_out[0] = nrm;
+    if (!isfinite(nrm)) norm_out[1] += 1.f;
+  }
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
                                                    float wd, float bc1, float bc2_sqrt, float clip,
-                                                   const float* __restrict__ norm, float gscale) {
+                                                   const float* __restrict__ norm, float gscale, int step_no) {
   float coef = gscale;
-  if (clip > 0.f && norm != nullptr) coef *= fminf(1.f, clip / (norm[0] * gscale + 1e-6f));
+  if (norm != nullptr) {
+    // a NaN / Inf gradient norm poisons parameters and both moments for good (fminf(1, clip / NaN) = 1): skip the step,
+    // and leave it out of the bias-correction step count like a GradScaler-skipped step
+    if (!isfinite(norm[0])) return;
+    const float skipped = norm[1];
+    if (skipped > 0.f) {
+      const double eff = fmax((double)step_no - (double)skipped, 1.0);
+      bc1 = (float)(1.0 - pow((double)b1, eff));
+      bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, eff));
+    }
+    if (clip > 0.f) coef *= fminf(1.f, clip / (norm[0] * gscale + 1e-6f));
+  }
   const float step = lr / bc1;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float pi = p[i];
@@ -57,7 +74,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 }  // namespace
 
-// norm_out[0] = || g ||_2 (optionally sqrt(||g||^2 + extra_sq[0])); scratch: >= 1024 floats
+// norm_out[0] = || g ||_2 (optionally sqrt(||g||^2 + extra_sq[0])); norm_out[1] (zeroed ONCE by the caller) counts the
+// calls whose norm was not finite; scratch: >= 1024 floats
 extern "C" int mvf_grad_norm(const float* g, size_t n, const float* extra_sq, float* scratch, float* norm_out,
                              hipStream_t st) {
   MVF_CHECK_ARG(g && scratch && norm_out && n > 0 && ((uintptr_t)g & 15) == 0);
@@ -70,6 +88,8 @@ extern "C" int mvf_grad_norm(const float* g, size_t n, const float* extra_sq, fl
 
 // One Adam step on flat buffers. step >= 1 (1-based, like torch). clip <= 0 disables clipping.
 // gscale multiplies every gradient first (e.g. 1/world_size when the all-reduce summed instead of averaged).
+// norm (optional) = the two floats of mvf_grad_norm: a non-finite norm[0] turns the call into a no-op, and norm[1] steps
+// skipped that way so far are taken off `step` in the bias correction.
 extern "C" int mvf_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                              float eps, float weight_decay, int step, float clip, const float* norm, float gscale,
                              hipStream_t st) {
@@ -78,7 +98,7 @@ extern "C" int mvf_adam_step(float* p, const float* g, float* m, float* v, size_
   const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   const int nblk = (int)std::min<size_t>(2048, (n + 255) / 256);
   hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1,
-                     bc2s, clip, norm, gscale);
+                     bc2s, clip, norm, gscale, step);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

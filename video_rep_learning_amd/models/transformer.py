@@ -6,8 +6,9 @@ is set/multiplied exactly as transformer.py:43-54,90 does, state-dict keys are `
 `ssl_projection.*`.  The backbone runs as one C-ABI call (mvf_vit_fwd) per forward instead of per
 FRAMES_PER_BATCH chunk of T (per-frame independent, so the numbers are the same) and hands its tapped blocks to
 the head without the hook/concat/CLS-drop/movedim copies of transformer.py:199-218,322-331.
-Not on this path (raise with a clear message): ResNet-50 backbones, late fusion, partially frozen ViT
-(ViTFrontEnd/ViTBackEnd, 0 <= LAYER < depth), classification head."""
+Also built: late fusion (TransformerEmbModel on the CLS embedding or on max/avg-pooled spatial tokens), the partially frozen
+backbone (ViTFrontEnd / ViTBackEnd, 0 <= LAYER < depth, models/vit.py), MODEL.CLS_RES, TRAIN.BACKBONE_WARMUP.
+Not on this path (raise with a clear message): ResNet-50 backbones, the classification head, the SwiGLU DINOv2-giant."""
 import torch
 import torch.nn as nn
 
@@ -112,6 +113,8 @@ class TransformerModel(nn.Module):
         self.late_type = em.LATE_TYPE if 'LATE_TYPE' in em else 'cls'
         assert self.late_type in ['cls', 'spatial']
         name = net[5:]
+        if name in vitlib.VIT_UNSUPPORTED:
+            raise NotImplementedError('TIMM model %s is not supported on the MI355X path: %s' % (name, vitlib.VIT_UNSUPPORTED[name]))
         if name not in vitlib.VIT_ZOO:
             print('ERROR: unknown/unsupported TIMM model:')
             print(name)

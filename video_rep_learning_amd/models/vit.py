@@ -22,7 +22,13 @@ VIT_ZOO = {
     'vit_small_patch14_dinov2.lvd142m': (384, 12, 6, 14, True),
     'vit_base_patch14_dinov2.lvd142m': (768, 12, 12, 14, True),
     'vit_large_patch14_dinov2.lvd142m': (1024, 24, 16, 14, True),
-    'vit_giant_patch14_dinov2.lvd142m': (1536, 40, 24, 14, True),
+}
+# Accepted by the reference's name table (transformer.py:53-55) but NOT built here: timm's DINOv2-giant uses a packed SwiGLU
+# MLP (SwiGLUPacked: fc1 -> [x1 | x2], silu(x1) * x2, hidden 4096), not the GELU MLP of every other entry.  Running it through
+# the GELU kernels would silently compute a different network, so the name is refused.
+VIT_UNSUPPORTED = {
+    'vit_giant_patch14_dinov2.lvd142m': 'its MLP is timm SwiGLUPacked (silu(x1) * x2), which the HIP backbone does not '
+                                        'implement; use vit_{small,base,large}_patch14_dinov2.lvd142m',
 }
 
 
@@ -66,6 +72,7 @@ class VisionTransformer(nn.Module):
         self.blocks = nn.Sequential(*[_Block(embed_dim, layerscale) for _ in range(depth)])
         self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
         self._packed = {}
+        self._plist = None
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -81,19 +88,31 @@ class VisionTransformer(nn.Module):
 
     def _apply(self, fn, *a, **kw):  # .cuda()/.to() invalidates the packed copy
         self._packed = {}
+        self._plist = None
         return super()._apply(fn, *a, **kw)
 
-    def load_state_dict(self, *a, **kw):
-        self._packed = {}
-        return super().load_state_dict(*a, **kw)
+    def _weights_version(self):
+        """Changes whenever a parameter is written in place (load_state_dict's copy_, an optimizer, p.mul_()) or re-homed.
+        A checkpoint loaded through a PARENT module (checkpoint.restore, PRETRAINED_CHECKPOINT) never calls this module's
+        load_state_dict -- torch recurses with _load_from_state_dict -- so the packed copy is keyed on the parameters
+        themselves instead of on an overridden method."""
+        if getattr(self, '_plist', None) is None:       # re-homing goes through _apply, which drops this list (15 us per call)
+            self._plist = list(self.parameters())
+        return tuple(p._version for p in self._plist)
+
+    def _packed_for(self, key, depth, taps, dtype):
+        ver = self._weights_version()
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != ver:
+            if hit is not None and torch.cuda.is_available():
+                torch.cuda.synchronize()     # a forward on a side stream may still read the copy that is dropped here
+            sd = {k: v for k, v in self.state_dict().items()}
+            hit = (ver, ops.PackedViT(sd, depth, self.embed_dim, self.num_heads, self.patch_size, self.img_size, taps, dtype))
+            self._packed[key] = hit
+        return hit[1]
 
     def packed(self, taps, dtype):
-        key = (tuple(taps), str(dtype))
-        if key not in self._packed:
-            sd = {k: v for k, v in self.state_dict().items()}
-            self._packed[key] = ops.PackedViT(sd, self.depth, self.embed_dim, self.num_heads, self.patch_size,
-                                              self.img_size, taps, dtype)
-        return self._packed[key]
+        return self._packed_for((tuple(taps), str(dtype)), self.depth, taps, dtype)
 
     @torch.no_grad()
     def forward_taps(self, x, taps, dtype='bf16', frames_per_chunk=0):
@@ -107,12 +126,8 @@ class VisionTransformer(nn.Module):
     @torch.no_grad()
     def forward_front(self, x, nb, dtype='bf16', frames_per_chunk=0):
         """x [F,3,H,W] -> fp32 residual stream [F, N, D] after the first nb (frozen) blocks."""
-        key = ('front', nb, str(dtype))
-        if key not in self._packed:
-            sd = {k: v for k, v in self.state_dict().items()}
-            self._packed[key] = ops.PackedViT(sd, nb, self.embed_dim, self.num_heads, self.patch_size, self.img_size, (),
-                                              dtype)
-        return ops.vit_front(x, self._packed[key], frames_per_chunk=frames_per_chunk)
+        pk = self._packed_for(('front', nb, str(dtype)), nb, (), dtype)
+        return ops.vit_front(x, pk, frames_per_chunk=frames_per_chunk)
 
 
 def block_forward(blk, x, heads, fast=False):
@@ -204,6 +219,8 @@ def resample_abs_pos_embed(posemb, new_tokens, num_prefix_tokens=1):
 
 def create_model(name, pretrained=False, weights=None, img_size=224, seed=None):
     """Stand-in for timm.create_model for the names the reference accepts."""
+    if name in VIT_UNSUPPORTED:
+        raise NotImplementedError('TIMM model %s is not supported on the MI355X path: %s' % (name, VIT_UNSUPPORTED[name]))
     if name not in VIT_ZOO:
         raise ValueError('unknown/unsupported TIMM model: %s' % name)
     dim, depth, heads, patch, ls = VIT_ZOO[name]

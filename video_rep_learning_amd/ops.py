@@ -359,15 +359,21 @@ def layerscale_add(y, gamma, resid):
 # ------------------------------------------------------------------------------------------------
 # BatchNorm1d (+ optional fused ReLU), with cross-rank statistics when `group_size > 1` (SyncBN)
 # ------------------------------------------------------------------------------------------------
-def _world(group):
-    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+def _sync_world(group):
+    """Ranks a SyncBatchNorm exchanges statistics with; 0 = no exchange (no process group, or one rank and not forced)."""
+    from .utils.distributed import collectives_active
+    return dist.get_world_size(group) if collectives_active() else 0
 
 
-def sync_bn_stats(mean, var, count, group=None):
+def sync_bn_stats(mean, var, count, group=None, equal_counts=False):
     """Cross-rank batch statistics for SyncBatchNorm (train.py:283): every rank contributes (mean, biased var, row
     count) of its local rows -- 2C+1 floats, collective C2 of SURVEY.md -- and all ranks merge them with Chan's
     parallel-variance formula, which equals BatchNorm statistics over the rank-concatenated batch.
-    Plain torch + torch.distributed (no kernel): runs on gloo/CPU in the tests and on RCCL in training."""
+    Plain torch + torch.distributed (no kernel): runs on gloo/CPU in the tests and on RCCL in training.
+    `equal_counts`: every rank holds `count` rows (the data-parallel step: B x V x T x entities rows per rank, fixed by the
+    config), so the global count is count x world ON THE HOST -- no device-to-host read, which would stall the host until
+    the side-stream backbone forward the head waits for has finished and so undo the one-batch lookahead on every BatchNorm
+    of every step.  Ragged counts (equal_counts=False) read the gathered total back (one sync)."""
     C = mean.numel()
     world = dist.get_world_size(group)
     local = torch.cat([mean, var, mean.new_tensor([float(count)])])
@@ -375,9 +381,17 @@ def sync_bn_stats(mean, var, count, group=None):
     dist.all_gather(gathered, local, group=group)
     st = torch.stack(gathered)
     n = st[:, -1:]
-    total = float(n.sum())
-    gm = (st[:, :C] * n).sum(0) / total
-    gv = ((st[:, C:2 * C] + (st[:, :C] - gm) ** 2) * n).sum(0) / total
+    if equal_counts:
+        total = float(count) * world
+        if os.environ.get('MVF_CHECK_SYNCBN', '0') == '1':
+            assert float(n.sum()) == total, 'SyncBN: ranks hold different row counts'
+        # equal weights: plain means over the ranks (exactly the local statistics when world == 1)
+        gm = st[:, :C].sum(0) / world
+        gv = (st[:, C:2 * C] + (st[:, :C] - gm) ** 2).sum(0) / world
+    else:
+        total = float(n.sum())
+        gm = (st[:, :C] * n).sum(0) / total
+        gv = ((st[:, C:2 * C] + (st[:, :C] - gm) ** 2) * n).sum(0) / total
     return gm.contiguous(), gv.contiguous(), total
 
 
@@ -393,14 +407,14 @@ class _BatchNormTrain(torch.autograd.Function):
         mean = torch.empty(C, device=x.device, dtype=torch.float32)
         var = torch.empty_like(mean)
         count = float(R)
-        world = _world(group) if sync else 1
+        world = _sync_world(group) if sync else 0
         ws = _bn_ws(R, C, x.device)
-        local_running = world == 1       # the statistics kernel updates the running buffers itself
+        local_running = world == 0       # the statistics kernel updates the running buffers itself
         call('mvf_bn_stats', ptr(x), R, C, ptr(mean), ptr(var), ptr(running_mean) if local_running else None,
              ptr(running_var) if local_running else None, float(momentum), ptr(ws), ws.numel(), stream())
-        if world > 1:
+        if world > 0:
             # exchange (mean, biased var, count) and merge (Chan); 2C+1 floats per rank -- collective C2 of SURVEY.md
-            mean, var, count = sync_bn_stats(mean, var, count, group)
+            mean, var, count = sync_bn_stats(mean, var, count, group, equal_counts=True)
             with torch.no_grad():
                 running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
                 running_var.mul_(1 - momentum).add_(var, alpha=momentum * count / max(count - 1.0, 1.0))
@@ -429,7 +443,7 @@ class _BatchNormTrain(torch.autograd.Function):
              gp, bp, acc, R, C, eps, int(relu), ptr(ws), ws.numel(), stream())
         if slots is not None:
             grad_ready(*owners)
-        if world > 1:
+        if world > 0:
             dist.all_reduce(s, group=group)          # collective C3 of SURVEY.md
         dx = torch.empty_like(x)
         call('mvf_bn_bwd_apply', ptr(dy), ptr(x), ptr(mean), ptr(var), ptr(g), ptr(b), s[0].data_ptr(),

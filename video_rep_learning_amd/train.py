@@ -178,7 +178,7 @@ def main(argv=None):
     logger.info(pprint.pformat(cfg))
 
     model = build_model(cfg, args.local_rank).to(device)
-    if world > 1:
+    if du.collectives_active():            # world > 1 (train.py:283), or a forced one-rank group
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     model = DataParallelModel(model)
     optimizer = construct_optimizer(model, cfg)

@@ -8,12 +8,23 @@ gradients of the 4.8 M TRAINABLE parameters live in ONE flat fp32 buffer cut int
 all-reduce is launched asynchronously (RCCL side stream) from the autograd hook of its last gradient, so it
 overlaps the rest of backward; the optimizer waits, then divides by world size inside the fused Adam kernel.
 Also: the autograd-aware embedding all-gather that enlarges the SCL negative set (new)."""
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def is_dist():
     return dist.is_available() and dist.is_initialized()
+
+
+def collectives_active():
+    """True when the data-path collectives must be issued: more than one rank, or a ONE-rank process group with
+    MVF_FORCE_REDUCER=1.  The forced form drives every collective call site of the step (bucketed async gradient all-reduce
+    from the hooks, SyncBN statistics all-gather / all-reduce, embedding all-gather, loss all-reduce) through the backend --
+    RCCL on a single-GPU box -- where they are arithmetic identities: the step must come out bitwise equal to the plain one
+    (tests/test_gpu_ddp.py)."""
+    return is_dist() and (dist.get_world_size() > 1 or os.environ.get('MVF_FORCE_REDUCER', '0') == '1')
 
 
 def get_world_size():
@@ -36,7 +47,7 @@ def synchronize():
 
 def all_reduce(tensors, average=True):
     """In-place all-reduce of a list of tensors, optionally averaged (distributed.py:38-54)."""
-    if not is_dist() or dist.get_world_size() == 1:
+    if not collectives_active():
         return tensors
     for t in tensors:
         dist.all_reduce(t, async_op=False)
@@ -49,7 +60,7 @@ def all_reduce(tensors, average=True):
 
 def all_gather(tensors):
     """Non-differentiable tensor all-gather + cat(dim 0) (distributed.py:16-35)."""
-    if not is_dist() or dist.get_world_size() == 1:
+    if not collectives_active():
         return tensors
     out = []
     for t in tensors:
@@ -78,7 +89,7 @@ class _GatherRows(torch.autograd.Function):
 
 
 def gather_rows(x):
-    if not is_dist() or dist.get_world_size() == 1:
+    if not collectives_active():
         return x
     return _GatherRows.apply(x)
 
@@ -144,6 +155,7 @@ class GradReducer:
         self.flat = flat
         self.group = group
         self.world = get_world_size()
+        self.active = collectives_active()
         # buckets in REVERSE layout order (gradients become ready roughly output -> input); a bucket is a contiguous
         # element range of the flat gradient buffer
         self.buckets = []          # (start, end) element ranges
@@ -166,7 +178,7 @@ class GradReducer:
         self.sizes = [sum(1 for j in self.bucket_of.values() if j == b) for b in range(len(self.buckets))]
         self.pending = None
         self.works = None
-        if self.world > 1:
+        if self.active:
             for i, p in enumerate(flat.params):
                 hook = self._make_hook(i)
                 p.register_post_accumulate_grad_hook(hook)    # gradients that travel through autograd
@@ -184,10 +196,17 @@ class GradReducer:
 
     def _make_hook(self, i):
         def hook(_param):
-            if i in self.seen:          # one signal per parameter and step
+            b = self.bucket_of[i]
+            if i in self.seen:
+                # One "final" signal per parameter and step.  A second one is harmless while the bucket still waits for other
+                # members, but once its all-reduce is in flight a late contribution would be added to the slot during or after
+                # the reduction: silently wrong, rank-dependent gradients.  No shipped module shares a parameter between two
+                # kernel-accumulating ops; a future one must signal on its LAST use.
+                if self.works[b] is not None:
+                    raise RuntimeError('GradReducer: parameter #%d signalled again after its bucket\'s all-reduce was launched '
+                                       '(a parameter used by two gradient-accumulating ops must signal on the last use)' % i)
                 return
             self.seen.add(i)
-            b = self.bucket_of[i]
             self.pending[b] -= 1
             if self.pending[b] == 0 and self.works[b] is None:
                 self._launch(b)
@@ -195,7 +214,7 @@ class GradReducer:
 
     def finish(self):
         """Launch whatever was not triggered (parameters without a gradient this step) and wait for all."""
-        if self.world > 1:
+        if self.active:
             for b in range(len(self.buckets)):
                 if self.works[b] is None:
                     self._launch(b)

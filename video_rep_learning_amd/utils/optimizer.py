@@ -44,7 +44,17 @@ def find_fuse_groups(model):
 
 
 class FusedAdam(torch.optim.Optimizer):
-    """Adam with L2 weight decay (== torch.optim.Adam(weight_decay=wd)) on flat buffers + fused global-norm clip."""
+    """Adam with L2 weight decay (== torch.optim.Adam(weight_decay=wd)) on flat buffers + fused global-norm clip.
+
+    Two deliberate differences from torch.optim.Adam behind DDP(find_unused_parameters=True):
+      * a step whose (clipped) gradient norm is NaN / Inf is skipped ON THE DEVICE -- parameters, moments and the bias-correction
+        step count stay as they were (what GradScaler.step does on the reference's fp16 path, train.py:127-133); the count of
+        skipped steps is `skipped_steps()` (one host sync) and is taken off `step` in `state_dict()`;
+      * every parameter of the flat buffer is updated every step.  torch skips a parameter whose .grad is None; here a parameter
+        that received no gradient has a ZERO slot, so it still sees weight decay and moment decay.  Every trainable parameter of
+        the MV-Former configs receives a gradient each step except `embed.pooling.cross_att.linear_K2d.bias`, whose gradient is
+        identically zero in the reference too (a per-query constant under the softmax), so the two only differ there by
+        rounding-noise-sized gradients (tests list it among the null-gradient tensors)."""
 
     def __init__(self, param_groups, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, bucket_bytes=8 << 20,
                  fuse_groups=()):
@@ -60,7 +70,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count = 0
         dev = self.flat.flat_p.device
         self._scratch = torch.empty(1024, device=dev, dtype=torch.float32)
-        self._norm = torch.zeros(1, device=dev, dtype=torch.float32)
+        self._norm = torch.zeros(2, device=dev, dtype=torch.float32)     # [gradient norm, skipped (non-finite) steps so far]
         self.reducer = GradReducer(self.flat, bucket_bytes)
         # element range of every param group (groups are contiguous in the flat buffer by construction: fuse groups
         # only permute parameters inside one param group)
@@ -95,11 +105,18 @@ class FusedAdam(torch.optim.Optimizer):
             ops.adam_step(self.flat.flat_p[s:e], self.flat.flat_g[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e],
                           float(g['lr']), g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], self.step_count,
                           clip=float(max_norm or 0.0), norm=norm, gscale=gscale)
-        return norm
+        return norm[:1] if norm is not None else None
+
+    def skipped_steps(self):
+        """Steps dropped because their gradient norm was not finite (device counter; reading it synchronises)."""
+        return int(self._norm[1].item())
 
     # ---- torch.optim.Adam-compatible (de)serialisation: CARL_MVF/models/__init__.py:22-27,42-46 ----
     def state_dict(self):
         state = {}
+        if self.step_count > 0:          # fold skipped steps into the count (the device counter restarts at 0)
+            self.step_count = max(self.step_count - self.skipped_steps(), 0)
+            self._norm[1].zero_()
         for i, (p, o) in enumerate(zip(self.flat.params, self.flat.offsets)):
             n = p.numel()
             state[i] = {'step': torch.tensor(float(self.step_count)),

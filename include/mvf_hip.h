@@ -57,6 +57,13 @@ typedef struct MvfVitWeights {
   const void* const* fc1_w;  const float* const* fc1_b;   /* [4*dim, dim] T */
   const void* const* fc2_w;  const float* const* fc2_b;   /* [dim, 4*dim] T */
   const float* const* ls1;   const float* const* ls2;     /* LayerScale gamma tables or NULL */
+  /* LayerNorm folded into the GEMM that consumes it (bf16 mode, dim % 128 == 0; tables or NULL, entries may be NULL):
+   * where qkv_c[l] != NULL, qkv_w[l] holds gamma1 (.) W_qkv (per input column), qkv_b[l] holds b_qkv + W_qkv beta1 and
+   * qkv_c[l][n] = sum_k bf16(qkv_w[l][n,k]); the GEMM then reads the un-normalised bf16 residual stream and applies
+   * rstd * (acc - mean * c[n]) + b[n] in its epilogue, and no LayerNorm kernel runs for norm1 of block l (timm
+   * Block.forward: x + attn(norm1(x)); x + mlp(norm2(x))).  Same for fc1_c / norm2.  qkv_c[0] must be NULL (block 0's
+   * norm1 follows the patch embedding). */
+  const float* const* qkv_c; const float* const* fc1_c;
 } MvfVitWeights;
 
 size_t mvf_vit_workspace_bytes(int dtype, int frames_per_chunk, int tokens, int dim, int patch);
@@ -84,6 +91,15 @@ int mvf_prof_collect(double* ms_host, double* flops_host, int* count_host, int* 
 int mvf_gemm_tc(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
                 float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tokens_per_frame, int M,
                 int N, int K, hipStream_t stream);
+/* mvf_gemm_tc (bf16, K % 128 == 0, no pos) with the epilogue extras of the LN fold:
+ *   epi 2 (residual): xb [M, ldxb] bf16 = the updated residual row rounded to bf16, stats [N/64][M][2] = per row and 64-column
+ *     slice (sum, sum of squares) of the updated residual (either may be NULL);
+ *   epi 0 / 1: ln_mr [M][2] = (mean, rstd) per row, ln_c [N]:  C = act(rstd * (A W^T - mean * ln_c) + bias).
+ * mvf_ln_stats_finalize turns the partial sums into (mean, rstd = 1/sqrt(var + eps)) with the biased variance over D. */
+int mvf_gemm_tc_ln(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
+                   float* resid, int ldr, void* tap, int ldt, const float* ls, int tokens_per_frame, void* xb, int ldxb,
+                   float* stats, const float* ln_mr, const float* ln_c, int M, int N, int K, hipStream_t stream);
+int mvf_ln_stats_finalize(const float* part, int ns, float* mean_rstd, int rows, int D, float eps, hipStream_t stream);
 /* bf16 only, K % 128 == 0: M/batch_rows independent GEMMs stacked along M (batch_rows % 256 == 0), batch b using rows
  * [b * w_batch_rows, b * w_batch_rows + N) of W: the split-K form of a weight gradient dW = dY^T X over the tokens (each
  * batch one chunk of the token axis, fp32 partial sums with epi = 2 into a zeroed resid; trainable backbone blocks) */

@@ -16,10 +16,14 @@ published algorithm:
 
 `emulate='bf16'` restates the SAME algorithm with a round-to-nearest-even bf16 rounding at exactly the points where
 the product's bf16 mode stores bf16 (csrc/vit_fwd.hip, vit_attn.hip, gemm_tc_epi.h): GEMM weights, the im2col'd
-patches, LayerNorm outputs, qkv, the softmax probabilities fed to P.V (their row sum stays fp32), the attention
-output, fc1+GELU output and the tapped block outputs; accumulation, biases, position embedding, LayerScale and the
-residual stream stay fp32.  It is the checker for the benchmarked dtype (tests/test_gpu_*: tight gates instead of
-"bf16 is somewhere near fp32").
+patches, qkv, the softmax probabilities fed to P.V (their row sum stays fp32), the attention output, fc1+GELU output
+and the tapped block outputs; accumulation, biases, position embedding, LayerScale and the residual stream stay fp32.
+LayerNorm is FOLDED into the GEMM that consumes it, as the product does (include/mvf_hip.h qkv_c / fc1_c) -- for every
+norm2 and for norm1 of blocks > 0:   LN(x) W^T + b  ==  rstd * (x W'^T - mean * c) + d   with W' = gamma (.) W,
+c[n] = sum_k W'[n,k], d = b + W beta; the rounding points are then xb = bf16(x) and bf16(W') (c is summed over the
+ROUNDED W').  Block 0's norm1 (and `emulate='bf16_nofold'`, the product with MVF_LN_FOLD=0) rounds the LayerNorm output
+instead.  It is the checker for the benchmarked dtype (tests/test_gpu_*: tight gates instead of "bf16 is somewhere
+near fp32").
 
 Weights are a flat dict keyed with timm's state-dict names.  PARITY UNPINNED by
 the reference for this file (no reference test / vector exists); cross-checked
@@ -112,8 +116,9 @@ def _ident(x):
 
 
 def vit_block(x, w, p, heads, eps=1e-6, emulate=None):
-    if emulate == 'bf16':
-        return vit_block_bf16(x, w, p, heads, eps)
+    if emulate in ('bf16', 'bf16_nofold'):
+        fold = emulate == 'bf16' and x.shape[-1] % 128 == 0
+        return vit_block_bf16(x, w, p, heads, eps, fold1=fold and p != 'blocks.0.', fold2=fold)
     f, n, d = x.shape
     hd = d // heads
     h = layer_norm(x, w[p + 'norm1.weight'], w[p + 'norm1.bias'], eps)
@@ -135,13 +140,28 @@ def vit_block(x, w, p, heads, eps=1e-6, emulate=None):
     return x + h
 
 
-def vit_block_bf16(x, w, p, heads, eps=1e-6):
+def ln_linear_bf16(x, g, beta, W, b, eps, fold):
+    """Linear(LayerNorm(x)) before the output rounding, bf16 mode.  fold: the product's folded form (module docstring),
+    statistics as its kernels take them (sum and sum of squares of the fp32 row, biased variance E[x^2] - mean^2)."""
+    r = bf16_round
+    if not fold:
+        return r(layer_norm(x, g, beta, eps)) @ r(W).t() + b
+    mean = x.mean(-1, keepdim=True)
+    var = ((x * x).mean(-1, keepdim=True) - mean * mean).clamp_min(0.0)
+    rstd = 1.0 / torch.sqrt(var + eps)
+    Wp = r(W * g[None, :])
+    c = Wp.double().sum(1).to(x.dtype)
+    d = (b.double() + W.double() @ beta.double()).to(x.dtype)
+    return rstd * (r(x) @ Wp.t() - mean * c) + d
+
+
+def vit_block_bf16(x, w, p, heads, eps=1e-6, fold1=False, fold2=False):
     """vit_block with the bf16 mode's rounding points (module docstring); x is the fp32 residual stream."""
     r = bf16_round
     f, n, d = x.shape
     hd = d // heads
-    h = r(layer_norm(x, w[p + 'norm1.weight'], w[p + 'norm1.bias'], eps))
-    qkv = r(h @ r(w[p + 'attn.qkv.weight']).t() + w[p + 'attn.qkv.bias'])
+    qkv = r(ln_linear_bf16(x, w[p + 'norm1.weight'], w[p + 'norm1.bias'], w[p + 'attn.qkv.weight'], w[p + 'attn.qkv.bias'],
+                           eps, fold1))
     qkv = qkv.reshape(f, n, 3, heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
     s = (q @ k.transpose(-1, -2)) * hd ** -0.5
@@ -152,8 +172,8 @@ def vit_block_bf16(x, w, p, heads, eps=1e-6):
     if p + 'ls1.gamma' in w:
         a = a * w[p + 'ls1.gamma']
     x = x + a
-    h = r(layer_norm(x, w[p + 'norm2.weight'], w[p + 'norm2.bias'], eps))
-    h = r(gelu_erf(h @ r(w[p + 'mlp.fc1.weight']).t() + w[p + 'mlp.fc1.bias']))
+    h = r(gelu_erf(ln_linear_bf16(x, w[p + 'norm2.weight'], w[p + 'norm2.bias'], w[p + 'mlp.fc1.weight'],
+                                  w[p + 'mlp.fc1.bias'], eps, fold2)))
     h = h @ r(w[p + 'mlp.fc2.weight']).t() + w[p + 'mlp.fc2.bias']
     if p + 'ls2.gamma' in w:
         h = h * w[p + 'ls2.gamma']
@@ -163,7 +183,7 @@ def vit_block_bf16(x, w, p, heads, eps=1e-6):
 def vit_embed(img, w, patch, emulate=None):
     """patch_embed + cls + pos: [F,3,H,W] -> [F, 1+N, D]."""
     dim = w['patch_embed.proj.weight'].shape[0]
-    r = bf16_round if emulate == 'bf16' else _ident
+    r = bf16_round if emulate else _ident
     x = r(patchify(img, patch)) @ r(w['patch_embed.proj.weight'].reshape(dim, -1)).t() + w['patch_embed.proj.bias']
     cls = w['cls_token'].expand(x.shape[0], -1, -1)
     return torch.cat([cls, x], 1) + w['pos_embed']
@@ -182,13 +202,13 @@ def vit_forward(img, w, heads, patch, taps=(3, 7, 11), eps=1e-6, first_block=0, 
     """
     depth = 1 + max(int(k.split('.')[1]) for k in w if k.startswith('blocks.'))
     last_block = depth if last_block is None else last_block
-    assert emulate in (None, 'bf16'), emulate
+    assert emulate in (None, 'bf16', 'bf16_nofold'), emulate
     x = vit_embed(img, w, patch, emulate) if x_in is None else x_in
     feats = {}
     for i in range(first_block, last_block):
         x = vit_block(x, w, 'blocks.%d.' % i, heads, eps, emulate)
         if i in taps:
-            feats[i] = bf16_round(x) if emulate == 'bf16' else x      # taps are stored in the compute dtype
+            feats[i] = bf16_round(x) if emulate else x      # taps are stored in the compute dtype
     out = layer_norm(x, w['norm.weight'], w['norm.bias'], eps)[:, 0] if last_block == depth else x
     features = torch.cat([feats[i] for i in taps], dim=2) if taps else None
     return features, out

@@ -117,7 +117,8 @@ def _forced_worker(rank, world, port, ret, gather):
     """One process, one GPU: a plain step first, then the same step on a ONE-rank `nccl` (= RCCL) process group with
     MVF_FORCE_REDUCER=1, which sends every collective of the data-parallel step through the backend: the per-bucket async
     all-reduce launched from the gradient hooks, the SyncBN all-gather (forward) and all-reduce (backward), the embedding
-    all-gather and the loss all-reduce.  On one rank they are identities, so loss and parameters must come out BITWISE equal."""
+    all-gather and the loss all-reduce.  On one rank they are identities, so the loss and every parameter must come out bit for
+    bit equal (LayerNorm gamma / beta up to their atomics' run-to-run noise)."""
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
     cfg = _setup(gather)
     full = _batch(cfg)
@@ -138,22 +139,27 @@ def _forced_worker(rank, world, port, ret, gather):
         loss, sd, _ = _train_one_step(cfg, full, sync_bn=True)
         dist.all_reduce = real
         red = du.all_reduce([torch.tensor([loss], device='cuda:0')])[0].item()      # C4 through RCCL
-        same = all(torch.equal(sd[k], ref_sd[k]) for k in ref_sd if 'running_' not in k and 'num_batches' not in k)
-        close = all(torch.allclose(sd[k].float(), ref_sd[k].float(), rtol=1e-5, atol=1e-7) for k in ref_sd if 'running_' in k)
-        ret['out'] = (ref_loss, loss, red, same, close, launched)
+        # LayerNorm gamma / beta gradients are accumulated with float atomics (mvf_ln_bwd), so two runs of the SAME step differ in
+        # their last bits; everything else is bit for bit.  1e-6 absolute on parameters of size O(0.1 .. 1) after one lr = 1e-3 step
+        diff = [(k, (sd[k].double() - ref_sd[k].double()).abs().max().item()) for k in ref_sd
+                if 'running_' not in k and 'num_batches' not in k
+                and not (torch.equal(sd[k], ref_sd[k]) or ('norm.' in k and torch.allclose(sd[k], ref_sd[k], rtol=0, atol=1e-6)))]
+        far = [(k, (sd[k].double() - ref_sd[k].double()).abs().max().item()) for k in ref_sd
+               if 'running_' in k and not torch.allclose(sd[k].float(), ref_sd[k].float(), rtol=1e-5, atol=1e-7)]
+        ret['out'] = (ref_loss, loss, red, diff, far, launched)
     finally:
         os.environ.pop('MVF_FORCE_REDUCER', None)
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize('gather', [False, True])
-def test_forced_reducer_on_one_rank_rccl_group_is_bitwise_the_plain_step(gather):
+def test_forced_reducer_on_one_rank_rccl_group_equals_the_plain_step(gather):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_forced_worker, args=(1, _free_port(), ret, gather), nprocs=1, join=True)
-    ref_loss, loss, red, same, close, launched = ret['out']
+    ref_loss, loss, red, diff, far, launched = ret['out']
     assert loss == ref_loss and red == loss, (ref_loss, loss, red)
-    assert same and close
+    assert not diff and not far, (diff[:8], far[:8])
     async_buckets = [n for n, is_async in launched if is_async]
     assert async_buckets and sum(async_buckets) >= 1_000_000, launched       # the flat gradient buffer went through RCCL
     assert any(not is_async for _n, is_async in launched), launched            # SyncBN backward all-reduce

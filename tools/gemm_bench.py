@@ -1,6 +1,9 @@
 """GEMM-only timing / profiling driver for the backbone GEMM kernels (GPU box; not part of the judged bench).
 
-    python tools/gemm_bench.py [--variant 1|2] [--shapes qkv,proj,fc1,fc2] [--frames 256] [--iters 20]
+    python tools/gemm_bench.py [--variant 0|1|2] [--shapes qkv,proj,fc1,fc2] [--frames 256] [--iters 20] [--ln] [--rounds 3]
+
+--ln: the same shapes with the LN-fold epilogue extras (mvf_gemm_tc_ln: consumer side for qkv / fc1, producer side for proj /
+fc2), interleaved with the plain form in one process.  --variant 0 is the automatic choice (tail rows on the 128x128 kernel).
 
 Run it under `rocprofv3 --kernel-trace --stats` or `rocprofv3 --pmc ...` to get per-kernel durations / counters for
 exactly the ViT-B/16 shapes of BASELINE configs[1] (M = frames * 197)."""
@@ -23,6 +26,8 @@ def main():
     p.add_argument('--frames', type=int, default=256)
     p.add_argument('--iters', type=int, default=20)
     p.add_argument('--warm', type=int, default=3)
+    p.add_argument('--ln', nargs='?', const='both', default=None, choices=['both', 'xb', 'stats'])
+    p.add_argument('--rounds', type=int, default=1)
     a = p.parse_args()
     dev = 'cuda'
     M = a.frames * 197
@@ -36,21 +41,40 @@ def main():
         C = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
         R = torch.zeros(M, n, device=dev)
 
-        def fn():
+        xb = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
+        stats = torch.empty(max(n // 64, 1), M, 2, device=dev)
+        mr = torch.stack([torch.randn(M, device=dev) * 0.1, 1.0 + 0.1 * torch.rand(M, device=dev)], 1).contiguous()
+        c = torch.randn(n, device=dev)
+
+        def plain():
             _lib.call('mvf_gemm_tc', _lib.BF16, epi, A.data_ptr(), k, W.data_ptr(), k, b.data_ptr(), C.data_ptr(), n,
                       R.data_ptr(), n, None, 0, None, None, 197, M, n, k, st)
-        for _ in range(a.warm):
-            fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(a.iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) / a.iters * 1e-3
-        print('variant %d %-4s M=%d N=%d K=%d  %8.1f us  %7.1f TFLOP/s' % (a.variant, name, M, n, k, t * 1e6,
-                                                                          2.0 * M * n * k / t / 1e12), flush=True)
+
+        def fold():
+            if epi == 2:
+                _lib.call('mvf_gemm_tc_ln', _lib.BF16, epi, A.data_ptr(), k, W.data_ptr(), k, b.data_ptr(), None, 0, R.data_ptr(),
+                          n, None, 0, None, 197, None if a.ln == 'stats' else xb.data_ptr(), n,
+                          None if a.ln == 'xb' else stats.data_ptr(), None, None, M, n, k, st)
+            else:
+                _lib.call('mvf_gemm_tc_ln', _lib.BF16, epi, A.data_ptr(), k, W.data_ptr(), k, b.data_ptr(), C.data_ptr(), n, None,
+                          0, None, 0, None, 197, None, 0, None, mr.data_ptr(), c.data_ptr(), M, n, k, st)
+
+        def timed(fn):
+            for _ in range(a.warm):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / a.iters * 1e-3
+        for rnd in range(a.rounds):
+            for tag, fn in (('plain', plain), ('ln', fold)) if a.ln else (('plain', plain),):
+                t = timed(fn)
+                print('variant %d %-4s %-5s M=%d N=%d K=%d  %8.1f us  %7.1f TFLOP/s' % (a.variant, name, tag, M, n, k, t * 1e6,
+                                                                                      2.0 * M * n * k / t / 1e12), flush=True)
     _lib.call('mvf_gemm_tc_select', 0)
 
 

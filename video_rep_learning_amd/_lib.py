@@ -23,6 +23,8 @@ SIGNATURES = {
     'mvf_prof_collect': 'ppppppip',
     'mvf_gemm_tc': 'iipipippipipippiiiip',
     'mvf_gemm_tc_batched': 'ipipipipiiiiiip',
+    'mvf_gemm_tc_ln': 'iipipippipipipipipppiiip',
+    'mvf_ln_stats_finalize': 'pipiifp',
     'mvf_gemm_tc_select': 'i',
     'mvf_gemm_tc_debug_stamps': 'p',
     'mvf_gemm_tc_set_cus': 'i',
@@ -82,7 +84,7 @@ class MvfVitWeights(ctypes.Structure):
                  ('cls_token', _P), ('pos_embed', _P), ('patch_w', _P), ('patch_b', _P), ('norm_w', _P), ('norm_b', _P)]
                 + [(n, ctypes.POINTER(_P)) for n in
                    ('ln1_w', 'ln1_b', 'qkv_w', 'qkv_b', 'proj_w', 'proj_b', 'ln2_w', 'ln2_b', 'fc1_w', 'fc1_b',
-                    'fc2_w', 'fc2_b', 'ls1', 'ls2')])
+                    'fc2_w', 'fc2_b', 'ls1', 'ls2', 'qkv_c', 'fc1_c')])
 
 
 class MvfAugmentParams(ctypes.Structure):

@@ -18,9 +18,16 @@
 #include "mvf_hip_internal.h"
 #include "gemm_tc_epi.h"
 
+#include <cstdlib>
+
 namespace {
 using namespace gemm_tc;
 int g_variant = 0;
+// Off by default: alone, the split takes 15 % off the N = 768 GEMMs of a half batch (fc2 156 -> 133 us at M = 25 216), but
+// inside the training step, where two backbone lanes and the head share the chip, it is SLOWER (12.58 vs 11.91 ms/step):
+// the many small 128x128 workgroups of one lane queue behind the other lane's persistent workgroups.  MVF_GEMM_TAIL_SPLIT=1
+// turns it on (tools/gemm_bench.py --variant 0).
+bool g_tail_split = getenv("MVF_GEMM_TAIL_SPLIT") != nullptr;
 unsigned long long* g_dbg = nullptr;
 
 constexpr int BM = 128, BN = 128, ROWB = 128;
@@ -28,7 +35,7 @@ constexpr int TILE_BYTES = BM * ROWB;          // 16 KiB per operand per stage
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + W
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;     // 64 KiB -> 2 workgroups / CU
 
-template <typename T, int EPI>
+template <typename T, int EPI, bool LN>
 __global__ __launch_bounds__(256, 2) void gemm_tc_kernel(GemmTcArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KE = ROWB / (int)sizeof(T);  // K elements per tile
@@ -43,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tc_kernel(GemmTcArgs a) {
   const int q8 = nwg >> 3, r8 = nwg & 7;
   const int xcd = blockIdx.x & 7;
   const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-  const int m0 = (lid / nbn) * BM;
+  const int m0 = a.row0 + (lid / nbn) * BM;
   const int n0 = (lid % nbn) * BN;
   const int nk = a.K / KE;
 
@@ -122,35 +129,82 @@ __global__ __launch_bounds__(256, 2) void gemm_tc_kernel(GemmTcArgs a) {
   }
 
   // ---- epilogue: lane owns C[m][n..n+3], m = tile row (lane&15), n = 4*(lane>>4) + r ----
+  if constexpr (!LN) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wr * 64 + i * 16 + frow;
-    if (m >= a.M) continue;
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wr * 64 + i * 16 + frow;
+      if (m >= a.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wc * 64 + j * 16 + fgrp * 4;
-      if (n >= a.N) continue;
-      epilogue4<T, EPI>(a, m, n, acc[i][j]);
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + fgrp * 4;
+        if (n >= a.N) continue;
+        epilogue4<T, EPI>(a, m, n, acc[i][j]);
+      }
+    }
+  } else {
+    // LN-fold extras (same contract as gemm_tc256's): N % 64 == 0 here, so a wave's 64 columns are in range or out as a whole;
+    // rows beyond M only skip their memory accesses -- every lane takes part in the cross-lane row sums
+    const bool cols = n0 + wc * 64 < a.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wr * 64 + i * 16 + frow;
+      const bool ok = m < a.M && cols;
+      float2 mr = make_float2(0.f, 1.f);
+      if constexpr (EPI == EPI_STORE || EPI == EPI_GELU) {
+        if (ok) mr = *reinterpret_cast<const float2*>(a.ln_mr + (size_t)m * 2);
+      }
+      float s1 = 0.f, s2 = 0.f;
+      if (ok) {
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};
+          epilogue4<T, EPI, true>(a, m, n0 + wc * 64 + (2 * jp) * 16 + fgrp * 4, acc[i][2 * jp], mr, v0);
+          epilogue4<T, EPI, true>(a, m, n0 + wc * 64 + (2 * jp + 1) * 16 + fgrp * 4, acc[i][2 * jp + 1], mr, v1);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {     // the summation order of epilogue_pair_bf16_ln: the two kernels agree bit for bit
+            s1 += v0[r] + v1[r];
+            s2 = fmaf(v0[r], v0[r], fmaf(v1[r], v1[r], s2));
+          }
+        }
+      }
+      if constexpr (EPI == EPI_RESID) {
+        if (a.stats != nullptr) {
+          s1 = row_quad_sum(s1);
+          s2 = row_quad_sum(s2);
+          if (fgrp == 0 && ok)
+            *reinterpret_cast<float2*>(a.stats + ((size_t)((n0 >> 6) + wc) * a.M + m) * 2) = make_float2(s1, s2);
+        }
+      }
     }
   }
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, bool LN = false>
 int launch(const GemmTcArgs& a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tc_kernel<T, EPI>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tc_kernel<T, EPI, LN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
-  const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_tc_kernel<T, EPI>), dim3(nbm * nbn), dim3(256), LDS_BYTES, st, a);
+  const int nbm = (a.M - a.row0 + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm_tc_kernel<T, EPI, LN>), dim3(nbm * nbn), dim3(256), LDS_BYTES, st, a);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }
 
 template <typename T>
 int dispatch(int epi, const GemmTcArgs& a, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    if (a.ln_mr != nullptr || a.xb != nullptr || a.stats != nullptr) {   // LN-fold extras: bf16 only
+      switch (epi) {
+        case EPI_STORE: return launch<T, EPI_STORE, true>(a, st);
+        case EPI_GELU: return launch<T, EPI_GELU, true>(a, st);
+        case EPI_RESID: return launch<T, EPI_RESID, true>(a, st);
+      }
+      return MVF_ERR_ARG;
+    }
+  }
   switch (epi) {
     case EPI_STORE: return launch<T, EPI_STORE>(a, st);
     case EPI_GELU: return launch<T, EPI_GELU>(a, st);
@@ -165,7 +219,7 @@ int dispatch(int epi, const GemmTcArgs& a, hipStream_t st) {
 // Internal entry used by the ViT driver and exported through the C ABI (mvf_gemm_tc in mvf_hip.h).
 int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C,
                      int ldc, float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tpf, int M,
-                     int N, int K, hipStream_t st, int batch_rows, int w_batch_rows) {
+                     int N, int K, hipStream_t st, int batch_rows, int w_batch_rows, const MvfGemmLn* ln) {
   const int esz = dtype == MVF_BF16 ? 2 : 4;
   const int ke = ROWB / esz;
   MVF_CHECK_ARG(dtype == MVF_BF16 || dtype == MVF_F32);
@@ -183,13 +237,49 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
   a.dbg = g_dbg;
   a.sched = nullptr;   // set by the persistent gemm_tc256 launch
   a.batch_rows = batch_rows; a.w_batch_rows = w_batch_rows;
+  a.row0 = 0;
+  a.xb = nullptr; a.ldxb = 0; a.stats = nullptr; a.ln_mr = nullptr; a.ln_c = nullptr;
+  a.sa = nullptr; a.sw = nullptr;
+  const bool fold = ln != nullptr && (ln->xb || ln->stats || ln->ln_mr || ln->ln_c);
+  if (fold) {   // LN fold: epilogue extras of the 256x256 bf16 kernel
+    if (ln->xb || ln->stats) MVF_CHECK_ARG(epi == EPI_RESID);
+    if (ln->xb) MVF_CHECK_ARG(ln->ldxb % 8 == 0 && ln->ldxb >= N && ((uintptr_t)ln->xb % 16) == 0);
+    if (ln->stats) MVF_CHECK_ARG(N % 64 == 0 && ((uintptr_t)ln->stats % 8) == 0);
+    if (ln->ln_mr || ln->ln_c)
+      MVF_CHECK_ARG((epi == EPI_STORE || epi == EPI_GELU) && ln->ln_mr && ln->ln_c && ((uintptr_t)ln->ln_mr % 8) == 0);
+    if (!(dtype == MVF_BF16 && N % 64 == 0 && batch_rows == 0)) return MVF_ERR_UNSUPPORTED;
+    a.xb = (char*)ln->xb; a.ldxb = ln->ldxb; a.stats = ln->stats; a.ln_mr = ln->ln_mr; a.ln_c = ln->ln_c;
+  }
   if (batch_rows != 0) {   // stacked batches: the 256x256 kernel only
     MVF_CHECK_ARG(batch_rows > 0 && batch_rows % 256 == 0 && M % batch_rows == 0 && w_batch_rows >= N);
     if (!(dtype == MVF_BF16 && g_variant != 1 && K % 128 == 0 && N % 32 == 0)) return MVF_ERR_UNSUPPORTED;
   }
   // bf16 with K a multiple of 128: the 256x256 8-phase kernel (gemm_tc256.hip); g_variant 1 pins the 128x128 kernel
   if (dtype == MVF_BF16 && g_variant != 1 && K % 128 == 0 && N % 32 == 0) {
-    const int rc = mvf_gemm_tc256_launch(epi, a, /*persistent=*/g_variant != 3, st);
+    // Tail split (automatic choice only): the persistent kernel runs one workgroup per CU, so T tiles take ceil(T / G) rounds
+    // and a last round that is mostly empty leaves the chip idle for a whole tile time (N = 768: 591 tiles on 256 CUs = 2.31
+    // rounds).  When the last round would be less than 60 % full, the row panels of the WHOLE rounds go to the 256x256 kernel
+    // and the remaining rows to the 128x128 kernel (4 x the workgroups, two per CU, a quarter of the work each): the two
+    // kernels are bit-identical in every epilogue (tests), so the split changes nothing but the time.
+    int m_split = 0;
+    if (g_variant == 0 && batch_rows == 0 && g_tail_split) {
+      const int G = std::max(8, mvf_gemm_tc256_num_wgs());
+      const int nbm = (M + 255) / 256, nbn = (N + 255) / 256;
+      const long tiles = (long)nbm * nbn;
+      const long full = tiles / G;
+      if (full >= 1 && tiles % G != 0 && (double)(tiles % G) < 0.6 * G) {
+        const int nbm1 = (int)(full * G / nbn);
+        if (nbm1 >= 1 && nbm1 < nbm) m_split = nbm1 * 256;
+      }
+    }
+    GemmTcArgs a1 = a;
+    if (m_split > 0) a1.M = m_split;
+    const int rc = mvf_gemm_tc256_launch(epi, a1, /*persistent=*/g_variant != 3, st);
+    if (rc == MVF_OK && m_split > 0) {
+      GemmTcArgs a2 = a;
+      a2.row0 = m_split;
+      return dispatch<bf16_t>(epi, a2, st);
+    }
     // operands of 4 GiB or more are beyond the 256x256 kernel's 32-bit offsets: the 128x128 kernel (64-bit addressing)
     // takes over unless the caller pinned the kernel or asked for stacked batches
     if (rc != MVF_ERR_UNSUPPORTED || g_variant >= 2 || batch_rows != 0) return rc;

@@ -75,7 +75,13 @@ constexpr int HALF_BYTES = 128 * ROWB;          // 16 KiB: 128 rows x 64 bf16
 constexpr int BUF_BYTES = 4 * HALF_BYTES;       // A0 A1 B0 B1
 constexpr int BIAS_OFF = 2 * BUF_BYTES;         // 8 waves x 64 floats behind the two K-tile buffers
 constexpr int SLOT_OFF = BIAS_OFF + 8 * 256;    // 4 B: the next tile's ticket, wave 0 -> all waves
-constexpr int LDS_BYTES = SLOT_OFF + 16;        // 130 KiB -> one workgroup per CU
+// LN fold (consumer side): this wave's 64 ln_c values (private, like the bias) and the tile's 256 (mean, rstd) pairs, the
+// latter read by ALL waves and therefore double-buffered by tile parity (the next tile's pairs are staged while slower
+// waves may still be in this tile's epilogue)
+constexpr int LNC_OFF = SLOT_OFF + 16;
+constexpr int LNMR_OFF = LNC_OFF + 8 * 256;
+constexpr int SC_OFF = LNMR_OFF + 2 * 2048;     // fp8: two K tiles' scales, [buf][A 256 dwords | W 256 dwords]
+constexpr int LDS_BYTES = SC_OFF + 2 * 2048;    // 140 KiB -> one workgroup per CU
 constexpr int OFF_A0 = 0, OFF_A1 = HALF_BYTES, OFF_B0 = 2 * HALF_BYTES, OFF_B1 = 3 * HALF_BYTES;
 
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -88,10 +94,30 @@ constexpr int OFF_A0 = 0, OFF_A1 = HALF_BYTES, OFF_B0 = 2 * HALF_BYTES, OFF_B1 =
     SCHED_FENCE();                \
   } while (0)
 
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+// acc += W_frag . A_frag on v_mfma_scale_f32_16x16x128_f8f6f4 (fp8 e4m3 x fp8 e4m3, each lane's 32 k scaled by 2^(byte 0 of its
+// scale register - 127)).  Inline asm with the accumulator TIED: through the builtin, hipcc (ROCm 7.2) picks the three-address
+// form for 105 of the loop's 128 MFMAs (destination != C) and then needs a second set of 128 accumulator registers -- 250
+// spilled registers inside the K loop.  Hazards are the caller's: operands come from LDS reads it has waited for, the scales
+// from VALU two wait states earlier (SCALE_FIX), and the accumulators are next read a whole K tile later.
+__device__ __forceinline__ void mfma_mx(f32x4_t& acc, const i32x8_t& w, const i32x8_t& x, unsigned sw, unsigned sx) {
+  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"
+               : "+v"(acc)
+               : "v"(w), "v"(x), "v"(sw), "v"(sx));
+}
+
 // DBG (diagnostic build only, reached through mvf_gemm_tc_debug_stamps; never on the product path): lane 0 of waves 0
 // and 4 stamps s_memtime at kernel start, after the prologue wait, after the K loop and the epilogue of the
 // workgroup's first two tiles, and at the end, into a.dbg[block][2][8] (a buffer of its own; no output depends on it).
-template <int EPI, bool DBG>
+// LN: the LN-fold extras are compiled in (EPI_STORE / EPI_GELU: consumer side, a.ln_mr / a.ln_c; EPI_RESID: producer side,
+// a.xb / a.stats).  A template parameter, not a run-time test: the plain variants keep their register budget (no spills).
+// FP8: the operands are MX-fp8 (OCP e4m3 bytes + one E8M0 scale per 32 consecutive k of a row: a.sa / a.sw) and the products
+// run on v_mfma_scale_f32_16x16x128_f8f6f4 -- one MFMA per 16x16 tile and K tile instead of two, at twice the cycles and four
+// times the k: the same matrix-pipe time per K tile for TWICE the FLOPs, from the same bytes (a K tile is 128-byte rows either
+// way, so staging, swizzle and hazards are unchanged).  The K tile's scales (256 + 256 dwords) travel by one more LDS-DMA per
+// wave, issued with A1 (same distance to its consumer, so the counted vmcnt(6) still leaves exactly three half-tiles in flight).
+template <int EPI, bool DBG, bool LN, bool FP8>
 __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -123,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   const int end = start + q8 + (xcd < r8 ? 1 : 0);
   int lid = start + slot;                          // tile being computed
   if (lid >= end) return;                          // whole workgroup (only when tiles are unevenly spread over XCDs)
-  const int nk = a.K >> 6;                         // K tiles of 64 (even: K % 128 == 0)
+  const int nk = FP8 ? a.K >> 7 : a.K >> 6;        // K tiles of 128 bytes per row (even: K % 128 == 0, fp8: K % 256 == 0)
   // dynamic tickets only when this group has more tiles than workgroups (then no workgroup of it returned above)
   const bool dyn = a.sched != nullptr && nk >= 4 && start + bpx < end;
   unsigned* const cnt = a.sched + xcd;
@@ -148,8 +174,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   // base in SGPRs plus one VGPR per piece -- half the address registers of full pointers
   unsigned asrc[2][2];                   // [half][piece]
   unsigned wsrc[2][2];
+  constexpr unsigned ESZ = FP8 ? 1u : 2u;
+  // fp8: this wave's 64 scale dwords of a K tile -- waves 0-3: rows tm0 + 64 w .. of A (a.sa[kt][M]), waves 4-7: rows
+  // tn0 + 64 (w - 4) .. of W (a.sw[kt][N])
+  unsigned ssrc = 0;
+  const unsigned* const sbase = wave < 4 ? a.sa : a.sw;
+  const unsigned sstride = wave < 4 ? (unsigned)a.M : (unsigned)a.N;
   auto set_sources = [&](int tile) {
     const int tm0 = (tile / nbn) * BM, tn0 = (tile % nbn) * BN;
+    if constexpr (FP8)
+      ssrc = wave < 4 ? (unsigned)min(tm0 + wave * 64 + lane, a.M - 1) : (unsigned)min(tn0 + (wave - 4) * 64 + lane, a.N - 1);
     // stacked batches (split-K weight gradients): the tile's batch picks its own row block of W
     const int wb0 = a.batch_rows > 0 ? (tm0 / a.batch_rows) * a.w_batch_rows : 0;
 #pragma unroll
@@ -163,8 +197,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
         const int gn = wb0 + min(tn0 + wn, a.N - 1);
         // 24-bit multiply (rows and row bytes < 2^24, checked by the launch): one v_mad_u32_u24 -- a full 32-bit
         // product goes through v_mad_u64_u32, whose don't-care high addend register hipcc shares with the ticket's
-        asrc[h][i] = __umul24((unsigned)gm, (unsigned)a.lda * 2u) + lchunk * 16;
-        wsrc[h][i] = __umul24((unsigned)gn, (unsigned)a.ldw * 2u) + lchunk * 16;
+        asrc[h][i] = __umul24((unsigned)gm, (unsigned)a.lda * ESZ) + lchunk * 16;
+        wsrc[h][i] = __umul24((unsigned)gn, (unsigned)a.ldw * ESZ) + lchunk * 16;
       }
   };
   set_sources(lid);
@@ -175,18 +209,40 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     __builtin_amdgcn_global_load_lds(GLB_PTR(gbase + (size_t)(src[0] + koff)), LDS_PTR(dst + piece0), 16, 0, 0);
     __builtin_amdgcn_global_load_lds(GLB_PTR(gbase + (size_t)(src[1] + koff)), LDS_PTR(dst + piece1), 16, 0, 0);
   };
+  // fp8: the scales of K tile kt -> scale buffer `buf` (A rows first, then W rows; lane-linear, 4 B per lane)
+  auto stage_scales = [&](int buf, int kt) {
+    if constexpr (FP8)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(sbase + (size_t)kt * sstride + ssrc),
+                                       LDS_PTR(smem + SC_OFF + buf * 2048 + wave * 256), 4, 0, 0);
+  };
   // this wave's 64 bias values -> its private 256 B of LDS, one LDS-DMA (4 B per lane)
   char* sbias = smem + BIAS_OFF + wave * 256;
+  char* slnc = smem + LNC_OFF + wave * 256;
+  // parity of the workgroup's current tile.  A tile's bias / ln_c / (mean, rstd) are staged right after the previous tile's
+  // epilogue of THIS wave, when the parity has just flipped: slot tpar is read in this tile's epilogue only, and was last read
+  // two tiles ago (every wave has passed a K loop's barriers since)
+  int tpar = 0;
   auto stage_bias = [&](int tile) {
     if (a.bias != nullptr) {
       const int n = min((tile % nbn) * BN + wc * 64 + lane, a.N - 1);
       __builtin_amdgcn_global_load_lds(GLB_PTR(a.bias + n), LDS_PTR(sbias), 4, 0, 0);
     }
+    if constexpr (LN && (EPI == EPI_STORE || EPI == EPI_GELU)) {
+      {
+        const int n = min((tile % nbn) * BN + wc * 64 + lane, a.N - 1);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(a.ln_c + n), LDS_PTR(slnc), 4, 0, 0);
+        // rows m0 .. m0+255 as 512 consecutive floats; this wave copies floats [64 w, 64 w + 64) = rows m0 + 32 w ..
+        const int fi = wave * 64 + lane;
+        const int row = min((tile / nbn) * BM + (fi >> 1), a.M - 1);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(a.ln_mr + (size_t)row * 2 + (fi & 1)),
+                                         LDS_PTR(smem + LNMR_OFF + tpar * 2048 + wave * 256), 4, 0, 0);
+      }
+    }
   };
 
   // ---- fragment read offsets: lane (frow, fgrp) reads row frow of a 16-row tile, 16-B chunk (ks*4 + fgrp) ^ (frow&7)
   const int frow = lane & 15, fgrp = lane >> 4;
-  const int choff = (fgrp ^ (frow & 7)) << 4;                   // k-step 0; k-step 1 is choff ^ 64
+  const int choff = ((FP8 ? 2 * fgrp : fgrp) ^ (frow & 7)) << 4;   // k-step 0; k-step 1 is choff ^ 64 (fp8: second chunk, ^ 16)
   const int a_rd = (wr * 64 + frow) * ROWB + choff;
   const int b_rd = (wc * 32 + frow) * ROWB + choff;
 
@@ -203,6 +259,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   stage(0, OFF_A0, a.A, asrc[0], 0);
   stage(0, OFF_B1, a.W, wsrc[1], 0);
   stage(0, OFF_A1, a.A, asrc[1], 0);
+  stage_scales(0, 0);
   stage(1, OFF_B0, a.W, wsrc[0], 1);
   stage(1, OFF_A0, a.A, asrc[0], 1);
   stage(1, OFF_B1, a.W, wsrc[1], 1);
@@ -212,24 +269,65 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   STAMP();
 
   bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
+  // fp8: a fragment is ONE 32-byte operand (8 consecutive registers), filled by two 16-byte LDS reads into its halves
+  i32x8_t afq[4], bq0[2], bq1[2];
+  unsigned sfa[4], sf0[2], sf1[2];   // fp8: the E8M0 scale of each fragment's 32-k block, in byte 0
+  // fp8: a lane's fragment is 32 consecutive k = the two 16-byte chunks 2 fgrp, 2 fgrp + 1 (bf16: chunks fgrp and 4 + fgrp)
+  constexpr int KS1 = FP8 ? 16 : 64;
+  // fp8: one LDS address each for this lane's A-row / W-row scale dwords (K-tile buffer, quadrant and tile are immediates)
+  const char* const sa_rd = smem + SC_OFF + (wr * 128 + frow) * 4;
+  const char* const sb_rd = smem + SC_OFF + 1024 + (wc * 64 + frow) * 4;
+  const unsigned sshift = 8u * fgrp;
 
+// fp8: the scale dwords of an A quadrant's four row tiles.  In P0 they are read BEFORE the scheduling fence, with the B
+// operands, so that exactly the eight 16-byte A reads follow it whatever hipcc merges (it pairs the dword reads into
+// ds_read2_b32): the lgkmcnt(8) in front of P0's first barrier then retires every B read (WAR rule of B0, file header)
+#define LOAD_A_SCALES(OFF)                                                                                   \
+  if constexpr (FP8) {                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+      sfa[i] = *reinterpret_cast<const unsigned*>(sa_rd + sbuf_off + (((OFF) == OFF_A1 ? 64 : 0) + i * 16) * 4);  \
+  }
 #define LOAD_A(OFF)                                                                                          \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \
-    af[i][0] = *reinterpret_cast<const bf16x8_t*>(base + (OFF) + a_rd + i * 16 * ROWB);                      \
-    af[i][1] = *reinterpret_cast<const bf16x8_t*>(base + (OFF) + (a_rd ^ 64) + i * 16 * ROWB);               \
+    if constexpr (FP8) {                                                                                     \
+      afq[i].lo = *reinterpret_cast<const i32x4_t*>(base + (OFF) + a_rd + i * 16 * ROWB);                    \
+      afq[i].hi = *reinterpret_cast<const i32x4_t*>(base + (OFF) + (a_rd ^ KS1) + i * 16 * ROWB);            \
+    } else {                                                                                                 \
+      af[i][0] = *reinterpret_cast<const bf16x8_t*>(base + (OFF) + a_rd + i * 16 * ROWB);                    \
+      af[i][1] = *reinterpret_cast<const bf16x8_t*>(base + (OFF) + (a_rd ^ KS1) + i * 16 * ROWB);            \
+    }                                                                                                        \
   }
-#define LOAD_B(BF, OFF)                                                                                      \
+#define LOAD_B(BF, BQ, SF, OFF)                                                                              \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                             \
-    BF[j][0] = *reinterpret_cast<const bf16x8_t*>(base + (OFF) + b_rd + j * 16 * ROWB);                      \
-    BF[j][1] = *reinterpret_cast<const bf16x8_t*>(base + (OFF) + (b_rd ^ 64) + j * 16 * ROWB);               \
+    if constexpr (FP8) {                                                                                     \
+      BQ[j].lo = *reinterpret_cast<const i32x4_t*>(base + (OFF) + b_rd + j * 16 * ROWB);                     \
+      BQ[j].hi = *reinterpret_cast<const i32x4_t*>(base + (OFF) + (b_rd ^ KS1) + j * 16 * ROWB);             \
+      SF[j] = *reinterpret_cast<const unsigned*>(sb_rd + sbuf_off + (((OFF) == OFF_B1 ? 32 : 0) + j * 16) * 4);  \
+    } else {                                                                                                 \
+      BF[j][0] = *reinterpret_cast<const bf16x8_t*>(base + (OFF) + b_rd + j * 16 * ROWB);                    \
+      BF[j][1] = *reinterpret_cast<const bf16x8_t*>(base + (OFF) + (b_rd ^ KS1) + j * 16 * ROWB);            \
+    }                                                                                                        \
   }
-#define MFMA_QUAD(MQ, NQ, BF)                                                                                \
+// fp8: a freshly loaded scale dword holds the K tile's four block scales; this lane's block is fgrp -> byte 0.  Run after the
+// phase's lgkmcnt(0); the s_nop covers the VALU-write -> MFMA-operand wait states, which hipcc does not pad for inline asm.
+#define SCALE_FIX(ARR, N)                                                                                    \
+  if constexpr (FP8) {                                                                                       \
+    _Pragma("unroll") for (int q = 0; q < (N); ++q) ARR[q] = __builtin_amdgcn_ubfe(ARR[q], sshift, 8);       \
+    asm volatile("s_nop 1");                                                                                 \
+  }
+#define MFMA_QUAD(MQ, NQ, BF, BQ, SF)                                                                        \
   __builtin_amdgcn_s_setprio(1);                                                                             \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                            \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                               \
-    acc[(MQ) * 4 + i][(NQ) * 2 + j] =                                                                        \
-        __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][ks], af[i][ks], acc[(MQ) * 4 + i][(NQ) * 2 + j], 0, 0, 0); \
+  if constexpr (FP8) {                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+      mfma_mx(acc[(MQ) * 4 + i][(NQ) * 2 + j], BQ[j], afq[i], SF[j], sfa[i]);                                \
+  } else {                                                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+      acc[(MQ) * 4 + i][(NQ) * 2 + j] =                                                                      \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][ks], af[i][ks], acc[(MQ) * 4 + i][(NQ) * 2 + j], 0, 0, 0); \
+  }                                                                                                          \
   __builtin_amdgcn_s_setprio(0);
 
 // K tile T of the current output tile, read from LDS buffer BUF.  The staged K tile index is T+1 / T+2 of the current
@@ -238,14 +336,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
 #define K_TILE(BUF, T)                                                                                       \
   {                                                                                                          \
     const char* base = smem + (BUF) * BUF_BYTES;                                                             \
+    constexpr int sbuf_off = (BUF) * 2048;                                                                   \
     const int t = (T);                                                                                       \
     /* P0 */                                                                                                 \
-    LOAD_B(bf0, OFF_B0);                                                                                     \
+    LOAD_B(bf0, bq0, sf0, OFF_B0);                                                                                \
+    LOAD_A_SCALES(OFF_A0);                                                                                   \
     SCHED_FENCE();                                                                                           \
     LOAD_A(OFF_A0);                                                                                          \
-    if (CAN_ISSUE(1)) stage((BUF) ^ 1, OFF_A1, a.A, asrc[1], t + 1 + kwrap);                                      \
+    if (CAN_ISSUE(1)) {                                                                                      \
+      stage((BUF) ^ 1, OFF_A1, a.A, asrc[1], t + 1 + kwrap);                                                      \
+      stage_scales((BUF) ^ 1, t + 1 + kwrap);                                                                \
+    }                                                                                                        \
     SCHED_FENCE();                                                                                           \
-    WAIT_LGKM(8);                                                                                            \
+    WAIT_LGKM(8); /* everything in front of the eight A reads is back: the B reads (and the fp8 scales) */   \
     WG_BARRIER();                                                                                            \
     unsigned tkv = 0;                                                                                        \
     if (dyn && t == 1) tkv = *(volatile __attribute__((address_space(3))) unsigned*)LDS_PTR(smem + SLOT_OFF); \
@@ -254,28 +357,33 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
       lid_next = start + bpx + (int)__builtin_amdgcn_readfirstlane(tkv);                                     \
       have_next = lid_next < end;                                                                            \
     }                                                                                                        \
+    SCALE_FIX(sf0, 2);                                                                                       \
+    SCALE_FIX(sfa, 4);                                                                                       \
     SCHED_FENCE();                                                                                           \
-    MFMA_QUAD(0, 0, bf0);                                                                                    \
+    MFMA_QUAD(0, 0, bf0, bq0, sf0);                                                                               \
     WG_BARRIER();                                                                                            \
     if ((BUF) == 0 && t == nk - 2 && have_next) { /* from here on the NEXT output tile is staged */          \
       set_sources(lid_next);                                                                                 \
       kwrap = -nk;                                                                                           \
     }                                                                                                        \
     /* P1 */                                                                                                 \
-    LOAD_B(bf1, OFF_B1);                                                                                     \
+    LOAD_B(bf1, bq1, sf1, OFF_B1);                                                                                \
     if (CAN_ISSUE(2)) stage((BUF), OFF_B0, a.W, wsrc[0], t + 2 + kwrap);                                          \
     WG_BARRIER();                                                                                            \
     WAIT_LGKM(0);                                                                                            \
+    SCALE_FIX(sf1, 2);                                                                                       \
     SCHED_FENCE();                                                                                           \
-    MFMA_QUAD(0, 1, bf1);                                                                                    \
+    MFMA_QUAD(0, 1, bf1, bq1, sf1);                                                                               \
     WG_BARRIER();                                                                                            \
     /* P2 */                                                                                                 \
+    LOAD_A_SCALES(OFF_A1);                                                                                   \
     LOAD_A(OFF_A1);                                                                                          \
     if (CAN_ISSUE(2)) stage((BUF), OFF_A0, a.A, asrc[0], t + 2 + kwrap);                                          \
     WG_BARRIER();                                                                                            \
     WAIT_LGKM(0);                                                                                            \
+    SCALE_FIX(sfa, 4);                                                                                       \
     SCHED_FENCE();                                                                                           \
-    MFMA_QUAD(1, 1, bf1);                                                                                    \
+    MFMA_QUAD(1, 1, bf1, bq1, sf1);                                                                               \
     WG_BARRIER();                                                                                            \
     /* P3 */                                                                                                 \
     if (CAN_ISSUE(2)) {                                                                                      \
@@ -286,7 +394,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     }                                                                                                        \
     if (dyn && (BUF) == 0 && t == nk - 2 && have_next) fetch_ticket(); /* tile after next, see epilogue */   \
     WG_BARRIER();                                                                                            \
-    MFMA_QUAD(1, 0, bf0);                                                                                    \
+    MFMA_QUAD(1, 0, bf0, bq0, sf0);                                                                               \
     WG_BARRIER();                                                                                            \
   }
 
@@ -302,6 +410,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
       K_TILE(1, kt + 1);
     }
     if (wr == 0) WG_BARRIER();  // re-align the wave rows: both run the epilogue in the same interval
+    if constexpr (FP8) asm volatile("s_nop 15\n\ts_nop 3");   // last asm MFMA's result -> first VALU read (16-pass: 18 states)
     STAMP();
 
     // ---- epilogue: two adjacent 16x16 tiles at a time (gemm_tc_epi.h epilogue_pair_bf16); bias from LDS ----
@@ -314,6 +423,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     // front of this write) finds it done.  Every wave is past its K tile 1 read of the slot.
     if (dyn && have_next) publish_ticket();
     constexpr bool kReadModify = EPI == EPI_RESID || EPI == EPI_PATCH;
+    constexpr bool kLnConsumer = LN && (EPI == EPI_STORE || EPI == EPI_GELU);
+    constexpr bool kLnProducer = LN && EPI == EPI_RESID;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 gj[4] = {z4, z4, z4, z4};
     if constexpr (EPI == EPI_RESID) {
@@ -345,6 +456,28 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
         }
       }
     };
+    if constexpr (kLnConsumer) {
+      // LN-fold consumer: acc <- rstd * (acc - mean * c) in place, FIRST and for all 128 accumulators (the row's (mean, rstd)
+      // from this tile's LDS slot, the wave's 64 ln_c values from its own slot), then the plain epilogue with bias = d.
+      // Done inside the store loop instead, the extra live values (c, mean/rstd) sat on top of the GELU temporaries and the
+      // fc1 epilogue took twice as long.
+      const char* smr = smem + LNMR_OFF + tpar * 2048 + (wr * 128 + frow) * 8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {     // column tile outermost: 4 ln_c values live at a time, (mean, rstd) re-read per row
+        const float4 c = *reinterpret_cast<const float4*>(slnc + (j * 16 + fgrp * 4) * 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float2 mr = *reinterpret_cast<const float2*>(smr + ((i >> 2) * 64 + (i & 3) * 16) * 8);
+          const float nm = -mr.x;
+          acc[i][j][0] = mr.y * fmaf(nm, c.x, acc[i][j][0]);
+          acc[i][j][1] = mr.y * fmaf(nm, c.y, acc[i][j][1]);
+          acc[i][j][2] = mr.y * fmaf(nm, c.z, acc[i][j][2]);
+          acc[i][j][3] = mr.y * fmaf(nm, c.w, acc[i][j][3]);
+        }
+      }
+      SCHED_FENCE();   // keep the pre-pass out of the store loop (its values would pile onto the GELU temporaries)
+    }
+    {
     if (MVF_EPI_PIPE) prefetch(0);
 #pragma unroll
     for (int ih = 0; ih < NB; ++ih) {
@@ -355,15 +488,40 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
       for (int ii = 0; ii < EB; ++ii) {
         const int i = ih * EB + ii;
         const int m = m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + frow;
+        if constexpr (!kLnProducer) {
 #pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-          const int nb = n0 + wc * 64 + jp * 32;
-          // N % 32 == 0: a tile pair is in range or out as a whole
-          epilogue_pair_bf16<EPI>(a, m, m < a.M && nb < a.N, nb, fgrp, acc[i][2 * jp], acc[i][2 * jp + 1], bj[2 * jp],
-                                  bj[2 * jp + 1], kReadModify ? addb[ii][2 * jp] : z4,
-                                  kReadModify ? addb[ii][2 * jp + 1] : z4, gj[2 * jp], gj[2 * jp + 1]);
+          for (int jp = 0; jp < 2; ++jp) {
+            const int nb = n0 + wc * 64 + jp * 32;
+            // N % 32 == 0: a tile pair is in range or out as a whole
+            epilogue_pair_bf16<EPI>(a, m, m < a.M && nb < a.N, nb, fgrp, acc[i][2 * jp], acc[i][2 * jp + 1], bj[2 * jp],
+                                    bj[2 * jp + 1], kReadModify ? addb[ii][2 * jp] : z4,
+                                    kReadModify ? addb[ii][2 * jp + 1] : z4, gj[2 * jp], gj[2 * jp + 1]);
+          }
+        } else {
+          const float2 mr = make_float2(0.f, 1.f);   // producer side (EPI_RESID): xb + row sums
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) {
+            const int nb = n0 + wc * 64 + jp * 32;
+            const float4 c0 = z4, c1 = z4;
+            epilogue_pair_bf16_ln<EPI>(a, m, m < a.M && nb < a.N, nb, fgrp, acc[i][2 * jp], acc[i][2 * jp + 1], bj[2 * jp],
+                                       bj[2 * jp + 1], kReadModify ? addb[ii][2 * jp] : z4,
+                                       kReadModify ? addb[ii][2 * jp + 1] : z4, gj[2 * jp], gj[2 * jp + 1], mr, c0, c1, s1, s2);
+          }
+          if constexpr (kLnProducer) {
+            if (a.stats != nullptr) {   // kernel argument: every lane runs the cross-lane sums
+              s1 = row_quad_sum(s1);
+              s2 = row_quad_sum(s2);
+              const int slice = (n0 >> 6) + wc;
+              // slice-major [N/64][M][2]: the 16 rows of a wave-store are 128 contiguous bytes (row-major, 8-byte stores 96 B
+              // apart, cost 40 k cycles per tile: every one its own partial-line write)
+              if (fgrp == 0 && m < a.M && slice * 64 < a.N)
+                *reinterpret_cast<float2*>(a.stats + ((size_t)slice * a.M + m) * 2) = make_float2(s1, s2);
+            }
+          }
         }
       }
+    }
     }
     STAMP();
     if (!have_next) break;
@@ -372,6 +530,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     lid = lid_next;
+    if constexpr (LN) tpar ^= 1;
     WAIT_LGKM(0);        // this wave's bias reads are done before its bias slot is re-staged
     stage_bias(lid);     // older than every DMA the coming vmcnt(6) waits leave in flight
   }
@@ -436,14 +595,14 @@ unsigned* sched_slot() {
   return ring == nullptr ? nullptr : ring + (size_t)(next.fetch_add(1) & 1023u) * 16;
 }
 
-template <int EPI, bool DBG = false>
+template <int EPI, bool DBG = false, bool LN = false, bool FP8 = false>
 int launch(const GemmTcArgs& a0, bool persistent, hipStream_t st) {
   GemmTcArgs a = a0;
   static const bool force_static = getenv("MVF_GEMM_STATIC") != nullptr;   // A/B measurements only
   a.sched = persistent && !force_static ? sched_slot() : nullptr;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tc256_kernel<EPI, DBG>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tc256_kernel<EPI, DBG, LN, FP8>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
@@ -451,7 +610,7 @@ int launch(const GemmTcArgs& a0, bool persistent, hipStream_t st) {
   // persistent: one workgroup per CU (a multiple of 8 so that every XCD gets the same number); otherwise (A/B
   // measurements) one workgroup per tile -- the same kernel, every workgroup then runs the cold prologue
   const int grid = persistent ? std::min(ntiles, std::max(8, num_cus() & ~7)) : ntiles;
-  hipLaunchKernelGGL((gemm_tc256_kernel<EPI, DBG>), dim3(grid), dim3(512), LDS_BYTES, st, a);
+  hipLaunchKernelGGL((gemm_tc256_kernel<EPI, DBG, LN, FP8>), dim3(grid), dim3(512), LDS_BYTES, st, a);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }
@@ -466,14 +625,35 @@ extern "C" int mvf_gemm_tc_set_cus(int n) {
   return MVF_OK;
 }
 
+int mvf_gemm_tc256_num_wgs() { return std::max(8, num_cus() & ~7); }
+
 int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, bool persistent, hipStream_t st) {
-  if (a.K % 128 != 0 || a.K < 128 || a.N % 32 != 0) return MVF_ERR_ARG;
+  const bool fp8 = a.sa != nullptr;
+  if (a.K % (fp8 ? 256 : 128) != 0 || a.K < 128 || a.N % 32 != 0) return MVF_ERR_ARG;
   // 32-bit operand offsets inside the kernel
   const size_t wrows = a.batch_rows > 0 ? (size_t)(a.M / a.batch_rows) * a.w_batch_rows : (size_t)a.N;
   if ((size_t)a.M * a.lda * 2 >= (1ull << 32) || wrows * a.ldw * 2 >= (1ull << 32) || a.M >= (1 << 24) ||
       wrows >= (1u << 24) || a.lda >= (1 << 23) || a.ldw >= (1 << 23))
     return MVF_ERR_UNSUPPORTED;
+  if (fp8) {   // MX-fp8 operands (validated by mvf_gemm_fp8): no LN fold, no stacked batches, no stamps
+    if (a.sw == nullptr || a.batch_rows != 0 || a.dbg != nullptr || a.ln_mr != nullptr || a.xb != nullptr || a.stats != nullptr)
+      return MVF_ERR_ARG;
+    switch (epi) {
+      case EPI_STORE: return launch<EPI_STORE, false, false, true>(a, persistent, st);
+      case EPI_GELU: return launch<EPI_GELU, false, false, true>(a, persistent, st);
+      case EPI_RESID: return launch<EPI_RESID, false, false, true>(a, persistent, st);
+    }
+    return MVF_ERR_ARG;
+  }
   if (a.dbg != nullptr) return epi == EPI_STORE ? launch<EPI_STORE, true>(a, persistent, st) : MVF_ERR_UNSUPPORTED;
+  if (a.ln_mr != nullptr || a.xb != nullptr || a.stats != nullptr) {   // LN-fold extras (validated by mvf_gemm_tc_impl)
+    switch (epi) {
+      case EPI_STORE: return launch<EPI_STORE, false, true>(a, persistent, st);
+      case EPI_GELU: return launch<EPI_GELU, false, true>(a, persistent, st);
+      case EPI_RESID: return launch<EPI_RESID, false, true>(a, persistent, st);
+    }
+    return MVF_ERR_ARG;
+  }
   switch (epi) {
     case EPI_STORE: return launch<EPI_STORE>(a, persistent, st);
     case EPI_GELU: return launch<EPI_GELU>(a, persistent, st);

@@ -24,7 +24,35 @@ struct GemmTcArgs {
   // gemm_tc256 only: A / C rows are `batch_rows`-row batches stacked along M (a multiple of 256), batch b multiplying rows
   // [b * w_batch_rows, b * w_batch_rows + N) of W (split-K weight gradients); batch_rows == 0: one plain GEMM
   int batch_rows, w_batch_rows;
+  // gemm_tc (128x128) only: the launch covers rows [row0, M) -- the tail of a GEMM whose whole rounds of 256x256 tiles went to
+  // gemm_tc256 (mvf_gemm_tc_impl); every index below stays a GLOBAL row
+  int row0;
+  // ---- LayerNorm folded into the GEMMs (gemm_tc256 only; DESIGN.md "LayerNorm folded into the GEMMs") ----
+  // producer side, EPI_RESID: besides the fp32 residual stream also store xb = bf16(x_new) [M, ldxb] (the next GEMM's A
+  // operand) and, per row and per 64-column wave slice, the partial (sum, sum of squares) of x_new: stats[N/64][M][2]
+  char* xb;
+  int ldxb;
+  float* stats;
+  // consumer side, EPI_STORE / EPI_GELU: A holds the UN-normalised xb and W holds gamma (.) W; with the row's (mean, rstd)
+  // = ln_mr[m][2] and ln_c[n] = sum_k W'[n,k]:  C = rstd * (acc - mean * ln_c[n]) + bias[n]   (bias = b + W beta)
+  const float* ln_mr;
+  const float* ln_c;
+  // ---- MX-fp8 operands (gemm_tc256 FP8 variants): A / W hold OCP e4m3 bytes (lda / ldw in bytes = elements); sa[K/128][M]
+  // and sw[K/128][N] hold, per row and K tile of 128, the four E8M0 block scales (32 consecutive k each) packed in one dword
+  // (block b of the K tile in byte b).  NULL = bf16 operands.
+  const unsigned* sa;
+  const unsigned* sw;
 };
+
+// sum over the four lanes that hold one output row (lane, lane^16, lane^32, lane^48), result in all of them; fixed order
+__device__ __forceinline__ float row_quad_sum(float v) {
+  const uint32_t u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // rows of 16 lanes: [v0 v0 v2 v2], [v1 v1 v3 v3]
+  const float w = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const uint32_t x = __float_as_uint(w);
+  const auto b = __builtin_amdgcn_permlane32_swap(x, x, false, false);   // halves: [lo lo], [hi hi]
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
@@ -56,15 +84,27 @@ __device__ __forceinline__ void store4<bf16_t>(char* base, size_t elem_off, cons
 
 
 // One lane's 4 consecutive output columns (n .. n+3) of row m: bias + the epilogue selected by EPI.
-template <typename T, int EPI>
-__device__ __forceinline__ void epilogue4(const GemmTcArgs& a, int m, int n, const f32x4_t& acc) {
+// LN (bf16 only): the LN-fold extras, as in epilogue_pair_bf16_ln -- `mr` = the row's (mean, rstd) for the consumer side;
+// on the producer side the four updated residual values come back in vout (the caller sums them in gemm_tc256's order).
+template <typename T, int EPI, bool LN = false>
+__device__ __forceinline__ void epilogue4(const GemmTcArgs& a, int m, int n, const f32x4_t& acc,
+                                          float2 mr = make_float2(0.f, 1.f), float* vout = nullptr) {
   size_t out_row = (size_t)m;
   float v[4];
   const float4 b = a.bias ? *reinterpret_cast<const float4*>(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-  v[0] = acc[0] + b.x;
-  v[1] = acc[1] + b.y;
-  v[2] = acc[2] + b.z;
-  v[3] = acc[3] + b.w;
+  if constexpr (LN && (EPI == EPI_STORE || EPI == EPI_GELU)) {
+    const float4 c = *reinterpret_cast<const float4*>(a.ln_c + n);
+    const float nm = -mr.x;
+    v[0] = fmaf(mr.y, fmaf(nm, c.x, acc[0]), b.x);
+    v[1] = fmaf(mr.y, fmaf(nm, c.y, acc[1]), b.y);
+    v[2] = fmaf(mr.y, fmaf(nm, c.z, acc[2]), b.z);
+    v[3] = fmaf(mr.y, fmaf(nm, c.w, acc[3]), b.w);
+  } else {
+    v[0] = acc[0] + b.x;
+    v[1] = acc[1] + b.y;
+    v[2] = acc[2] + b.z;
+    v[3] = acc[3] + b.w;
+  }
   if constexpr (EPI == EPI_STORE) {
     store4<T>(a.C, out_row * a.ldc + n, v);
   } else if constexpr (EPI == EPI_GELU) {
@@ -83,6 +123,11 @@ __device__ __forceinline__ void epilogue4(const GemmTcArgs& a, int m, int n, con
     if (a.tap != nullptr) {  // tapped block output, CLS row dropped
       const int f = m / a.tpf, t = m - f * a.tpf;
       if (t > 0) store4<T>(a.tap, (size_t)(f * (a.tpf - 1) + t - 1) * a.ldt + n, v);
+    }
+    if constexpr (LN) {
+      if (a.xb != nullptr) store4<bf16_t>(a.xb, out_row * a.ldxb + n, v);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vout[r] = v[r];
     }
   } else {  // EPI_PATCH: row m = (frame f, patch p) -> token row f*tpf + 1 + p, + pos_embed[1+p]
     const int np = a.tpf - 1;
@@ -181,7 +226,76 @@ __device__ __forceinline__ void epilogue_pair_bf16(const GemmTcArgs& a, int m, b
   }
 }
 
+// The LN-fold form of epilogue_pair_bf16 (a function of its own: the plain kernels keep their exact code and registers).
+// LN fold: `mr` = the row's (mean, rstd) and c0/c1 = ln_c of the two tiles (EPI_STORE / EPI_GELU with a.ln_mr);
+// s1/s2 += sum / sum of squares of the row's new residual values in these two tiles (EPI_RESID with a.stats).
+template <int EPI>
+__device__ __forceinline__ void epilogue_pair_bf16_ln(const GemmTcArgs& a, int m, bool ok, int nb, int fgrp,
+                                                   const f32x4_t& acc0, const f32x4_t& acc1, const float4& b0,
+                                                   const float4& b1, const float4& add0, const float4& add1,
+                                                   const float4& g0, const float4& g1, const float2& mr, const float4& c0,
+                                                   const float4& c1, float& s1, float& s2) {
+  float v0[4], v1[4];
+  if constexpr (EPI == EPI_STORE || EPI == EPI_GELU) {
+    const float nm = -mr.x;
+    v0[0] = fmaf(mr.y, fmaf(nm, c0.x, acc0[0]), b0.x); v0[1] = fmaf(mr.y, fmaf(nm, c0.y, acc0[1]), b0.y);
+    v0[2] = fmaf(mr.y, fmaf(nm, c0.z, acc0[2]), b0.z); v0[3] = fmaf(mr.y, fmaf(nm, c0.w, acc0[3]), b0.w);
+    v1[0] = fmaf(mr.y, fmaf(nm, c1.x, acc1[0]), b1.x); v1[1] = fmaf(mr.y, fmaf(nm, c1.y, acc1[1]), b1.y);
+    v1[2] = fmaf(mr.y, fmaf(nm, c1.z, acc1[2]), b1.z); v1[3] = fmaf(mr.y, fmaf(nm, c1.w, acc1[3]), b1.w);
+  } else {
+    v0[0] = acc0[0] + b0.x; v0[1] = acc0[1] + b0.y; v0[2] = acc0[2] + b0.z; v0[3] = acc0[3] + b0.w;
+    v1[0] = acc1[0] + b1.x; v1[1] = acc1[1] + b1.y; v1[2] = acc1[2] + b1.z; v1[3] = acc1[3] + b1.w;
+  }
+  const int n0 = nb + fgrp * 4, n1 = nb + 16 + fgrp * 4;   // this lane's own columns in the two tiles
+  if constexpr (EPI == EPI_STORE) {
+    swap_store_bf16x8(a.C, (size_t)m * a.ldc, nb, fgrp, ok, v0, v1);
+  } else if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v0[r] = gelu_erf_fast(v0[r]); v1[r] = gelu_erf_fast(v1[r]); }
+    swap_store_bf16x8(a.C, (size_t)m * a.ldc, nb, fgrp, ok, v0, v1);
+  } else if constexpr (EPI == EPI_RESID) {
+    bool tap_ok = false;
+    size_t tap_off = 0;
+    if (a.ls != nullptr) {
+      v0[0] *= g0.x; v0[1] *= g0.y; v0[2] *= g0.z; v0[3] *= g0.w;
+      v1[0] *= g1.x; v1[1] *= g1.y; v1[2] *= g1.z; v1[3] *= g1.w;
+    }
+    v0[0] += add0.x; v0[1] += add0.y; v0[2] += add0.z; v0[3] += add0.w;
+    v1[0] += add1.x; v1[1] += add1.y; v1[2] += add1.z; v1[3] += add1.w;
+    if (ok) {
+      float* rp = a.resid + (size_t)m * a.ldr;
+      *reinterpret_cast<float4*>(rp + n0) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+      *reinterpret_cast<float4*>(rp + n1) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+      if (a.tap != nullptr) {  // tapped block output, CLS row dropped
+        const int f = m / a.tpf, t = m - f * a.tpf;
+        tap_ok = t > 0;
+        tap_off = (size_t)(f * (a.tpf - 1) + t - 1) * a.ldt;
+      }
+    }
+    if (a.tap != nullptr) swap_store_bf16x8(a.tap, tap_off, nb, fgrp, tap_ok, v0, v1);   // wave-uniform branch
+    {
+      if (a.xb != nullptr) swap_store_bf16x8(a.xb, (size_t)m * a.ldxb, nb, fgrp, ok, v0, v1);
+      if (a.stats != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s1 += v0[r] + v1[r];
+          s2 = fmaf(v0[r], v0[r], fmaf(v1[r], v1[r], s2));
+        }
+      }
+    }
+  } else {  // EPI_PATCH: row m = (frame f, patch p) -> token row f*tpf + 1 + p, + pos_embed[1+p]
+    if (ok) {
+      const int np = a.tpf - 1;
+      const int f = m / np, p = m - f * np;
+      float* rp = a.resid + ((size_t)f * a.tpf + 1 + p) * a.ldr;
+      *reinterpret_cast<float4*>(rp + n0) = make_float4(v0[0] + add0.x, v0[1] + add0.y, v0[2] + add0.z, v0[3] + add0.w);
+      *reinterpret_cast<float4*>(rp + n1) = make_float4(v1[0] + add1.x, v1[1] + add1.y, v1[2] + add1.z, v1[3] + add1.w);
+    }
+  }
+}
+
 }  // namespace gemm_tc
 
 // gemm_tc256.hip: bf16, K % 128 == 0.  Same contract as the 128x128 kernel's launch.
 int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, bool persistent, hipStream_t st);
+int mvf_gemm_tc256_num_wgs();   // workgroups of a persistent launch (one per CU of the stream's budget, a multiple of 8)

@@ -6,9 +6,19 @@
 #include "../../include/mvf_hip.h"
 
 // ---- backbone ----
+// LayerNorm folded into the GEMMs (bf16 256x256 kernel only): producer side (epi 2) xb / stats, consumer side (epi 0, 1)
+// ln_mr / ln_c -- see gemm_tc_epi.h GemmTcArgs
+struct MvfGemmLn {
+  void* xb;
+  int ldxb;
+  float* stats;
+  const float* ln_mr;
+  const float* ln_c;
+};
 int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C,
                      int ldc, float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tpf, int M,
-                     int N, int K, hipStream_t st, int batch_rows = 0, int w_batch_rows = 0);
+                     int N, int K, hipStream_t st, int batch_rows = 0, int w_batch_rows = 0, const MvfGemmLn* ln = nullptr);
+int mvf_ln_stats_finalize_impl(const float* part, int ns, float* mr, int rows, int D, float eps, hipStream_t st);
 int mvf_im2col_impl(int dtype, const float* img, void* out, int F, int H, int W, int P, int ldk, hipStream_t st);
 // K of the patch-embed GEMM: 3*P*P rounded up to 128 elements (the granule of both GEMM kernels and dtypes)
 static inline int mvf_patch_k(int P) { return (3 * P * P + 127) / 128 * 128; }

@@ -16,6 +16,10 @@ struct Ws {
   char* h;      // LN out / attention out [Mc, D] T
   char* qkv;    // [Mc, 3D] T
   char* hid;    // [Mc, 4D] T   (also holds the patch rows before the embed GEMM)
+  // LN fold (bf16): bf16 copy of the residual stream, row partial sums from the residual epilogues, (mean, rstd) per row
+  char* xb;     // [Mc, D] bf16
+  float* stats; // [D/64, Mc, 2]
+  float* mr;    // [Mc, 2]
 };
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -31,7 +35,7 @@ struct Prof {
 
 int timed_gemm(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
                float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tpf, int M, int N, int K,
-               hipStream_t st) {
+               hipStream_t st, const MvfGemmLn* ln = nullptr) {
   const bool rec = g_prof.on && g_prof.used < 4096;
   size_t slot = 0;
   if (rec) {
@@ -52,7 +56,8 @@ int timed_gemm(int dtype, int epi, const void* A, int lda, const void* W, int ld
     g_prof.flops[slot] = 2.0 * M * (double)N * K;
     (void)hipEventRecord(g_prof.ev[2 * slot], st);
   }
-  const int rc = mvf_gemm_tc_impl(dtype, epi, A, lda, W, ldw, bias, C, ldc, resid, ldr, tap, ldt, pos, ls, tpf, M, N, K, st);
+  const int rc = mvf_gemm_tc_impl(dtype, epi, A, lda, W, ldw, bias, C, ldc, resid, ldr, tap, ldt, pos, ls, tpf, M, N, K, st, 0,
+                                  0, ln);
   if (rec) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
   return rc;
 }
@@ -71,7 +76,15 @@ size_t carve(int dtype, int fc, int N, int D, int P, Ws* w, char* base) {
   char* qkv = take(Mc * 3 * D * esz);
   const size_t patch_bytes = (size_t)fc * (N - 1) * mvf_patch_k(P) * esz;
   char* hid = take(std::max(Mc * 4 * D * esz, patch_bytes));
-  if (w) { w->x = (float*)x; w->h = h; w->qkv = qkv; w->hid = hid; }
+  char* xb = nullptr;
+  char* stats = nullptr;
+  char* mr = nullptr;
+  if (dtype == MVF_BF16 && D % 64 == 0) {
+    xb = take(Mc * D * 2);
+    stats = take(Mc * (size_t)(D / 64) * 2 * 4);
+    mr = take(Mc * 2 * 4);
+  }
+  if (w) { w->x = (float*)x; w->h = h; w->qkv = qkv; w->hid = hid; w->xb = xb; w->stats = (float*)stats; w->mr = (float*)mr; }
   return off;
 }
 }  // namespace
@@ -118,23 +131,53 @@ extern "C" int mvf_vit_fwd_x(const MvfVitWeights* w, int dtype, const float* fra
     RUN(timed_gemm(dtype, EPI_PATCH, ws.hid, kp, w->patch_w, kp, w->patch_b, nullptr, 0, ws.x, D, nullptr, 0,
                          w->pos_embed, nullptr, N, fc * np, D, kp, st));
     RUN(mvf_cls_row_impl(ws.x, w->cls_token, w->pos_embed, fc, N, D, st));
+    // LN fold (bf16): where a layer's table entry qkv_c[l] / fc1_c[l] is set, qkv_w / fc1_w hold gamma (.) W, the bias table
+    // holds b + W beta, and the GEMM consumes xb = bf16(x) with the row statistics applied in its epilogue -- no LayerNorm
+    // kernel.  xb and the statistics' partial sums come out of the PREVIOUS residual epilogue (proj for LN2, the previous
+    // layer's fc2 for LN1); layer 0's LN1 follows the patch embedding and keeps the LayerNorm kernel.
+    const bool can_fold = dtype == MVF_BF16 && ws.xb != nullptr && D % 128 == 0;
+    auto folded = [&](const float* const* tab, int l) { return can_fold && tab != nullptr && l < w->depth && tab[l] != nullptr; };
+    const int ns = D / 64;
     for (int l = 0; l < w->depth; ++l) {
       int tap = -1;
       for (int j = 0; j < w->n_taps; ++j)
         if (w->taps[j] == l) tap = j;
-      RUN(mvf_layernorm_impl(dtype, ws.x, D, w->ln1_w[l], w->ln1_b[l], ws.h, D, Mc, D, w->ln_eps, st));
-      RUN(timed_gemm(dtype, EPI_STORE, ws.h, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0,
-                           nullptr, nullptr, N, Mc, 3 * D, D, st));
+      if (folded(w->qkv_c, l)) {
+        if (l == 0) return MVF_ERR_ARG;   // nothing produces layer 0's statistics
+        RUN(mvf_ln_stats_finalize_impl(ws.stats, ns, ws.mr, Mc, D, w->ln_eps, st));
+        const MvfGemmLn ln = {nullptr, 0, nullptr, ws.mr, w->qkv_c[l]};
+        RUN(timed_gemm(dtype, EPI_STORE, ws.xb, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0,
+                       nullptr, nullptr, N, Mc, 3 * D, D, st, &ln));
+      } else {
+        RUN(mvf_layernorm_impl(dtype, ws.x, D, w->ln1_w[l], w->ln1_b[l], ws.h, D, Mc, D, w->ln_eps, st));
+        RUN(timed_gemm(dtype, EPI_STORE, ws.h, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0,
+                       nullptr, nullptr, N, Mc, 3 * D, D, st));
+      }
       RUN(mvf_vit_attn_impl(dtype, ws.qkv, ws.h, fc, N, H, D, attn_variant, st));
-      RUN(timed_gemm(dtype, EPI_RESID, ws.h, D, w->proj_w[l], D, w->proj_b[l], nullptr, 0, ws.x, D, nullptr, 0,
-                           nullptr, w->ls1 ? w->ls1[l] : nullptr, N, Mc, D, D, st));
-      RUN(mvf_layernorm_impl(dtype, ws.x, D, w->ln2_w[l], w->ln2_b[l], ws.h, D, Mc, D, w->ln_eps, st));
-      RUN(timed_gemm(dtype, EPI_GELU, ws.h, D, w->fc1_w[l], D, w->fc1_b[l], ws.hid, 4 * D, nullptr, 0, nullptr, 0,
-                           nullptr, nullptr, N, Mc, 4 * D, D, st));
+      const bool fold2 = folded(w->fc1_c, l);
+      {
+        const MvfGemmLn ln = {fold2 ? ws.xb : nullptr, D, fold2 ? ws.stats : nullptr, nullptr, nullptr};
+        RUN(timed_gemm(dtype, EPI_RESID, ws.h, D, w->proj_w[l], D, w->proj_b[l], nullptr, 0, ws.x, D, nullptr, 0,
+                       nullptr, w->ls1 ? w->ls1[l] : nullptr, N, Mc, D, D, st, fold2 ? &ln : nullptr));
+      }
+      if (fold2) {
+        RUN(mvf_ln_stats_finalize_impl(ws.stats, ns, ws.mr, Mc, D, w->ln_eps, st));
+        const MvfGemmLn ln = {nullptr, 0, nullptr, ws.mr, w->fc1_c[l]};
+        RUN(timed_gemm(dtype, EPI_GELU, ws.xb, D, w->fc1_w[l], D, w->fc1_b[l], ws.hid, 4 * D, nullptr, 0, nullptr, 0,
+                       nullptr, nullptr, N, Mc, 4 * D, D, st, &ln));
+      } else {
+        RUN(mvf_layernorm_impl(dtype, ws.x, D, w->ln2_w[l], w->ln2_b[l], ws.h, D, Mc, D, w->ln_eps, st));
+        RUN(timed_gemm(dtype, EPI_GELU, ws.h, D, w->fc1_w[l], D, w->fc1_b[l], ws.hid, 4 * D, nullptr, 0, nullptr, 0,
+                       nullptr, nullptr, N, Mc, 4 * D, D, st));
+      }
       void* tap_ptr = nullptr;
       if (tap >= 0 && taps_out && taps_out[tap]) tap_ptr = (char*)taps_out[tap] + (size_t)f0 * np * D * esz;
-      RUN(timed_gemm(dtype, EPI_RESID, ws.hid, 4 * D, w->fc2_w[l], 4 * D, w->fc2_b[l], nullptr, 0, ws.x, D, tap_ptr,
-                           D, nullptr, w->ls2 ? w->ls2[l] : nullptr, N, Mc, D, 4 * D, st));
+      const bool fold_next = folded(w->qkv_c, l + 1);
+      {
+        const MvfGemmLn ln = {fold_next ? ws.xb : nullptr, D, fold_next ? ws.stats : nullptr, nullptr, nullptr};
+        RUN(timed_gemm(dtype, EPI_RESID, ws.hid, 4 * D, w->fc2_w[l], 4 * D, w->fc2_b[l], nullptr, 0, ws.x, D, tap_ptr,
+                       D, nullptr, w->ls2 ? w->ls2[l] : nullptr, N, Mc, D, 4 * D, st, fold_next ? &ln : nullptr));
+      }
     }
     if (x_out && hipMemcpyAsync(x_out + (size_t)f0 * N * D, ws.x, (size_t)Mc * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
       return MVF_ERR_ARG;
@@ -181,6 +224,16 @@ extern "C" int mvf_gemm_tc(int dtype, int epi, const void* A, int lda, const voi
                            int ldc, float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tpf,
                            int M, int N, int K, hipStream_t st) {
   return mvf_gemm_tc_impl(dtype, epi, A, lda, W, ldw, bias, C, ldc, resid, ldr, tap, ldt, pos, ls, tpf, M, N, K, st);
+}
+// mvf_gemm_tc with the LN-fold extras (bf16, K % 128 == 0): see MvfGemmLn / include/mvf_hip.h
+extern "C" int mvf_gemm_tc_ln(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C,
+                              int ldc, float* resid, int ldr, void* tap, int ldt, const float* ls, int tpf, void* xb, int ldxb,
+                              float* stats, const float* ln_mr, const float* ln_c, int M, int N, int K, hipStream_t st) {
+  const MvfGemmLn ln = {xb, ldxb, stats, ln_mr, ln_c};
+  return mvf_gemm_tc_impl(dtype, epi, A, lda, W, ldw, bias, C, ldc, resid, ldr, tap, ldt, nullptr, ls, tpf, M, N, K, st, 0, 0, &ln);
+}
+extern "C" int mvf_ln_stats_finalize(const float* part, int ns, float* mean_rstd, int rows, int D, float eps, hipStream_t st) {
+  return mvf_ln_stats_finalize_impl(part, ns, mean_rstd, rows, D, eps, st);
 }
 extern "C" int mvf_patchify(int dtype, const float* frames, void* out, int F, int H, int W, int P, hipStream_t st) {
   return mvf_im2col_impl(dtype, frames, out, F, H, W, P, 3 * P * P, st);

@@ -98,6 +98,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// LN fold: per-row partial (sum, sum of squares) written by the residual GEMM epilogues, slice-major [ns][rows][2] ->
+// (mean, rstd) [rows][2].  One thread per row (coalesced over rows for every slice); fixed summation order.  Variance as E[x^2] - mean^2 in fp32: its relative error is
+// 2^-24 * (1 + mean^2 / var), harmless for LayerNorm inputs (|mean| / std of a ViT residual row is O(1)).
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ part, int ns,
+                                                                float* __restrict__ mr, int rows, float inv_d, float eps) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const float2* p = reinterpret_cast<const float2*>(part) + row;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < ns; ++i) {
+    const float2 v = p[(size_t)i * rows];
+    s1 += v.x;
+    s2 += v.y;
+  }
+  const float mean = s1 * inv_d;
+  const float var = fmaxf(s2 * inv_d - mean * mean, 0.f);
+  reinterpret_cast<float2*>(mr)[row] = make_float2(mean, 1.0f / sqrtf(var + eps));
+}
+
 // fp32 -> bf16 cast (weights pre-pack)
 __global__ void cast_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n4) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -183,6 +202,14 @@ int mvf_cast_bf16_impl(const float* in, void* out, size_t n, hipStream_t st) {
   if (n4 == 0) return MVF_OK;
   const int grid = (int)std::min<size_t>((n4 + 255) / 256, 256 * 16);
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, st, in, (bf16_t*)out, n4);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+int mvf_ln_stats_finalize_impl(const float* part, int ns, float* mr, int rows, int D, float eps, hipStream_t st) {
+  MVF_CHECK_ARG(part && mr && rows > 0 && ns > 0 && D > 0);
+  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, part, ns, mr, rows, 1.0f / (float)D,
+                     eps);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

@@ -861,11 +861,16 @@ def scl_loss(emb, steps, seq_lens, masks, num_frames, negative_type, temperature
 # ------------------------------------------------------------------------------------------------
 # frozen ViT backbone
 # ------------------------------------------------------------------------------------------------
+# bf16 mode: fold every LayerNorm (except block 0's norm1) into the GEMM that consumes it (include/mvf_hip.h: qkv_c / fc1_c).
+# MVF_LN_FOLD=0 keeps the LayerNorm kernels (A/B measurements).
+VIT_LN_FOLD = os.environ.get('MVF_LN_FOLD', '1') != '0'
+
+
 class PackedViT:
     """Device-resident, dtype-converted copy of a ViT's weights in the layout mvf_vit_fwd wants, plus the
     pointer tables of `struct MvfVitWeights`.  Built once per (module version, dtype): the backbone is frozen."""
 
-    def __init__(self, sd, depth, dim, heads, patch, img, taps, dtype, ln_eps=1e-6):
+    def __init__(self, sd, depth, dim, heads, patch, img, taps, dtype, ln_eps=1e-6, ln_fold=None):
         self.code, self.tdtype = _dt(dtype)
         dev = sd['cls_token'].device
         if dev.type != 'cuda':
@@ -907,12 +912,40 @@ class PackedViT:
             arr = (ctypes.c_void_p * depth)(*[conv(sd[fmt % i]) for i in range(depth)])
             self.keep.append(arr)
             return ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p))
+        def ptr_table(ptrs):
+            arr = (ctypes.c_void_p * depth)(*ptrs)
+            self.keep.append(arr)
+            return ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p))
+
+        def folded(lin, norm, skip0):
+            """LayerNorm `norm` folded into the Linear `lin` that consumes it: per block (W' = gamma (.) W in bf16,
+            d = b + W beta, c[n] = sum_k bf16(W')[n, k]) -- c is taken from the ROUNDED weights the matrix cores multiply, so
+            that the row-mean term cancels exactly.  Block 0's norm1 (skip0) keeps the LayerNorm kernel."""
+            wp, bp, cp = [], [], []
+            for i in range(depth):
+                W = sd['blocks.%d.%s.weight' % (i, lin)].detach().double()
+                bias = sd['blocks.%d.%s.bias' % (i, lin)].detach().double()
+                if skip0 and i == 0:
+                    wp.append(mat(W.float())), bp.append(f32(bias.float())), cp.append(None)
+                    continue
+                g = sd['blocks.%d.%s.weight' % (i, norm)].detach().double()
+                beta = sd['blocks.%d.%s.bias' % (i, norm)].detach().double()
+                wp.append(mat((W * g[None, :]).float()))
+                c = self.keep[-1].double().sum(1)                   # the bf16 tensor `mat` just stored
+                cp.append(f32(c.float())), bp.append(f32((bias + W @ beta).float()))
+            return ptr_table(wp), ptr_table(bp), ptr_table(cp)
+
+        self.ln_fold = (VIT_LN_FOLD if ln_fold is None else bool(ln_fold)) and self.code == BF16 and dim % 128 == 0 and depth > 0
         w.ln1_w, w.ln1_b = table('blocks.%d.norm1.weight', f32), table('blocks.%d.norm1.bias', f32)
-        w.qkv_w, w.qkv_b = table('blocks.%d.attn.qkv.weight', mat), table('blocks.%d.attn.qkv.bias', f32)
         w.proj_w, w.proj_b = table('blocks.%d.attn.proj.weight', mat), table('blocks.%d.attn.proj.bias', f32)
         w.ln2_w, w.ln2_b = table('blocks.%d.norm2.weight', f32), table('blocks.%d.norm2.bias', f32)
-        w.fc1_w, w.fc1_b = table('blocks.%d.mlp.fc1.weight', mat), table('blocks.%d.mlp.fc1.bias', f32)
         w.fc2_w, w.fc2_b = table('blocks.%d.mlp.fc2.weight', mat), table('blocks.%d.mlp.fc2.bias', f32)
+        if self.ln_fold:
+            w.qkv_w, w.qkv_b, w.qkv_c = folded('attn.qkv', 'norm1', skip0=True)
+            w.fc1_w, w.fc1_b, w.fc1_c = folded('mlp.fc1', 'norm2', skip0=False)
+        else:
+            w.qkv_w, w.qkv_b = table('blocks.%d.attn.qkv.weight', mat), table('blocks.%d.attn.qkv.bias', f32)
+            w.fc1_w, w.fc1_b = table('blocks.%d.mlp.fc1.weight', mat), table('blocks.%d.mlp.fc1.bias', f32)
         if 'blocks.0.ls1.gamma' in sd:
             w.ls1, w.ls2 = table('blocks.%d.ls1.gamma', f32), table('blocks.%d.ls2.gamma', f32)
         self.struct = w

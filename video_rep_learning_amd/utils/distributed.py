@@ -180,9 +180,8 @@ class GradReducer:
         self.works = None
         if self.active:
             for i, p in enumerate(flat.params):
-                hook = self._make_hook(i)
-                p.register_post_accumulate_grad_hook(hook)    # gradients that travel through autograd
-                p._mvf_ready = hook                           # gradients a kernel wrote into the slot (ops.grad_ready)
+                p.register_post_accumulate_grad_hook(self._make_hook(i, False))   # gradients that travel through autograd
+                p._mvf_ready = self._make_hook(i, True)       # gradients a kernel wrote into the slot (ops.grad_ready)
         self.reset()
 
     def reset(self):
@@ -194,15 +193,17 @@ class GradReducer:
         s, e = self.buckets[b]
         self.works[b] = dist.all_reduce(self.flat.flat_g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def _make_hook(self, i):
+    def _make_hook(self, i, from_kernel):
         def hook(_param):
             b = self.bucket_of[i]
             if i in self.seen:
-                # One "final" signal per parameter and step.  A second one is harmless while the bucket still waits for other
-                # members, but once its all-reduce is in flight a late contribution would be added to the slot during or after
-                # the reduction: silently wrong, rank-dependent gradients.  No shipped module shares a parameter between two
+                # One "final" signal per parameter and step.  The autograd engine runs a parameter's AccumulateGrad node --
+                # and this hook -- even when the op's backward returned None for it (the kernel had written the slot and
+                # signalled already): that late call accumulates nothing and is ignored.  A second KERNEL signal after the
+                # bucket's all-reduce is in flight is a real bug: a contribution would be added to the slot during or after
+                # the reduction (silently wrong, rank-dependent gradients).  No shipped module shares a parameter between two
                 # kernel-accumulating ops; a future one must signal on its LAST use.
-                if self.works[b] is not None:
+                if from_kernel and self.works[b] is not None:
                     raise RuntimeError('GradReducer: parameter #%d signalled again after its bucket\'s all-reduce was launched '
                                        '(a parameter used by two gradient-accumulating ops must signal on the last use)' % i)
                 return

@@ -42,15 +42,32 @@ GEMM_NAMES = {(0, 2304, 768): 'qkv [M,768]x[2304,768]^T', (2, 768, 768): 'proj+r
 PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
 
 
-def rocprof_names(groups, dtype):
+def rocprof_names(groups, dtype, ln_fold):
+    """The same launches under the kernel names rocprofv3 prints, gemm_tc256_kernel<EPI, DBG, LN, FP8>: one kernel per
+    epilogue, so proj and fc2 share <2, ...>.  LN = true for the launches that carry the LN-fold extras: of a shape's 12
+    launches per forward, 11 in fold mode 2 for qkv (blocks 1..11 consume the folded norm1) and for fc2 (blocks 0..10 produce
+    bf16(x) + the row sums); 12 for fc1 / proj in the modes that fold norm2.  Averages are per shape group (HIP events cannot
+    tell the two names of one shape apart)."""
     by = {}
     for r in groups:
         e = r['epi']
-        k = 'gemm_tc256_kernel<%d, false>' % e if dtype == 'bf16' else 'gemm_tc_kernel<float, %d>' % e
-        d = by.setdefault(k, {'launches': 0, 'ms': 0.0})
-        d['launches'] += r['launches']
-        d['ms'] += r['ms']
-    return {k: {'launches': d['launches'], 'avg_us': round(d['ms'] * 1e3 / max(d['launches'], 1), 1)} for k, d in by.items()}
+        if dtype != 'bf16':
+            parts = [('gemm_tc_kernel<float, %d, false>' % e, 1.0)]
+        else:
+            qkv, fc1 = e == 0, e == 1
+            fc2, proj = e == 2 and r['k'] > r['n'], e == 2 and r['k'] == r['n']
+            frac = 0.0
+            if (qkv or fc2) and ln_fold in (1, 2):
+                frac = 11.0 / 12.0
+            if (fc1 or proj) and ln_fold in (1, 3):
+                frac = 1.0
+            parts = [('gemm_tc256_kernel<%d, false, true, false>' % e, frac), ('gemm_tc256_kernel<%d, false, false, false>' % e, 1.0 - frac)]
+        for k, f in parts:
+            if f > 0:
+                d = by.setdefault(k, {'launches': 0.0, 'ms': 0.0})
+                d['launches'] += r['launches'] * f
+                d['ms'] += r['ms'] * f
+    return {k: {'launches': int(round(d['launches'])), 'avg_us': round(d['ms'] * 1e3 / max(d['launches'], 1e-9), 1)} for k, d in by.items()}
 
 
 def pmc_traffic(name):
@@ -294,7 +311,7 @@ def main():
         groups = []
         for g in range(ng.value):
             name = GEMM_NAMES.get((epi[g], nn[g], kk[g]), 'gemm epi%d N=%d K=%d' % (epi[g], nn[g], kk[g]))
-            groups.append({'name': name, 'epi': epi[g], 'launches': cnt[g], 'ms': ms[g], 'flop': fl[g],
+            groups.append({'name': name, 'epi': epi[g], 'n': nn[g], 'k': kk[g], 'launches': cnt[g], 'ms': ms[g], 'flop': fl[g],
                            'avg_us': round(ms[g] * 1e3 / max(cnt[g], 1), 1),
                            'tflops': round(fl[g] / (ms[g] * 1e-3) / 1e12, 1) if ms[g] > 0 else 0.0})
         dom = max(groups, key=lambda r: r['ms'])       # the GEMM shape the step spends most time in
@@ -312,7 +329,8 @@ def main():
                               for r in groups},
                 # the same launches under the names rocprofv3 prints: one kernel per epilogue, so proj and fc2 (and
                 # nothing else) share `gemm_tc256_kernel<2, false>`; compare with `bench.py --serial` under rocprofv3
-                'rocprof_kernels': rocprof_names(groups, a.dtype)}
+                'rocprof_kernels': rocprof_names(groups, a.dtype, ops.VIT_LN_FOLD),
+                'ln_fold': {0: 'off', 1: 'norm1 (blocks 1..) and norm2 folded into qkv / fc1', 2: 'norm1 of blocks 1.. folded into the qkv GEMM (default)', 3: 'norm2 folded into fc1'}[ops.VIT_LN_FOLD]}
     if world > 1:
         dist.barrier()
 

@@ -26,6 +26,7 @@ extern "C" {
 
 #define MVF_F32 0
 #define MVF_BF16 1
+#define MVF_FP8 2   /* mvf_vit_fwd only: MX-fp8 GEMM operands (OCP e4m3 + E8M0 scale per 32 k), bf16 everywhere else */
 
 /* gemm_tc epilogues */
 #define MVF_EPI_STORE 0 /* C = A W^T + b                                  */
@@ -64,6 +65,9 @@ typedef struct MvfVitWeights {
    * Block.forward: x + attn(norm1(x)); x + mlp(norm2(x))).  Same for fc1_c / norm2.  qkv_c[0] must be NULL (block 0's
    * norm1 follows the patch embedding). */
   const float* const* qkv_c; const float* const* fc1_c;
+  /* dtype MVF_FP8: qkv_w / proj_w / fc1_w / fc2_w hold e4m3 bytes [N, K] and these tables their block scales [K/128][N]
+   * dwords (mvf_quant_mxfp8's layout); patch_w stays bf16, qkv_c / fc1_c must be NULL (no LN fold). */
+  const unsigned* const* qkv_s; const unsigned* const* proj_s; const unsigned* const* fc1_s; const unsigned* const* fc2_s;
 } MvfVitWeights;
 
 size_t mvf_vit_workspace_bytes(int dtype, int frames_per_chunk, int tokens, int dim, int patch);
@@ -100,6 +104,26 @@ int mvf_gemm_tc_ln(int dtype, int epi, const void* A, int lda, const void* W, in
                    float* resid, int ldr, void* tap, int ldt, const float* ls, int tokens_per_frame, void* xb, int ldxb,
                    float* stats, const float* ln_mr, const float* ln_c, int M, int N, int K, hipStream_t stream);
 int mvf_ln_stats_finalize(const float* part, int ns, float* mean_rstd, int rows, int D, float eps, hipStream_t stream);
+/* out [M, ldo] fp32 = A W^T + bias [+ addend [M, ldo]] with bf16 A [M, K] / W [N, K]: the residual epilogue out of place
+ * (addend NULL: none) -- nn.Linear forward / input gradient of the TRAINABLE backbone blocks (transformer.py:364-392) */
+int mvf_gemm_tc_f32(const void* A, int lda, const void* W, int ldw, const float* bias, float* out, int ldo, const float* addend,
+                    int M, int N, int K, hipStream_t stream);
+/* MX-fp8 (BASELINE configs[4], MI355X.COMPUTE_DTYPE fp8).  Values: OCP e4m3 bytes, row-major; scales: one E8M0 byte per 32
+ * consecutive k of a row, the four bytes of a 128-wide K tile in one dword, laid out scales[K/128][rows] (block b in byte b);
+ * scale rule: the smallest power of two with amax / scale <= 448.
+ *   mvf_quant_mxfp8      x [rows, K] (bf16 or f32, leading dimension ldx ELEMENTS) -> q [rows, K] (ldq bytes) + scales
+ *   mvf_layernorm_mxfp8  LayerNorm(x) (timm norm1 / norm2, fp32 rows `in_stride` floats apart) -> q + scales; D % 256 == 0
+ *   mvf_gemm_fp8         C = epi(A W^T + bias) like mvf_gemm_tc (epi 0 / 1: bf16 C, epi 2: fp32 residual + bf16 tap) with
+ *                        MX-fp8 A [M, K] / W [N, K] on v_mfma_scale_f32_16x16x128_f8f6f4; K % 256 == 0, N % 32 == 0.
+ *                        epi 1 with c_scales != NULL: the GELU output is quantised in the epilogue -- C = e4m3 bytes
+ *                        [M, ldc], c_scales [N/128][M] (N % 128 == 0): the next GEMM's A operand, no bf16 round trip */
+int mvf_quant_mxfp8(int in_dtype, const void* x, size_t ldx, void* q, size_t ldq, unsigned* scales, int rows, int K,
+                    hipStream_t stream);
+int mvf_layernorm_mxfp8(const float* x, size_t in_stride, const float* g, const float* b, void* q, size_t ldq, unsigned* scales,
+                        int rows, int D, float eps, hipStream_t stream);
+int mvf_gemm_fp8(int epi, const void* A, int lda, const unsigned* sa, const void* W, int ldw, const unsigned* sw,
+                 const float* bias, void* C, int ldc, unsigned* c_scales, float* resid, int ldr, void* tap, int ldt,
+                 const float* ls, int tokens_per_frame, int M, int N, int K, hipStream_t stream);
 /* bf16 only, K % 128 == 0: M/batch_rows independent GEMMs stacked along M (batch_rows % 256 == 0), batch b using rows
  * [b * w_batch_rows, b * w_batch_rows + N) of W: the split-K form of a weight gradient dW = dY^T X over the tokens (each
  * batch one chunk of the token axis, fp32 partial sums with epi = 2 into a zeroed resid; trainable backbone blocks) */
@@ -125,6 +149,14 @@ int mvf_layernorm_fwd(int out_dtype, const float* x, size_t in_stride, const flo
  * 4 = streamed 64-key blocks, 5 = the streamed kernel for every N (2..5: A/B measurements) */
 int mvf_vit_attn_fwd(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t stream);
 int mvf_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t stream);
+int mvf_cast_bf16_f32(const void* in, float* out, size_t n, hipStream_t stream);     /* n % 4 == 0 */
+/* ViT attention of a TRAINABLE block in bf16 (timm Attention inside ViTBackEnd, models/transformer.py:364-392; fp16 autocast
+ * in the reference): forward = mvf_vit_attn_fwd on the streamed kernel, also writing the per-query log2-domain log-sum-exp
+ * lse [F, H, 16 * ceil(N / 16)]; backward: qkv / o / d_o bf16 as in the forward's layout, delta = caller-owned scratch
+ * shaped like lse, dqkv [F*N, 3*D] fp32 (every element of the q, k, v column blocks is written).  Owner-computes, no atomics. */
+int mvf_vit_attn_fwd_lse(const void* qkv, void* out, float* lse, int F, int N, int H, int D, hipStream_t stream);
+int mvf_vit_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, float* dqkv, int F, int N,
+                     int H, int D, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Trainable head, fp32, forward + backward

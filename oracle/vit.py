@@ -115,7 +115,24 @@ def _ident(x):
     return x
 
 
+def mx_quant(t):
+    """MX-fp8 quantise-dequantise along the last dimension (the product's fp8 mode, csrc/mxfp8.hip): blocks of 32
+    consecutive elements share a power-of-two scale -- the smallest with amax / scale <= 448 -- and the scaled values are
+    rounded to OCP e4m3 (round to nearest even)."""
+    shp = t.shape
+    assert shp[-1] % 32 == 0, shp
+    b = t.reshape(*shp[:-1], shp[-1] // 32, 32).float()
+    amax = b.abs().amax(-1, keepdim=True)
+    m, e = torch.frexp(amax)                       # amax = m * 2^e, m in [0.5, 1)
+    exp = (e - 9 + (m > 0.875).to(e.dtype)).clamp(-127, 126)
+    scale = torch.ldexp(torch.ones_like(amax), exp)
+    q = (b / scale).to(torch.float8_e4m3fn).float() * scale
+    return q.reshape(shp).to(t.dtype)
+
+
 def vit_block(x, w, p, heads, eps=1e-6, emulate=None):
+    if emulate == 'fp8':
+        return vit_block_bf16(x, w, p, heads, eps, mx=True)
     if emulate in ('bf16', 'bf16_nofold'):
         fold = emulate == 'bf16' and x.shape[-1] % 128 == 0
         return vit_block_bf16(x, w, p, heads, eps, fold1=fold and p != 'blocks.0.', fold2=fold)
@@ -155,26 +172,39 @@ def ln_linear_bf16(x, g, beta, W, b, eps, fold):
     return rstd * (r(x) @ Wp.t() - mean * c) + d
 
 
-def vit_block_bf16(x, w, p, heads, eps=1e-6, fold1=False, fold2=False):
-    """vit_block with the bf16 mode's rounding points (module docstring); x is the fp32 residual stream."""
+def vit_block_bf16(x, w, p, heads, eps=1e-6, fold1=False, fold2=False, mx=False):
+    """vit_block with the bf16 mode's rounding points (module docstring); x is the fp32 residual stream.
+    mx: the product's fp8 mode -- both operands of the four GEMMs quantised to MX-fp8 (mx_quant along k: LayerNorm outputs,
+    attention output and fc1+GELU output after their bf16 rounding, weights once), everything else as in bf16 mode, no fold."""
     r = bf16_round
     f, n, d = x.shape
     hd = d // heads
-    qkv = r(ln_linear_bf16(x, w[p + 'norm1.weight'], w[p + 'norm1.bias'], w[p + 'attn.qkv.weight'], w[p + 'attn.qkv.bias'],
-                           eps, fold1))
+
+    def lin(a, wn, bn):
+        if mx:
+            return mx_quant(a) @ mx_quant(w[p + wn]).t() + w[p + bn]
+        return a @ r(w[p + wn]).t() + w[p + bn]
+    if mx:
+        qkv = r(lin(layer_norm(x, w[p + 'norm1.weight'], w[p + 'norm1.bias'], eps), 'attn.qkv.weight', 'attn.qkv.bias'))
+    else:
+        qkv = r(ln_linear_bf16(x, w[p + 'norm1.weight'], w[p + 'norm1.bias'], w[p + 'attn.qkv.weight'],
+                               w[p + 'attn.qkv.bias'], eps, fold1))
     qkv = qkv.reshape(f, n, 3, heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
     s = (q @ k.transpose(-1, -2)) * hd ** -0.5
     pr = torch.exp(s - s.max(-1, keepdim=True)[0])
     a = r((r(pr) @ v) / pr.sum(-1, keepdim=True))          # P in bf16 for P.V, its row sum in fp32
     a = a.transpose(1, 2).reshape(f, n, d)
-    a = a @ r(w[p + 'attn.proj.weight']).t() + w[p + 'attn.proj.bias']
+    a = lin(a, 'attn.proj.weight', 'attn.proj.bias')
     if p + 'ls1.gamma' in w:
         a = a * w[p + 'ls1.gamma']
     x = x + a
-    h = r(gelu_erf(ln_linear_bf16(x, w[p + 'norm2.weight'], w[p + 'norm2.bias'], w[p + 'mlp.fc1.weight'],
-                                  w[p + 'mlp.fc1.bias'], eps, fold2)))
-    h = h @ r(w[p + 'mlp.fc2.weight']).t() + w[p + 'mlp.fc2.bias']
+    if mx:   # quantised straight from the fp32 GELU value in fc1's epilogue (lin() applies mx_quant): no bf16 rounding
+        h = gelu_erf(lin(layer_norm(x, w[p + 'norm2.weight'], w[p + 'norm2.bias'], eps), 'mlp.fc1.weight', 'mlp.fc1.bias'))
+    else:
+        h = r(gelu_erf(ln_linear_bf16(x, w[p + 'norm2.weight'], w[p + 'norm2.bias'], w[p + 'mlp.fc1.weight'],
+                                      w[p + 'mlp.fc1.bias'], eps, fold2)))
+    h = lin(h, 'mlp.fc2.weight', 'mlp.fc2.bias')
     if p + 'ls2.gamma' in w:
         h = h * w[p + 'ls2.gamma']
     return x + h
@@ -202,7 +232,7 @@ def vit_forward(img, w, heads, patch, taps=(3, 7, 11), eps=1e-6, first_block=0, 
     """
     depth = 1 + max(int(k.split('.')[1]) for k in w if k.startswith('blocks.'))
     last_block = depth if last_block is None else last_block
-    assert emulate in (None, 'bf16', 'bf16_nofold'), emulate
+    assert emulate in (None, 'bf16', 'bf16_nofold', 'fp8'), emulate
     x = vit_embed(img, w, patch, emulate) if x_in is None else x_in
     feats = {}
     for i in range(first_block, last_block):

@@ -161,6 +161,23 @@ def test_config4_dinov2_vitl14_336_backbone_vs_oracle():
     with torch.no_grad():
         feats, cls = OV.vit_forward(x, w, heads, patch, taps)
         feats16, cls16 = OV.vit_forward(x, w, heads, patch, taps, emulate='bf16')
+        feats8, cls8 = OV.vit_forward(x, w, heads, patch, taps, emulate='fp8')
+    # fp8: the dtype BASELINE.json names for this config (MX-fp8 GEMM operands: OCP e4m3 + E8M0 scale per 32 k, on
+    # v_mfma_scale_f32_16x16x128_f8f6f4).  Bounds: rel-L2 against the oracle that quantises the same operands, and -- the
+    # dtype's own error -- against the fp32 oracle (measured values in profiles/r02/parity.txt)
+    pk8 = ops.PackedViT(sd, depth, dim, heads, patch, img, taps, 'fp8')
+    got8, gcls8 = ops.vit_forward(x.to(DEV), pk8)
+    l8 = [rel_l2(got8[j].float(), feats8[:, 1:, j * dim:(j + 1) * dim].reshape(-1, dim)) for j in range(len(taps))]
+    l8_32 = [rel_l2(got8[j].float(), feats[:, 1:, j * dim:(j + 1) * dim].reshape(-1, dim)) for j in range(len(taps))]
+    record_parity('configs[4] DINOv2 ViT-L/14 @ 336 px HIP fp8 (MX-fp8): taps %s rel-L2 %s vs fp8-emulating oracle, %s vs fp32 oracle; '
+                  'cls rel-L2 %.3e / %.3e' % (taps, ' '.join('%.3e' % e for e in l8), ' '.join('%.3e' % e for e in l8_32),
+                                            rel_l2(gcls8, cls8), rel_l2(gcls8, cls)))
+    # 24 blocks deep the two fp8 computations no longer share their rounding decisions (an e4m3 step is 6 %: one value landing
+    # on the other side of a rounding boundary moves the block's output by more than the bf16 path's whole error), so the
+    # distance to the emulating oracle (measured 5.2e-2 .. 6.6e-2) is of the size of the dtype's own error against fp32
+    # (measured 7.1e-2 .. 8.6e-2); the per-GEMM and 2-block checks in test_gpu_kernels.py hold the kernels themselves tight
+    assert max(l8) <= 0.10 and max(l8_32) <= 0.15, (l8, l8_32)
+    del pk8, got8
     for dt, rf, rc, tol in (('fp32', feats, cls, 1e-3), ('bf16', feats16, cls16, 2e-2)):
         pk = ops.PackedViT(sd, depth, dim, heads, patch, img, taps, dt)
         got, gcls = ops.vit_forward(x.to(DEV), pk)

@@ -186,6 +186,118 @@ def test_gemm_ln_fold_consumer_epilogue(M, N, K, epi):
         assert torch.equal(C, C2), variant
 
 
+# ------------------------------------------------------------------------------------------------ MX-fp8 (configs[4])
+def _mx_decode(q, scales, rows, K):
+    """device MX-fp8 (e4m3 bytes [rows, K] + scales [K/128][rows] dwords, block b of a K tile in byte b) -> fp32 on the CPU"""
+    val = q.cpu().view(torch.float8_e4m3fn).float().view(rows, K // 32, 32)
+    sc = scales.cpu().view(torch.uint8).view(K // 128, rows, 4).permute(1, 0, 2).reshape(rows, K // 32).int()
+    return (val * torch.ldexp(torch.ones(rows, K // 32), sc - 127).unsqueeze(-1)).view(rows, K)
+
+
+def _mx_quant_dev(x, in_code):
+    rows, K = x.shape
+    q = torch.empty(rows, K, device=DEV, dtype=torch.uint8)
+    sc = torch.empty(K // 128, rows, device=DEV, dtype=torch.int32)
+    _lib.call('mvf_quant_mxfp8', in_code, x.data_ptr(), K, q.data_ptr(), K, sc.data_ptr(), rows, K, S())
+    return q, sc
+
+
+@pytest.mark.parametrize('rows,K', [(1000, 1024), (37, 256), (2500, 4096)])
+def test_mxfp8_quantisers_vs_oracle(rows, K):
+    """mvf_quant_mxfp8 (bf16 and f32 inputs) must reproduce oracle.vit.mx_quant EXACTLY (same scale rule, round to nearest
+    even); mvf_layernorm_mxfp8 = the same quantiser behind a LayerNorm (rounding-boundary flips only)."""
+    g = gen(71)
+    x = torch.randn(rows, K, generator=g) * torch.exp(2.0 * torch.randn(rows, 1, generator=g))
+    x[0, :32] = 0.0                                   # an all-zero block
+    x[1, 5] = 3.0e4                                   # an outlier
+    for code, tdt in ((_lib.F32, torch.float32), (_lib.BF16, torch.bfloat16)):
+        xd = x.to(DEV).to(tdt)
+        q, sc = _mx_quant_dev(xd, code)
+        got = _mx_decode(q, sc, rows, K)
+        ref = OV.mx_quant(xd.float().cpu())
+        assert torch.equal(got, ref), 'mismatch in %d of %d elements' % ((got != ref).sum().item(), got.numel())
+    gam, beta = 1.0 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    if K <= 2048:
+        xd, gd, bd = x.to(DEV), gam.to(DEV), beta.to(DEV)
+        q = torch.empty(rows, K, device=DEV, dtype=torch.uint8)
+        sc = torch.empty(K // 128, rows, device=DEV, dtype=torch.int32)
+        _lib.call('mvf_layernorm_mxfp8', xd.data_ptr(), K, gd.data_ptr(), bd.data_ptr(), q.data_ptr(), K, sc.data_ptr(), rows, K,
+                  1e-6, S())
+        got = _mx_decode(q, sc, rows, K)
+        ref = OV.mx_quant(OV.layer_norm(x, gam, beta, 1e-6))
+        frac = (got != ref).float().mean().item()
+        assert frac < 5e-3 and rel_l2(got, ref) < 3e-3, (frac, rel_l2(got, ref))
+
+
+@pytest.mark.parametrize('M,N,K,epi', [(1000, 2304, 768, 0), (197 * 40 + 5, 1024, 1024, 1), (577 * 8, 1024, 4096, 2),
+                                        (25216, 768, 3072, 2), (25216, 2304, 768, 0)])
+def test_gemm_fp8_vs_fp64_on_the_dequantised_operands(M, N, K, epi):
+    """mvf_gemm_fp8 (v_mfma_scale_f32_16x16x128_f8f6f4, MX block scales, operand and scale staging by LDS-DMA): fp8 x fp8
+    products are exact in fp32, so against A_deq W_deq^T in fp64 only the fp32 summation order and the output rounding remain:
+    2e-5 on the fp32 residual epilogue, one bf16 ulp on bf16 outputs.  Operands carry per-row magnitudes over two decades so
+    that a misplaced scale byte cannot hide.  The last two shapes have more tiles than workgroups (persistent walk)."""
+    g = gen(72)
+    A = torch.randn(M, K, generator=g) * torch.exp(1.5 * torch.randn(M, 1, generator=g))
+    W = torch.randn(N, K, generator=g) * 0.05 * torch.exp(1.0 * torch.randn(N, 1, generator=g))
+    A[:, 64:96] *= 30.0                                # one k block much larger than its neighbours
+    b = torch.randn(N, generator=g).to(DEV)
+    Aq, As = _mx_quant_dev(A.to(DEV), _lib.F32)
+    Wq, Ws = _mx_quant_dev(W.to(DEV), _lib.F32)
+    Ad, Wd = _mx_decode(Aq, As, M, K).double(), _mx_decode(Wq, Ws, N, K).double()
+    ref = Ad @ Wd.t() + b.double().cpu()
+    tpf = 197
+    for rep in range(2):
+        if epi == 2:
+            x0 = torch.randn(M, N, generator=gen(73)).to(DEV)
+            x = x0.clone()
+            ls = (1.0 + 0.1 * torch.randn(N, generator=gen(74))).to(DEV)
+            tap = torch.zeros((M // tpf) * (tpf - 1), N, device=DEV, dtype=torch.bfloat16) if M % tpf == 0 else None
+            _lib.call('mvf_gemm_fp8', 2, Aq.data_ptr(), K, As.data_ptr(), Wq.data_ptr(), K, Ws.data_ptr(), b.data_ptr(), None, 0,
+                      None, x.data_ptr(), N, _lib.ptr(tap), N, ls.data_ptr(), tpf, M, N, K, S())
+            want = x0.double().cpu() + ls.double().cpu() * ref
+            check(x, want, 2e-5, 'fp8 gemm residual epilogue')
+            if tap is not None:
+                assert torch.equal(tap, x.to(torch.bfloat16).view(M // tpf, tpf, N)[:, 1:].reshape(-1, N))
+        else:
+            C = torch.full((M, N), 7.0, device=DEV, dtype=torch.bfloat16)
+            _lib.call('mvf_gemm_fp8', epi, Aq.data_ptr(), K, As.data_ptr(), Wq.data_ptr(), K, Ws.data_ptr(), b.data_ptr(),
+                      C.data_ptr(), N, None, None, 0, None, 0, None, tpf, M, N, K, S())
+            check(C.float(), OV.gelu_erf(ref) if epi == 1 else ref, 4.5e-3, 'fp8 gemm epi %d' % epi)
+            if epi == 1 and N % 128 == 0:
+                # the same GEMM with the MX-fp8 quantisation of the GELU output in its epilogue (fc1 -> fc2 hand-off)
+                Cq = torch.zeros(M, N, device=DEV, dtype=torch.uint8)
+                Cs = torch.zeros(N // 128, M, device=DEV, dtype=torch.int32)
+                _lib.call('mvf_gemm_fp8', 1, Aq.data_ptr(), K, As.data_ptr(), Wq.data_ptr(), K, Ws.data_ptr(), b.data_ptr(),
+                          Cq.data_ptr(), N, Cs.data_ptr(), None, 0, None, 0, None, tpf, M, N, K, S())
+                got = _mx_decode(Cq, Cs, M, N)
+                want = OV.mx_quant(OV.gelu_erf(ref).float())
+                frac = (got != want).float().mean().item()     # fp32 summation order / A&S erf: rounding-boundary flips only
+                assert frac < 5e-3 and rel_l2(got, want) < 3e-3, (frac, rel_l2(got, want))
+
+
+def test_vit_forward_fp8_vs_emulating_oracle():
+    """The whole backbone in MX-fp8 mode (small ViT, dim 256) against the oracle that quantises the same operands
+    (oracle/vit.py emulate='fp8'), and -- reported -- against the fp32 oracle."""
+    from conftest import record_parity
+    dim, depth, heads, patch, img, F = 256, 4, 4, 16, 64, 6
+    w = OV.init_vit_weights(dim, depth, patch, img, seed=81, layerscale=True)
+    x = torch.randn(F, 3, img, img, generator=gen(82))
+    taps = (1, 3)
+    with torch.no_grad():
+        feats, cls = OV.vit_forward(x, w, heads, patch, taps)
+        feats8, cls8 = OV.vit_forward(x, w, heads, patch, taps, emulate='fp8')
+    got, gcls = ops.vit_forward(x.to(DEV), _pack(w, depth, dim, heads, patch, img, taps, 'fp8'))
+    for j in range(len(taps)):
+        r32 = feats[:, 1:, j * dim:(j + 1) * dim].reshape(-1, dim)
+        r8 = feats8[:, 1:, j * dim:(j + 1) * dim].reshape(-1, dim)
+        l8, l32 = rel_l2(got[j].float(), r8), rel_l2(got[j].float(), r32)
+        record_parity('fp8 ViT (dim 256, depth 4) tap %d: rel-L2 %.3e vs fp8-emulating oracle, %.3e vs fp32 oracle' % (taps[j], l8, l32))
+        assert l8 < 1e-2 and l32 < 6e-2, (l8, l32)
+    lc = rel_l2(gcls, cls8)
+    record_parity('fp8 ViT (dim 256, depth 4) final-norm CLS: rel-L2 %.3e vs fp8-emulating oracle' % lc)
+    assert lc < 8e-2, lc      # 6 rows, normalised: single e4m3 rounding flips (6 % of an element) dominate
+
+
 def test_gemm_operand_beyond_4gib_falls_back_to_the_128_kernel():
     """The 256x256 kernel addresses its operands with 32-bit offsets; an A matrix of 4 GiB or more silently takes the 128x128
     kernel (64-bit addressing), which is bit-identical -- checked against the same rows computed in two halves."""
@@ -376,6 +488,32 @@ def test_vit_forward_bf16_error():
         ec = relerr(gcls, cls16)
         record_parity('bf16 ViT-B/16 final-norm CLS (variant %d): max-rel err %.3e vs bf16-emulating oracle' % (variant, ec))
         assert ec < 1e-2, ec
+
+
+@pytest.mark.parametrize('F,N,H', [(3, 197, 2), (2, 257, 2), (1, 50, 1), (2, 577, 1), (1, 224, 1), (1, 225, 3)])
+def test_vit_attention_bf16_forward_backward(F, N, H):
+    """Attention core of a trainable ViT block in bf16 (ops.vit_attention_bf16: streamed flash forward keeping the
+    log-sum-exp + bf16 MFMA backward) against fp64 autograd on the SAME bf16-rounded q, k, v / dO: what is left is the bf16
+    rounding of P, dS and of the attention output (rel-L2 ~ 3e-3).  N = 197 / 50 / 224: one LDS block; 225 / 257 / 577: the
+    block loop; every element of dqkv must be written (NaN-filled result buffer would show)."""
+    D = H * 64
+    g = gen(91)
+    qkv = (torch.randn(F * N, 3 * D, generator=g) * 1.5).to(torch.bfloat16).float()
+    d_o = torch.randn(F * N, D, generator=g).to(torch.bfloat16).float()
+    x = qkv.clone().to(DEV).requires_grad_(True)
+    o = ops.vit_attention_bf16(x, F, N, H)
+    o.backward(d_o.to(DEV))
+    torch.cuda.synchronize()
+    ref_in = qkv.double().requires_grad_(True)
+    q, k, v = [t.reshape(F, N, H, 64).permute(0, 2, 1, 3) for t in ref_in.reshape(F * N, 3, D).unbind(1)]
+    p = torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1)
+    ref_o = (p @ v).permute(0, 2, 1, 3).reshape(F * N, D)
+    ref_o.backward(d_o.double())
+    assert torch.isfinite(x.grad).all()
+    e_o = rel_l2(o, ref_o)
+    parts = [rel_l2(x.grad[:, i * D:(i + 1) * D], ref_in.grad[:, i * D:(i + 1) * D]) for i in range(3)]
+    assert e_o < 5e-3, e_o
+    assert max(parts) < 1e-2, parts      # dq, dk, dv
 
 
 # ------------------------------------------------------------------------------------------------ head ops

@@ -419,4 +419,6 @@ def test_partial_freeze_bf16_mode_tracks_fp32_mode():
     worst = min((torch.nn.functional.cosine_similarity(g16[n].flatten(), g32[n].flatten(), dim=0).item(), n)
                 for n in g32 if g32[n].numel() > 64 and g32[n].norm() > 1e-6)
     print('bf16 vs fp32 partial freeze: loss %.5f vs %.5f; worst gradient cosine %.4f (%s)' % (l16, l32, worst[0], worst[1]))
-    assert worst[0] > 0.98, worst
+    # 0.95: with the trainable blocks' attention in bf16 too (forward and backward) the worst cosine measured is 0.963 (a
+    # LayerNorm bias with a small gradient); with fp32 attention it was 0.985
+    assert worst[0] > 0.95, worst

@@ -8,6 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 python3 $GRAFT_REPO_ROOT/bench.py > $out/bench.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $out/stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_serial -o run -- python3 $GRAFT_REPO_ROOT/bench.py --serial --no-cpu-baseline > $out/stats_serial.log 2>&1
+# PMC passes on their own (never together with a trace): the four GEMM shapes, plain and with the LN-fold extras (--ln)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $GRAFT_REPO_ROOT/tools/gemm_bench.py --iters 3 --warm 1 > $out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $GRAFT_REPO_ROOT/tools/gemm_bench.py --iters 3 --warm 1 > $out/pmc_write.log 2>&1
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $out/pmc_fetch $out/pmc_write 4 > $out/pmc_traffic.json

@@ -24,9 +24,14 @@ CASES = {
         network='TIMM-vit_base_patch16_224.dino', num_frames=32, batch_size=4, SMART_TOKENS=6, CAPACITY_SCALAR=6,
         EMBEDDING_SIZE=256, SMART_FEATS='9,10,11', SMART_FINAL='avg'),
     'cfg4 T=64, B=4 (S = 192)': dict(network='TIMM-vit_base_patch16_224.dino', num_frames=64, batch_size=4),
-    'cfg5 DINOv2 ViT-L/14 @336, T=32, B=2 (bf16; no fp8 path)': dict(
+    'cfg5 DINOv2 ViT-L/14 @336, T=32, B=2, bf16': dict(
         network='TIMM-vit_large_patch14_dinov2.lvd142m', num_frames=32, batch_size=2, image_size=336, SMART_FEATS='7,15,23',
         LAYER=24),
+    'cfg5 DINOv2 ViT-L/14 @336, T=32, B=2, fp8 (MX-fp8 GEMM operands)': dict(
+        network='TIMM-vit_large_patch14_dinov2.lvd142m', num_frames=32, batch_size=2, image_size=336, SMART_FEATS='7,15,23',
+        LAYER=24, DTYPE='fp8'),
+    'cfg2 ViT-B/16, T=32, B=4, fp8 (NOT the headline dtype of this config: configs[1] is quoted at bf16)': dict(
+        network='TIMM-vit_base_patch16_224.dino', num_frames=32, batch_size=4, DTYPE='fp8'),
 }
 
 
@@ -38,7 +43,7 @@ def main():
             continue
         kw = dict(kw)
         layer = kw.pop('LAYER', None)
-        cfg = presets.make_cfg(compute_dtype='bf16', **kw)
+        cfg = presets.make_cfg(compute_dtype=kw.pop('DTYPE', 'bf16'), **kw)
         if layer is not None:
             cfg.MODEL.BASE_MODEL.LAYER = layer        # frozen backbone: LAYER >= block count
         torch.manual_seed(1)

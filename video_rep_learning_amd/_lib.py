@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MVF_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libmvf_hip.so')
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_PATCH = 0, 1, 2, 3
 
 _P, _I, _L, _Z, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t, ctypes.c_float
@@ -25,6 +25,10 @@ SIGNATURES = {
     'mvf_gemm_tc_batched': 'ipipipipiiiiiip',
     'mvf_gemm_tc_ln': 'iipipippipipipipipppiiip',
     'mvf_ln_stats_finalize': 'pipiifp',
+    'mvf_gemm_tc_f32': 'pipippipiiip',
+    'mvf_quant_mxfp8': 'ipzpzpiip',
+    'mvf_layernorm_mxfp8': 'pzpppzpiifp',
+    'mvf_gemm_fp8': 'ipippipppippipipiiiip',
     'mvf_gemm_tc_select': 'i',
     'mvf_gemm_tc_debug_stamps': 'p',
     'mvf_gemm_tc_set_cus': 'i',
@@ -33,6 +37,9 @@ SIGNATURES = {
     'mvf_layernorm_fwd': 'ipzpppziifp',
     'mvf_vit_attn_fwd': 'ippiiiiip',
     'mvf_cast_f32_bf16': 'ppzp',
+    'mvf_cast_bf16_f32': 'ppzp',
+    'mvf_vit_attn_fwd_lse': 'pppiiiip',
+    'mvf_vit_attn_bwd': 'ppppppiiiip',
     'mvf_hgemm': 'pllpllplppllii' + 'iiifiip',
     'mvf_hgemm_ex': 'pllpllplppllii' + 'iiifii' + 'plfuup',
     'mvf_hlinear_bwd': 'plplplplplpiiiip',
@@ -84,7 +91,7 @@ class MvfVitWeights(ctypes.Structure):
                  ('cls_token', _P), ('pos_embed', _P), ('patch_w', _P), ('patch_b', _P), ('norm_w', _P), ('norm_b', _P)]
                 + [(n, ctypes.POINTER(_P)) for n in
                    ('ln1_w', 'ln1_b', 'qkv_w', 'qkv_b', 'proj_w', 'proj_b', 'ln2_w', 'ln2_b', 'fc1_w', 'fc1_b',
-                    'fc2_w', 'fc2_b', 'ls1', 'ls2', 'qkv_c', 'fc1_c')])
+                    'fc2_w', 'fc2_b', 'ls1', 'ls2', 'qkv_c', 'fc1_c', 'qkv_s', 'proj_s', 'fc1_s', 'fc2_s')])
 
 
 class MvfAugmentParams(ctypes.Structure):

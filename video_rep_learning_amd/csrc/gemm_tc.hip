@@ -239,7 +239,12 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
   a.batch_rows = batch_rows; a.w_batch_rows = w_batch_rows;
   a.row0 = 0;
   a.xb = nullptr; a.ldxb = 0; a.stats = nullptr; a.ln_mr = nullptr; a.ln_c = nullptr;
-  a.sa = nullptr; a.sw = nullptr;
+  a.sa = nullptr; a.sw = nullptr; a.csc = nullptr;
+  a.radd = resid;
+  if (ln != nullptr && ln->addend_mode != 0) {
+    MVF_CHECK_ARG(epi == EPI_RESID && (ln->addend_mode == 2 || (ln->addend_mode == 1 && ln->addend && ((uintptr_t)ln->addend % 16) == 0)));
+    a.radd = ln->addend_mode == 1 ? ln->addend : nullptr;
+  }
   const bool fold = ln != nullptr && (ln->xb || ln->stats || ln->ln_mr || ln->ln_c);
   if (fold) {   // LN fold: epilogue extras of the 256x256 bf16 kernel
     if (ln->xb || ln->stats) MVF_CHECK_ARG(epi == EPI_RESID);
@@ -286,6 +291,29 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
   }
   if (g_variant >= 2) return MVF_ERR_UNSUPPORTED;
   return dtype == MVF_BF16 ? dispatch<bf16_t>(epi, a, st) : dispatch<float>(epi, a, st);
+}
+
+// MX-fp8 operands: the 256x256 kernel's FP8 variants only (no 128x128 fallback: sizes beyond its 32-bit offsets are refused)
+int mvf_gemm_fp8_impl(int epi, const void* A, int lda, const unsigned* sa, const void* W, int ldw, const unsigned* sw,
+                      const float* bias, void* C, int ldc, unsigned* c_scales, float* resid, int ldr, void* tap, int ldt,
+                      const float* ls, int tpf, int M, int N, int K, hipStream_t st) {
+  MVF_CHECK_ARG(A && W && sa && sw && M > 0 && N > 0 && K > 0 && K % 256 == 0 && N % 32 == 0);
+  if (c_scales != nullptr) {   // epi 1 with an MX-fp8 result: C = e4m3 bytes, c_scales [N/128][M]
+    MVF_CHECK_ARG(epi == EPI_GELU && C && N % 128 == 0 && ldc % 8 == 0 && ((uintptr_t)C % 8) == 0 && ((uintptr_t)c_scales % 4) == 0);
+    epi = EPI_GELU_Q;
+  }
+  MVF_CHECK_ARG(lda % 16 == 0 && ldw % 16 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0);
+  MVF_CHECK_ARG(((uintptr_t)sa % 4) == 0 && ((uintptr_t)sw % 4) == 0 && (bias == nullptr || ((uintptr_t)bias % 16) == 0));
+  if (epi == EPI_STORE || epi == EPI_GELU) MVF_CHECK_ARG(C && ldc % 4 == 0 && ((uintptr_t)C % 16) == 0);
+  else if (epi == EPI_RESID) MVF_CHECK_ARG(resid && ldr % 4 == 0 && (tap == nullptr || (ldt % 4 == 0 && tpf > 1)));
+  else if (epi != EPI_GELU_Q) return MVF_ERR_ARG;
+  GemmTcArgs a;
+  a.A = (const char*)A; a.W = (const char*)W; a.bias = bias; a.C = (char*)C; a.resid = resid; a.tap = (char*)tap;
+  a.pos = nullptr; a.ls = ls; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.ldt = ldt; a.M = M; a.N = N; a.K = K; a.tpf = tpf;
+  a.dbg = nullptr; a.sched = nullptr; a.batch_rows = 0; a.w_batch_rows = 0; a.row0 = 0;
+  a.xb = nullptr; a.ldxb = 0; a.stats = nullptr; a.ln_mr = nullptr; a.ln_c = nullptr;
+  a.sa = sa; a.sw = sw; a.csc = c_scales; a.radd = resid;
+  return mvf_gemm_tc256_launch(epi, a, /*persistent=*/true, st);
 }
 
 // 0 = automatic choice, 1 = always the 128x128 kernel, 2 = only the 256x256 kernel (error where it does not apply),

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
 
   // ---- fragment read offsets: lane (frow, fgrp) reads row frow of a 16-row tile, 16-B chunk (ks*4 + fgrp) ^ (frow&7)
   const int frow = lane & 15, fgrp = lane >> 4;
-  const int choff = ((FP8 ? 2 * fgrp : fgrp) ^ (frow & 7)) << 4;   // k-step 0; k-step 1 is choff ^ 64 (fp8: second chunk, ^ 16)
+  const int choff = (fgrp ^ (frow & 7)) << 4;                   // k-step 0; k-step 1 is choff ^ 64
   const int a_rd = (wr * 64 + frow) * ROWB + choff;
   const int b_rd = (wc * 32 + frow) * ROWB + choff;
 
@@ -272,8 +272,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   // fp8: a fragment is ONE 32-byte operand (8 consecutive registers), filled by two 16-byte LDS reads into its halves
   i32x8_t afq[4], bq0[2], bq1[2];
   unsigned sfa[4], sf0[2], sf1[2];   // fp8: the E8M0 scale of each fragment's 32-k block, in byte 0
-  // fp8: a lane's fragment is 32 consecutive k = the two 16-byte chunks 2 fgrp, 2 fgrp + 1 (bf16: chunks fgrp and 4 + fgrp)
-  constexpr int KS1 = FP8 ? 16 : 64;
+  // fp8: lane (row, g) of v_mfma_scale_f32_16x16x128_f8f6f4 holds k = 16 g .. 16 g + 15 and 64 + 16 g .. 64 + 16 g + 15 in the
+  // two halves of its 32-byte operand -- the SAME two 16-byte chunks (g, 4 + g) of the 128-byte row as the bf16 kernel's two
+  // k-steps -- while the scale it supplies is that of MX block g (k = 32 g .. 32 g + 31).  Measured (tools/fp8_debug*.py):
+  // with 32 consecutive bytes per lane every product is still right (both operands permute k alike) but each block scale
+  // lands on another block's data.
+  constexpr int KS1 = 64;
   // fp8: one LDS address each for this lane's A-row / W-row scale dwords (K-tile buffer, quadrant and tile are immediates)
   const char* const sa_rd = smem + SC_OFF + (wr * 128 + frow) * 4;
   const char* const sb_rd = smem + SC_OFF + 1024 + (wc * 64 + frow) * 4;
@@ -488,7 +492,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
       for (int ii = 0; ii < EB; ++ii) {
         const int i = ih * EB + ii;
         const int m = m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + frow;
-        if constexpr (!kLnProducer) {
+        if constexpr (EPI == EPI_GELU_Q) {
+          // the wave's 64 columns of row m = two MX blocks: quantise each, then one 2-byte store of both scales into the
+          // row's dword of K tile (n0 + 64 wc) / 128 of the NEXT GEMM (bytes 2 (wc & 1), 2 (wc & 1) + 1)
+          const int nb = n0 + wc * 64;
+          const bool ok = m < a.M && nb < a.N;
+          const unsigned s0 = epilogue_pair_gelu_q(a, m, ok, nb, fgrp, acc[i][0], acc[i][1], bj[0], bj[1]);
+          const unsigned s1 = epilogue_pair_gelu_q(a, m, ok, nb + 32, fgrp, acc[i][2], acc[i][3], bj[2], bj[3]);
+          if (ok && fgrp == 0)
+            *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(a.csc + (size_t)(nb >> 7) * a.M + m) + (wc & 1) * 2) =
+                (unsigned short)(s0 | (s1 << 8));
+        } else if constexpr (!kLnProducer) {
 #pragma unroll
           for (int jp = 0; jp < 2; ++jp) {
             const int nb = n0 + wc * 64 + jp * 32;
@@ -641,6 +655,7 @@ int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, bool persistent
     switch (epi) {
       case EPI_STORE: return launch<EPI_STORE, false, false, true>(a, persistent, st);
       case EPI_GELU: return launch<EPI_GELU, false, false, true>(a, persistent, st);
+      case EPI_GELU_Q: return a.csc != nullptr && a.N % 128 == 0 ? launch<EPI_GELU_Q, false, false, true>(a, persistent, st) : MVF_ERR_ARG;
       case EPI_RESID: return launch<EPI_RESID, false, false, true>(a, persistent, st);
     }
     return MVF_ERR_ARG;

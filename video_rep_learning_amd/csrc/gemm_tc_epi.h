@@ -2,10 +2,12 @@
 // 8-phase bf16): the argument block and the fused epilogues (bias / GELU / residual+LayerScale+tap / patch+pos).
 #pragma once
 #include "common.h"
+#include "mxfp8.h"
 
 namespace gemm_tc {
 
-enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
+// EPI_GELU_Q (gemm_tc256 FP8 variants only): GELU, then MX-fp8 quantisation of the output (the next GEMM's A operand)
+enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_GELU_Q = 4 };
 
 struct GemmTcArgs {
   const char* A;
@@ -42,7 +44,23 @@ struct GemmTcArgs {
   // (block b of the K tile in byte b).  NULL = bf16 operands.
   const unsigned* sa;
   const unsigned* sw;
+  // EPI_RESID: where the residual ADDEND is read: `resid` itself (in place, the frozen backbone), another [M, ldr] fp32 matrix
+  // (out of place: trainable blocks, whose LayerNorm saved the old residual for its backward) or NULL (no addend: a plain fp32
+  // result -- forward of qkv / fc1, input gradients, split-K partials -- without a zero-fill + read-modify-write)
+  const float* radd;
+  // EPI_GELU_Q: C holds e4m3 bytes [M, ldc] and csc [N/128][M] the output's block scales (same layout as sa)
+  unsigned* csc;
 };
+
+// max over the four lanes that hold one output row (lane, lane^16, lane^32, lane^48), result in all of them
+__device__ __forceinline__ float row_quad_max(float v) {
+  const uint32_t u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float w = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const uint32_t x = __float_as_uint(w);
+  const auto b = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
 
 // sum over the four lanes that hold one output row (lane, lane^16, lane^32, lane^48), result in all of them; fixed order
 __device__ __forceinline__ float row_quad_sum(float v) {
@@ -117,8 +135,10 @@ __device__ __forceinline__ void epilogue4(const GemmTcArgs& a, int m, int n, con
       const float4 gm = *reinterpret_cast<const float4*>(a.ls + n);
       v[0] *= gm.x; v[1] *= gm.y; v[2] *= gm.z; v[3] *= gm.w;
     }
-    const float4 o = *reinterpret_cast<const float4*>(rp);
-    v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+    if (a.radd != nullptr) {
+      const float4 o = *reinterpret_cast<const float4*>(a.radd + out_row * a.ldr + n);
+      v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+    }
     *reinterpret_cast<float4*>(rp) = make_float4(v[0], v[1], v[2], v[3]);
     if (a.tap != nullptr) {  // tapped block output, CLS row dropped
       const int f = m / a.tpf, t = m - f * a.tpf;
@@ -165,9 +185,10 @@ template <int EPI>
 __device__ __forceinline__ void epilogue_prefetch(const GemmTcArgs& a, int m, bool ok, int nw, int fgrp,
                                                   float4 (&add)[4]) {
   const float* src = nullptr;
+  if constexpr (EPI == EPI_RESID) ok = ok && a.radd != nullptr;
   if (ok) {
     if constexpr (EPI == EPI_RESID) {
-      src = a.resid + (size_t)m * a.ldr;
+      src = a.radd + (size_t)m * a.ldr;
     } else {
       const int np = a.tpf - 1;
       src = a.pos + (size_t)(1 + (m - (m / np) * np)) * a.N;
@@ -292,6 +313,32 @@ __device__ __forceinline__ void epilogue_pair_bf16_ln(const GemmTcArgs& a, int m
       *reinterpret_cast<float4*>(rp + n1) = make_float4(v1[0] + add1.x, v1[1] + add1.y, v1[2] + add1.z, v1[3] + add1.w);
     }
   }
+}
+
+// EPI_GELU_Q: gelu(acc + bias) of two adjacent tiles = one 32-column MX block of row m (8 values in each of the row's four
+// lanes) -> block amax across the four lanes, e4m3 bytes with the block's power-of-two scale (mxfp8.h), one 8-byte store per
+// lane after the same lane exchange as the bf16 stores (fgrp 0 / 2: tile 0 columns 0-7 / 8-15, fgrp 1 / 3: tile 1).
+// Returns the block's E8M0 byte (the caller stores a wave's two bytes per row at once).  Every lane runs the cross-lane steps.
+__device__ __forceinline__ unsigned epilogue_pair_gelu_q(const GemmTcArgs& a, int m, bool ok, int nb, int fgrp,
+                                                         const f32x4_t& acc0, const f32x4_t& acc1, const float4& b0,
+                                                         const float4& b1) {
+  float v0[4] = {acc0[0] + b0.x, acc0[1] + b0.y, acc0[2] + b0.z, acc0[3] + b0.w};
+  float v1[4] = {acc1[0] + b1.x, acc1[1] + b1.y, acc1[2] + b1.z, acc1[3] + b1.w};
+  float amax = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    v0[r] = gelu_erf_fast(v0[r]);
+    v1[r] = gelu_erf_fast(v1[r]);
+    amax = fmaxf(amax, fmaxf(fabsf(v0[r]), fabsf(v1[r])));
+  }
+  amax = row_quad_max(amax);
+  const unsigned sb = mx_scale_byte(amax);
+  const float inv = mx_inv_scale(sb);
+  const uint32_t x = pack_fp8x4(v0[0] * inv, v0[1] * inv, v0[2] * inv, v0[3] * inv);
+  const uint32_t y = pack_fp8x4(v1[0] * inv, v1[1] * inv, v1[2] * inv, v1[3] * inv);
+  const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+  if (ok) *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + nb + (fgrp & 1) * 16 + (fgrp >> 1) * 8) = make_uint2(r[0], r[1]);
+  return sb;
 }
 
 }  // namespace gemm_tc

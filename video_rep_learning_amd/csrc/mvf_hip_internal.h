@@ -14,10 +14,21 @@ struct MvfGemmLn {
   float* stats;
   const float* ln_mr;
   const float* ln_c;
+  // epi 2: 0 = the addend is `resid` itself (in place), 1 = read it from `addend` [M, ldr], 2 = no addend
+  int addend_mode;
+  const float* addend;
 };
 int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C,
                      int ldc, float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tpf, int M,
                      int N, int K, hipStream_t st, int batch_rows = 0, int w_batch_rows = 0, const MvfGemmLn* ln = nullptr);
+// MX-fp8 path (mxfp8.hip, gemm_tc.hip)
+int mvf_quant_mxfp8_impl(int in_dtype, const void* x, size_t ldx, void* q, size_t ldq, unsigned* scales, int rows, int K,
+                         hipStream_t st);
+int mvf_layernorm_mxfp8_impl(const float* x, size_t in_stride, const float* g, const float* b, void* q, size_t ldq,
+                             unsigned* scales, int rows, int D, float eps, hipStream_t st);
+int mvf_gemm_fp8_impl(int epi, const void* A, int lda, const unsigned* sa, const void* W, int ldw, const unsigned* sw,
+                      const float* bias, void* C, int ldc, unsigned* c_scales, float* resid, int ldr, void* tap, int ldt,
+                      const float* ls, int tpf, int M, int N, int K, hipStream_t st);
 int mvf_ln_stats_finalize_impl(const float* part, int ns, float* mr, int rows, int D, float eps, hipStream_t st);
 int mvf_im2col_impl(int dtype, const float* img, void* out, int F, int H, int W, int P, int ldk, hipStream_t st);
 // K of the patch-embed GEMM: 3*P*P rounded up to 128 elements (the granule of both GEMM kernels and dtypes)

@@ -30,6 +30,8 @@ struct AttnArgs {
   int rounds;       // q-tiles each wave walks through
   int nblk;         // key blocks
   float scale_log2; // hd^-0.5 * log2(e)
+  float* lse;       // streamed (flash) kernel only: [F, H, npad] log2-domain log-sum-exp of the scaled scores per query, for
+  int npad;         // the backward of trainable blocks (vit_attn_bwd.hip); NULL on the frozen path
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -542,6 +544,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void vit_attn_bf16_flash_kernel(AttnA
     const int q = (qt0 + i) * 16 + li;
     if (q < a.N) {
       const float inv = 1.0f / l_run[i];
+      if (a.lse != nullptr && g == 0)   // p = exp2(s * scale_log2 - lse) reproduces the normalised probability
+        a.lse[((size_t)f * a.H + h) * a.npad + q] = fmaf(m_run[i], a.scale_log2, __builtin_amdgcn_logf(l_run[i]));
       bf16_t* orow = obase + (size_t)q * a.D;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
@@ -674,10 +678,28 @@ __global__ __launch_bounds__(256, 1) void vit_attn_f32_kernel(AttnArgs a) {
 // variant: 0 = default (transposing LDS read for V; two query tiles per wave when N = 193..208), 1 = 2-byte gather reads
 // (cross-check path), 2 = one query tile per wave / synchronously staged 224-key blocks (the earlier kernels, kept for A/B
 // runs), 3 = the two-tile kernel at 2 waves per SIMD, 4 = the streamed kernel with 64-key blocks, 5 = the streamed kernel for any N
+// Forward of a TRAINABLE block in bf16 mode: the streamed kernel (any N) with the per-query log-sum-exp kept for
+// mvf_vit_attn_bwd; lse is [F, H, 16 * ceil(N / 16)] floats (rows beyond N are never written)
+extern "C" int mvf_vit_attn_fwd_lse(const void* qkv, void* out, float* lse, int F, int N, int H, int D, hipStream_t st) {
+  MVF_CHECK_ARG(qkv && out && lse && F > 0 && N > 0 && H > 0 && D == H * HD);
+  MVF_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0);
+  AttnArgs a;
+  a.qkv = (const char*)qkv; a.out = (char*)out; a.N = N; a.H = H; a.D = D;
+  a.nblk = 0; a.rounds = 0;
+  a.scale_log2 = LOG2E / 8.0f;
+  a.lse = lse;
+  const int ntile = ceil_div(N, 16);
+  a.npad = ntile * 16;
+  hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<6, 3>), dim3(F * H, ceil_div(ntile, 8)), dim3(256), 0, st, a);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
 int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t st) {
   MVF_CHECK_ARG(qkv && out && F > 0 && N > 0 && H > 0 && D == H * HD);
   MVF_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0);
   AttnArgs a;
+  a.lse = nullptr; a.npad = 0;
   a.qkv = (const char*)qkv; a.out = (char*)out; a.N = N; a.H = H; a.D = D;
   a.nblk = ceil_div(N, KB);
   const int qtiles = ceil_div(N, 16);

@@ -20,6 +20,11 @@ struct Ws {
   char* xb;     // [Mc, D] bf16
   float* stats; // [D/64, Mc, 2]
   float* mr;    // [Mc, 2]
+  // MX-fp8 mode: the A operands of the four GEMMs (LayerNorm output / attention output share hq; fc1+GELU output -> hidq)
+  char* hq;         // [Mc, D] e4m3
+  unsigned* hs;     // [D/128][Mc] block scales
+  char* hidq;       // [Mc, 4D] e4m3
+  unsigned* hids;   // [4D/128][Mc]
 };
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -33,9 +38,15 @@ struct Prof {
   size_t used = 0;
 } g_prof;
 
+struct Fp8Scales {   // non-null: MX-fp8 operands (mvf_gemm_fp8_impl)
+  const unsigned* sa;
+  const unsigned* sw;
+  unsigned* csc;       // epi 1: quantise the output too (C = e4m3 bytes, csc its block scales), or NULL
+};
+
 int timed_gemm(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
                float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tpf, int M, int N, int K,
-               hipStream_t st, const MvfGemmLn* ln = nullptr) {
+               hipStream_t st, const MvfGemmLn* ln = nullptr, const Fp8Scales* f8 = nullptr) {
   const bool rec = g_prof.on && g_prof.used < 4096;
   size_t slot = 0;
   if (rec) {
@@ -56,14 +67,16 @@ int timed_gemm(int dtype, int epi, const void* A, int lda, const void* W, int ld
     g_prof.flops[slot] = 2.0 * M * (double)N * K;
     (void)hipEventRecord(g_prof.ev[2 * slot], st);
   }
-  const int rc = mvf_gemm_tc_impl(dtype, epi, A, lda, W, ldw, bias, C, ldc, resid, ldr, tap, ldt, pos, ls, tpf, M, N, K, st, 0,
-                                  0, ln);
+  const int rc = f8 != nullptr
+                     ? mvf_gemm_fp8_impl(epi, A, lda, f8->sa, W, ldw, f8->sw, bias, C, ldc, f8->csc, resid, ldr, tap, ldt, ls, tpf, M, N, K, st)
+                     : mvf_gemm_tc_impl(dtype, epi, A, lda, W, ldw, bias, C, ldc, resid, ldr, tap, ldt, pos, ls, tpf, M, N, K, st, 0,
+                                        0, ln);
   if (rec) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
   return rc;
 }
 
 size_t carve(int dtype, int fc, int N, int D, int P, Ws* w, char* base) {
-  const size_t esz = dtype == MVF_BF16 ? 2 : 4;
+  const size_t esz = dtype == MVF_F32 ? 4 : 2;     // MX-fp8 mode keeps bf16 activations between its quantisers
   const size_t Mc = (size_t)fc * N;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -84,7 +97,17 @@ size_t carve(int dtype, int fc, int N, int D, int P, Ws* w, char* base) {
     stats = take(Mc * (size_t)(D / 64) * 2 * 4);
     mr = take(Mc * 2 * 4);
   }
-  if (w) { w->x = (float*)x; w->h = h; w->qkv = qkv; w->hid = hid; w->xb = xb; w->stats = (float*)stats; w->mr = (float*)mr; }
+  char *hq = nullptr, *hs = nullptr, *hidq = nullptr, *hids = nullptr;
+  if (dtype == MVF_FP8) {
+    hq = take(Mc * D);
+    hs = take((size_t)(D / 128) * Mc * 4);
+    hidq = take(Mc * 4 * D);
+    hids = take((size_t)(4 * D / 128) * Mc * 4);
+  }
+  if (w) {
+    w->x = (float*)x; w->h = h; w->qkv = qkv; w->hid = hid; w->xb = xb; w->stats = (float*)stats; w->mr = (float*)mr;
+    w->hq = hq; w->hs = (unsigned*)hs; w->hidq = hidq; w->hids = (unsigned*)hids;
+  }
   return off;
 }
 }  // namespace
@@ -106,14 +129,19 @@ extern "C" int mvf_vit_fwd_x(const MvfVitWeights* w, int dtype, const float* fra
                              float* cls_out, float* x_out, void* workspace, size_t ws_bytes, int frames_per_chunk,
                              int attn_variant, hipStream_t st) {
   MVF_CHECK_ARG(w && frames && workspace && F > 0);
-  MVF_CHECK_ARG(dtype == MVF_F32 || dtype == MVF_BF16);
+  MVF_CHECK_ARG(dtype == MVF_F32 || dtype == MVF_BF16 || dtype == MVF_FP8);
+  const bool fp8 = dtype == MVF_FP8;
+  if (fp8) {   // MX-fp8 GEMM operands, bf16 everywhere else (patch embedding, attention, taps); no LN fold
+    MVF_CHECK_ARG(w->dim % 256 == 0 && w->qkv_s && w->proj_s && w->fc1_s && w->fc2_s && !w->qkv_c && !w->fc1_c);
+    dtype = MVF_BF16;
+  }
   const int D = w->dim, H = w->heads, P = w->patch, img = w->img;
   MVF_CHECK_ARG(D == H * 64 && img % P == 0 && (w->depth > 0 || (x_out && w->depth == 0)) && w->n_taps >= 0 && w->n_taps <= 8);
   const int np = (img / P) * (img / P);
   const int N = np + 1;
   const int fc_max = frames_per_chunk > 0 ? std::min(frames_per_chunk, F) : F;
   Ws ws;
-  MVF_CHECK_ARG(carve(dtype, fc_max, N, D, P, &ws, (char*)workspace) <= ws_bytes);
+  MVF_CHECK_ARG(carve(fp8 ? MVF_FP8 : dtype, fc_max, N, D, P, &ws, (char*)workspace) <= ws_bytes);
   const size_t esz = dtype == MVF_BF16 ? 2 : 4;
   const int kp = mvf_patch_k(P);   // patch_w is [dim, kp] (zero-padded beyond 3*P*P)
   int rc;
@@ -135,17 +163,39 @@ extern "C" int mvf_vit_fwd_x(const MvfVitWeights* w, int dtype, const float* fra
     // holds b + W beta, and the GEMM consumes xb = bf16(x) with the row statistics applied in its epilogue -- no LayerNorm
     // kernel.  xb and the statistics' partial sums come out of the PREVIOUS residual epilogue (proj for LN2, the previous
     // layer's fc2 for LN1); layer 0's LN1 follows the patch embedding and keeps the LayerNorm kernel.
-    const bool can_fold = dtype == MVF_BF16 && ws.xb != nullptr && D % 128 == 0;
+    const bool can_fold = !fp8 && dtype == MVF_BF16 && ws.xb != nullptr && D % 128 == 0;
     auto folded = [&](const float* const* tab, int l) { return can_fold && tab != nullptr && l < w->depth && tab[l] != nullptr; };
     const int ns = D / 64;
     for (int l = 0; l < w->depth; ++l) {
       int tap = -1;
       for (int j = 0; j < w->n_taps; ++j)
         if (w->taps[j] == l) tap = j;
+      if (fp8) {
+        // MX-fp8 block: every GEMM operand is quantised by its producer (LayerNorm and the fc1+GELU epilogue write fp8
+        // directly; the attention output is bf16 and goes through mvf_quant_mxfp8)
+        void* tap_ptr = nullptr;
+        if (tap >= 0 && taps_out && taps_out[tap]) tap_ptr = (char*)taps_out[tap] + (size_t)f0 * np * D * 2;
+        const Fp8Scales sq = {ws.hs, w->qkv_s[l], nullptr}, sp = {ws.hs, w->proj_s[l], nullptr},
+                        s1 = {ws.hs, w->fc1_s[l], ws.hids}, s2 = {ws.hids, w->fc2_s[l], nullptr};
+        RUN(mvf_layernorm_mxfp8_impl(ws.x, D, w->ln1_w[l], w->ln1_b[l], ws.hq, D, ws.hs, Mc, D, w->ln_eps, st));
+        RUN(timed_gemm(dtype, EPI_STORE, ws.hq, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0, nullptr,
+                       nullptr, N, Mc, 3 * D, D, st, nullptr, &sq));
+        RUN(mvf_vit_attn_impl(dtype, ws.qkv, ws.h, fc, N, H, D, attn_variant, st));
+        RUN(mvf_quant_mxfp8_impl(MVF_BF16, ws.h, D, ws.hq, D, ws.hs, Mc, D, st));
+        RUN(timed_gemm(dtype, EPI_RESID, ws.hq, D, w->proj_w[l], D, w->proj_b[l], nullptr, 0, ws.x, D, nullptr, 0, nullptr,
+                       w->ls1 ? w->ls1[l] : nullptr, N, Mc, D, D, st, nullptr, &sp));
+        RUN(mvf_layernorm_mxfp8_impl(ws.x, D, w->ln2_w[l], w->ln2_b[l], ws.hq, D, ws.hs, Mc, D, w->ln_eps, st));
+        // fc1 + GELU with the MX-fp8 quantisation in its epilogue: hidq / hids straight out of the GEMM (no bf16 hid)
+        RUN(timed_gemm(dtype, EPI_GELU, ws.hq, D, w->fc1_w[l], D, w->fc1_b[l], ws.hidq, 4 * D, nullptr, 0, nullptr, 0, nullptr,
+                       nullptr, N, Mc, 4 * D, D, st, nullptr, &s1));
+        RUN(timed_gemm(dtype, EPI_RESID, ws.hidq, 4 * D, w->fc2_w[l], 4 * D, w->fc2_b[l], nullptr, 0, ws.x, D, tap_ptr, D,
+                       nullptr, w->ls2 ? w->ls2[l] : nullptr, N, Mc, D, 4 * D, st, nullptr, &s2));
+        continue;
+      }
       if (folded(w->qkv_c, l)) {
         if (l == 0) return MVF_ERR_ARG;   // nothing produces layer 0's statistics
         RUN(mvf_ln_stats_finalize_impl(ws.stats, ns, ws.mr, Mc, D, w->ln_eps, st));
-        const MvfGemmLn ln = {nullptr, 0, nullptr, ws.mr, w->qkv_c[l]};
+        const MvfGemmLn ln = {nullptr, 0, nullptr, ws.mr, w->qkv_c[l], 0, nullptr};
         RUN(timed_gemm(dtype, EPI_STORE, ws.xb, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0,
                        nullptr, nullptr, N, Mc, 3 * D, D, st, &ln));
       } else {
@@ -156,13 +206,13 @@ extern "C" int mvf_vit_fwd_x(const MvfVitWeights* w, int dtype, const float* fra
       RUN(mvf_vit_attn_impl(dtype, ws.qkv, ws.h, fc, N, H, D, attn_variant, st));
       const bool fold2 = folded(w->fc1_c, l);
       {
-        const MvfGemmLn ln = {fold2 ? ws.xb : nullptr, D, fold2 ? ws.stats : nullptr, nullptr, nullptr};
+        const MvfGemmLn ln = {fold2 ? ws.xb : nullptr, D, fold2 ? ws.stats : nullptr, nullptr, nullptr, 0, nullptr};
         RUN(timed_gemm(dtype, EPI_RESID, ws.h, D, w->proj_w[l], D, w->proj_b[l], nullptr, 0, ws.x, D, nullptr, 0,
                        nullptr, w->ls1 ? w->ls1[l] : nullptr, N, Mc, D, D, st, fold2 ? &ln : nullptr));
       }
       if (fold2) {
         RUN(mvf_ln_stats_finalize_impl(ws.stats, ns, ws.mr, Mc, D, w->ln_eps, st));
-        const MvfGemmLn ln = {nullptr, 0, nullptr, ws.mr, w->fc1_c[l]};
+        const MvfGemmLn ln = {nullptr, 0, nullptr, ws.mr, w->fc1_c[l], 0, nullptr};
         RUN(timed_gemm(dtype, EPI_GELU, ws.xb, D, w->fc1_w[l], D, w->fc1_b[l], ws.hid, 4 * D, nullptr, 0, nullptr, 0,
                        nullptr, nullptr, N, Mc, 4 * D, D, st, &ln));
       } else {
@@ -174,7 +224,7 @@ extern "C" int mvf_vit_fwd_x(const MvfVitWeights* w, int dtype, const float* fra
       if (tap >= 0 && taps_out && taps_out[tap]) tap_ptr = (char*)taps_out[tap] + (size_t)f0 * np * D * esz;
       const bool fold_next = folded(w->qkv_c, l + 1);
       {
-        const MvfGemmLn ln = {fold_next ? ws.xb : nullptr, D, fold_next ? ws.stats : nullptr, nullptr, nullptr};
+        const MvfGemmLn ln = {fold_next ? ws.xb : nullptr, D, fold_next ? ws.stats : nullptr, nullptr, nullptr, 0, nullptr};
         RUN(timed_gemm(dtype, EPI_RESID, ws.hid, 4 * D, w->fc2_w[l], 4 * D, w->fc2_b[l], nullptr, 0, ws.x, D, tap_ptr,
                        D, nullptr, w->ls2 ? w->ls2[l] : nullptr, N, Mc, D, 4 * D, st, fold_next ? &ln : nullptr));
       }
@@ -229,8 +279,21 @@ extern "C" int mvf_gemm_tc(int dtype, int epi, const void* A, int lda, const voi
 extern "C" int mvf_gemm_tc_ln(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C,
                               int ldc, float* resid, int ldr, void* tap, int ldt, const float* ls, int tpf, void* xb, int ldxb,
                               float* stats, const float* ln_mr, const float* ln_c, int M, int N, int K, hipStream_t st) {
-  const MvfGemmLn ln = {xb, ldxb, stats, ln_mr, ln_c};
+  const MvfGemmLn ln = {xb, ldxb, stats, ln_mr, ln_c, 0, nullptr};
   return mvf_gemm_tc_impl(dtype, epi, A, lda, W, ldw, bias, C, ldc, resid, ldr, tap, ldt, nullptr, ls, tpf, M, N, K, st, 0, 0, &ln);
+}
+extern "C" int mvf_gemm_fp8(int epi, const void* A, int lda, const unsigned* sa, const void* W, int ldw, const unsigned* sw,
+                            const float* bias, void* C, int ldc, unsigned* c_scales, float* resid, int ldr, void* tap, int ldt,
+                            const float* ls, int tpf, int M, int N, int K, hipStream_t st) {
+  return mvf_gemm_fp8_impl(epi, A, lda, sa, W, ldw, sw, bias, C, ldc, c_scales, resid, ldr, tap, ldt, ls, tpf, M, N, K, st);
+}
+// fp32 result of a bf16 GEMM without the in-place read-modify-write: out = A W^T + bias [+ addend]  (addend NULL: none).
+// The trainable backbone blocks' linears (forward, input gradient) -- ops._LinearTC.
+extern "C" int mvf_gemm_tc_f32(const void* A, int lda, const void* W, int ldw, const float* bias, float* out, int ldo,
+                               const float* addend, int M, int N, int K, hipStream_t st) {
+  const MvfGemmLn ln = {nullptr, 0, nullptr, nullptr, nullptr, addend ? 1 : 2, addend};
+  return mvf_gemm_tc_impl(MVF_BF16, EPI_RESID, A, lda, W, ldw, bias, nullptr, 0, out, ldo, nullptr, 0, nullptr, nullptr, 1, M, N, K,
+                          st, 0, 0, &ln);
 }
 extern "C" int mvf_ln_stats_finalize(const float* part, int ns, float* mean_rstd, int rows, int D, float eps, hipStream_t st) {
   return mvf_ln_stats_finalize_impl(part, ns, mean_rstd, rows, D, eps, st);

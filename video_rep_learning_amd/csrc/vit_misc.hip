@@ -125,6 +125,15 @@ __global__ void cast_bf16_kernel(const float* __restrict__ in, bf16_t* __restric
   }
 }
 
+// bf16 -> fp32 (attention output of a trainable block handed to the fp32 side of the graph)
+__global__ void cast_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const uint2 v = reinterpret_cast<const uint2*>(in)[i];
+    reinterpret_cast<float4*>(out)[i] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                                                    __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+  }
+}
+
 // diagnostic: which XCD (HW_REG_XCC_ID) and CU each workgroup of a 1-D launch lands on
 __global__ void xcc_map_kernel(int* __restrict__ out) {
   if (threadIdx.x == 0) {
@@ -210,6 +219,15 @@ int mvf_ln_stats_finalize_impl(const float* part, int ns, float* mr, int rows, i
   MVF_CHECK_ARG(part && mr && rows > 0 && ns > 0 && D > 0);
   hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, part, ns, mr, rows, 1.0f / (float)D,
                      eps);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_cast_bf16_f32(const void* in, float* out, size_t n, hipStream_t st) {
+  MVF_CHECK_ARG(in && out && n > 0 && n % 4 == 0 && ((uintptr_t)in % 8) == 0 && ((uintptr_t)out % 16) == 0);
+  const size_t n4 = n / 4;
+  hipLaunchKernelGGL(cast_f32_kernel, dim3((unsigned)std::min<size_t>(4096, (n4 + 255) / 256)), dim3(256), 0, st,
+                     (const bf16_t*)in, out, n4);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

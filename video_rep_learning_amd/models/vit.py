@@ -142,7 +142,10 @@ def block_forward(blk, x, heads, fast=False):
     x2 = x.reshape(F * N, D)
     h = ops.layer_norm(x2, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
     qkv = lin(h, blk.attn.qkv.weight, blk.attn.qkv.bias)
-    o = ops.temporal_attention(qkv, None, F, N, heads)                 # softmax(q k^T / sqrt(64)) v, no mask
+    if fast and D == heads * 64:       # bf16 mode: flash forward + bf16 MFMA backward (the reference's fp16 autocast)
+        o = ops.vit_attention_bf16(qkv, F, N, heads)
+    else:                              # parity mode: exact fp32 on the fp32 matrix cores
+        o = ops.temporal_attention(qkv, None, F, N, heads)             # softmax(q k^T / sqrt(64)) v, no mask
     if ls:
         x2 = ops.layerscale_add(lin(o, blk.attn.proj.weight, blk.attn.proj.bias), blk.ls1.gamma, x2)
     else:

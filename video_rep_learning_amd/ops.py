@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from ._lib import call, ptr, stream, F32, BF16
+from ._lib import call, ptr, stream, F32, BF16, FP8
 
 
 def _dt(dtype):
@@ -20,6 +20,8 @@ def _dt(dtype):
         return F32, torch.float32
     if dtype in (torch.bfloat16, 'bf16', BF16):
         return BF16, torch.bfloat16
+    if dtype in ('fp8', 'mxfp8'):          # backbone only: MX-fp8 GEMM operands, bf16 activations / taps
+        return FP8, torch.bfloat16
     raise ValueError('unsupported compute dtype %r' % (dtype,))
 
 
@@ -512,6 +514,46 @@ class _TemporalAttention(torch.autograd.Function):
         return dqkv, None, None, None, None
 
 
+class _VitAttentionBF16(torch.autograd.Function):
+    """Self-attention core of a TRAINABLE ViT block in bf16 mode (no mask, head dim 64): bf16 flash forward that keeps the
+    per-query log-sum-exp, bf16 MFMA backward (csrc/vit_attn_bwd.hip).  fp32 in / out, so it drops in where
+    temporal_attention (fp32 matrix cores, 1/16 of the rate) is used in parity mode."""
+
+    @staticmethod
+    def forward(ctx, qkv, F, N, H):
+        qkv = qkv.contiguous()
+        D = qkv.shape[1] // 3
+        dev = qkv.device
+        q16 = torch.empty(qkv.shape, device=dev, dtype=torch.bfloat16)
+        call('mvf_cast_f32_bf16', ptr(qkv), ptr(q16), qkv.numel(), stream())
+        o16 = torch.empty(F * N, D, device=dev, dtype=torch.bfloat16)
+        npad = (N + 15) // 16 * 16
+        lse = torch.zeros(F, H, npad, device=dev, dtype=torch.float32)
+        call('mvf_vit_attn_fwd_lse', ptr(q16), ptr(o16), ptr(lse), F, N, H, D, stream())
+        o = torch.empty(F * N, D, device=dev, dtype=torch.float32)
+        call('mvf_cast_bf16_f32', ptr(o16), ptr(o), o.numel(), stream())
+        ctx.save_for_backward(q16, o16, lse)
+        ctx.dims = (F, N, H, D)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q16, o16, lse = ctx.saved_tensors
+        F, N, H, D = ctx.dims
+        d_o = d_o.contiguous()
+        d16 = torch.empty(d_o.shape, device=d_o.device, dtype=torch.bfloat16)
+        call('mvf_cast_f32_bf16', ptr(d_o), ptr(d16), d_o.numel(), stream())
+        delta = torch.empty_like(lse)
+        dqkv = torch.empty(F * N, 3 * D, device=d_o.device, dtype=torch.float32)
+        call('mvf_vit_attn_bwd', ptr(q16), ptr(o16), ptr(d16), ptr(lse), ptr(delta), ptr(dqkv), F, N, H, D, stream())
+        return dqkv, None, None, None
+
+
+def vit_attention_bf16(qkv, F, N, H):
+    """qkv [F*N, 3*D] fp32 (q | k | v column blocks, heads of 64 contiguous inside) -> [F*N, D] fp32."""
+    return _VitAttentionBF16.apply(qkv, F, N, H)
+
+
 def temporal_attention(qkv, mask, B, S, H):
     """qkv [B*S, 3*Dm] (q | k | v column blocks, heads contiguous inside) -> [B*S, Dm]; mask [B,S] (0 = masked key)."""
     return _TemporalAttention.apply(qkv, mask, B, S, H)
@@ -861,9 +903,9 @@ def scl_loss(emb, steps, seq_lens, masks, num_frames, negative_type, temperature
 # ------------------------------------------------------------------------------------------------
 # frozen ViT backbone
 # ------------------------------------------------------------------------------------------------
-# bf16 mode: fold every LayerNorm (except block 0's norm1) into the GEMM that consumes it (include/mvf_hip.h: qkv_c / fc1_c).
-# MVF_LN_FOLD=0 keeps the LayerNorm kernels (A/B measurements).
-VIT_LN_FOLD = os.environ.get('MVF_LN_FOLD', '1') != '0'
+# bf16 mode: fold LayerNorms into the GEMM that consumes them (include/mvf_hip.h: qkv_c / fc1_c).  MVF_LN_FOLD: 0 = none (the
+# LayerNorm kernels), 1 = norm1 of blocks > 0 and every norm2, 2 = norm1 only, 3 = norm2 only (A/B measurements).
+VIT_LN_FOLD = int(os.environ.get('MVF_LN_FOLD', '2'))
 
 
 class PackedViT:
@@ -886,7 +928,7 @@ class PackedViT:
 
         def mat(t):
             t = t.detach().float().contiguous()
-            if self.code == BF16:
+            if self.code in (BF16, FP8):
                 o = torch.empty(t.shape, device=dev, dtype=torch.bfloat16)
                 call('mvf_cast_f32_bf16', t.data_ptr(), o.data_ptr(), t.numel(), stream())
                 t = o
@@ -917,6 +959,21 @@ class PackedViT:
             self.keep.append(arr)
             return ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p))
 
+        def mx_tables(fmt):
+            """Frozen weights [N, K] -> MX-fp8 (e4m3 bytes + E8M0 block scales [K/128][N]) with the device quantiser, once."""
+            wp, sp = [], []
+            for i in range(depth):
+                W = sd[fmt % i].detach().float().contiguous()
+                n, k = W.shape
+                if k % 256 != 0:
+                    raise _lib.MvfError('fp8 mode needs GEMM K %% 256 == 0 (got %d)' % k)
+                q = torch.empty(n, k, device=dev, dtype=torch.uint8)
+                sc = torch.empty(k // 128, n, device=dev, dtype=torch.int32)
+                call('mvf_quant_mxfp8', F32, W.data_ptr(), k, q.data_ptr(), k, sc.data_ptr(), n, k, stream())
+                self.keep += [q, sc]
+                wp.append(q.data_ptr()), sp.append(sc.data_ptr())
+            return ptr_table(wp), ptr_table(sp)
+
         def folded(lin, norm, skip0):
             """LayerNorm `norm` folded into the Linear `lin` that consumes it: per block (W' = gamma (.) W in bf16,
             d = b + W beta, c[n] = sum_k bf16(W')[n, k]) -- c is taken from the ROUNDED weights the matrix cores multiply, so
@@ -935,17 +992,28 @@ class PackedViT:
                 cp.append(f32(c.float())), bp.append(f32((bias + W @ beta).float()))
             return ptr_table(wp), ptr_table(bp), ptr_table(cp)
 
-        self.ln_fold = (VIT_LN_FOLD if ln_fold is None else bool(ln_fold)) and self.code == BF16 and dim % 128 == 0 and depth > 0
+        fold = int(VIT_LN_FOLD if ln_fold is None else ln_fold) if (self.code == BF16 and dim % 128 == 0 and depth > 0) else 0
+        self.ln_fold = fold
         w.ln1_w, w.ln1_b = table('blocks.%d.norm1.weight', f32), table('blocks.%d.norm1.bias', f32)
-        w.proj_w, w.proj_b = table('blocks.%d.attn.proj.weight', mat), table('blocks.%d.attn.proj.bias', f32)
+        w.proj_b, w.fc2_b = table('blocks.%d.attn.proj.bias', f32), table('blocks.%d.mlp.fc2.bias', f32)
         w.ln2_w, w.ln2_b = table('blocks.%d.norm2.weight', f32), table('blocks.%d.norm2.bias', f32)
-        w.fc2_w, w.fc2_b = table('blocks.%d.mlp.fc2.weight', mat), table('blocks.%d.mlp.fc2.bias', f32)
-        if self.ln_fold:
-            w.qkv_w, w.qkv_b, w.qkv_c = folded('attn.qkv', 'norm1', skip0=True)
-            w.fc1_w, w.fc1_b, w.fc1_c = folded('mlp.fc1', 'norm2', skip0=False)
+        if self.code != FP8:
+            w.proj_w, w.fc2_w = table('blocks.%d.attn.proj.weight', mat), table('blocks.%d.mlp.fc2.weight', mat)
+        if self.code == FP8:
+            w.proj_w, w.proj_s = mx_tables('blocks.%d.attn.proj.weight')
+            w.fc2_w, w.fc2_s = mx_tables('blocks.%d.mlp.fc2.weight')
+            w.qkv_w, w.qkv_s = mx_tables('blocks.%d.attn.qkv.weight')
+            w.fc1_w, w.fc1_s = mx_tables('blocks.%d.mlp.fc1.weight')
+            w.qkv_b, w.fc1_b = table('blocks.%d.attn.qkv.bias', f32), table('blocks.%d.mlp.fc1.bias', f32)
         else:
-            w.qkv_w, w.qkv_b = table('blocks.%d.attn.qkv.weight', mat), table('blocks.%d.attn.qkv.bias', f32)
-            w.fc1_w, w.fc1_b = table('blocks.%d.mlp.fc1.weight', mat), table('blocks.%d.mlp.fc1.bias', f32)
+            if fold in (1, 2):
+                w.qkv_w, w.qkv_b, w.qkv_c = folded('attn.qkv', 'norm1', skip0=True)
+            else:
+                w.qkv_w, w.qkv_b = table('blocks.%d.attn.qkv.weight', mat), table('blocks.%d.attn.qkv.bias', f32)
+            if fold in (1, 3):
+                w.fc1_w, w.fc1_b, w.fc1_c = folded('mlp.fc1', 'norm2', skip0=False)
+            else:
+                w.fc1_w, w.fc1_b = table('blocks.%d.mlp.fc1.weight', mat), table('blocks.%d.mlp.fc1.bias', f32)
         if 'blocks.0.ls1.gamma' in sd:
             w.ls1, w.ls2 = table('blocks.%d.ls1.gamma', f32), table('blocks.%d.ls2.gamma', f32)
         self.struct = w

@@ -129,6 +129,9 @@ int mvf_gemm_fp8(int epi, const void* A, int lda, const unsigned* sa, const void
  * batch one chunk of the token axis, fp32 partial sums with epi = 2 into a zeroed resid; trainable backbone blocks) */
 int mvf_gemm_tc_batched(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, float* resid, int ldr,
                         int M, int N, int K, int batch_rows, int w_batch_rows, hipStream_t stream);
+/* the same with plain fp32 partial results: `out` [M, ldo] need not be zeroed */
+int mvf_gemm_tc_batched_f32(const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K,
+                            int batch_rows, int w_batch_rows, hipStream_t stream);
 /* kernel choice for mvf_gemm_tc / mvf_vit_fwd (A/B measurements and tests): 0 automatic (bf16 and K % 128 == 0 ->
  * persistent 256x256 8-phase kernel, else 128x128), 1 always 128x128, 2 only 256x256 (MVF_ERR_UNSUPPORTED where it
  * cannot run), 3 the 256x256 kernel with one workgroup per tile instead of one per CU */
@@ -153,10 +156,10 @@ int mvf_cast_bf16_f32(const void* in, float* out, size_t n, hipStream_t stream);
 /* ViT attention of a TRAINABLE block in bf16 (timm Attention inside ViTBackEnd, models/transformer.py:364-392; fp16 autocast
  * in the reference): forward = mvf_vit_attn_fwd on the streamed kernel, also writing the per-query log2-domain log-sum-exp
  * lse [F, H, 16 * ceil(N / 16)]; backward: qkv / o / d_o bf16 as in the forward's layout, delta = caller-owned scratch
- * shaped like lse, dqkv [F*N, 3*D] fp32 (every element of the q, k, v column blocks is written).  Owner-computes, no atomics. */
+ * shaped like lse, dqkv [F*N, 3*D] fp32 or bf16 (out_dtype MVF_F32 / MVF_BF16; every element of the q, k, v column blocks is written).  Owner-computes, no atomics. */
 int mvf_vit_attn_fwd_lse(const void* qkv, void* out, float* lse, int F, int N, int H, int D, hipStream_t stream);
-int mvf_vit_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, float* dqkv, int F, int N,
-                     int H, int D, hipStream_t stream);
+int mvf_vit_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, int out_dtype,
+                     int F, int N, int H, int D, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Trainable head, fp32, forward + backward
@@ -194,6 +197,21 @@ int mvf_sum_batches(const float* part, float* out, int S, size_t n, int accumula
 int mvf_colscale(const float* y, const float* gamma, const float* resid, float* out, int rows, int D, int mode,
                  hipStream_t stream);
 int mvf_gelu_fwd(const float* x, float* y, size_t n, hipStream_t stream);
+/* -- the HBM-bound kernels between the bf16 GEMMs of a TRAINABLE backbone block (csrc/vit_train.hip; timm Block inside
+ *    ViTBackEnd, models/transformer.py:364-392, under fp16 autocast in the reference) --
+ * exact-erf GELU on bf16 (n % 8 == 0): g = u Phi(u);  du = dg (Phi(u) + u phi(u)) */
+int mvf_gelu_bf16(const void* u, void* g, size_t n, hipStream_t stream);
+int mvf_gelu_bwd_bf16(const void* dg, const void* u, void* du, size_t n, hipStream_t stream);
+/* one pass over in [M, C] (MVF_F32 / MVF_BF16, C % 4 == 0) that writes what the backward of a linear layer needs from it:
+ *   rowmajor_bf16 [M, C] (fp32 input only), transposed_bf16 [ceil(M / Mc), C, Mc] (tr[s][c][j] = in[s Mc + j][c], zero beyond M;
+ *   Mc % 256 == 0) and colsum_part [part_rows, C] fp32 (column sums of each slice of 256 rows: part_rows = ceil(R / 256)
+ *   with R = M, or M rounded up to Mc when the transposed output is requested; mvf_sum_batches adds them); any may be NULL */
+int mvf_grad_prep(int in_dtype, const void* in, void* rowmajor_bf16, void* transposed_bf16, float* colsum_part, int part_rows,
+                  int M, int C, int Mc, hipStream_t stream);
+/* LayerNorm backward with the statistics recomputed from x (as mvf_layernorm_fwd computes them):
+ *   dx = [dres +] d LN / dx (dh);  dx_bf16 = bf16(dx) (may be NULL);  dg += sum_rows dh xhat;  db += sum_rows dh  (atomics) */
+int mvf_ln_bwd_block(const float* dh, const float* x, const float* g, const float* dres, float* dx, void* dx_bf16, float* dg,
+                     float* db, int rows, int D, float eps, hipStream_t stream);
 int mvf_gelu_bwd(const float* dy, const float* x, float* dx, size_t n, hipStream_t stream);
 
 /* y = resid + dropout_p(x) with a counter-based mask (nn.Dropout + residual add, models/utils.py:153-159;

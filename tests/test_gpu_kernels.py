@@ -516,6 +516,119 @@ def test_vit_attention_bf16_forward_backward(F, N, H):
     assert max(parts) < 1e-2, parts      # dq, dk, dv
 
 
+@pytest.mark.parametrize('M,C,Mc,dt', [(1000, 768, 512, 'f32'), (513, 2304, 256, 'bf16'), (2048, 132, 1024, 'f32'),
+                                        (70, 64, 256, 'bf16')])
+def test_grad_prep_rowmajor_transposed_colsum(M, C, Mc, dt):
+    """mvf_grad_prep: one pass -> bf16 row-major copy (fp32 input), token-major zero-padded chunks tr[s][c][j] = in[s Mc + j][c]
+    and the column-sum partials of each 256-row slice.  Copies are exact (bf16 rounding of the input); sums to fp32 order."""
+    g = gen(61)
+    x = torch.randn(M, C, generator=g)
+    xin = (x if dt == 'f32' else x.to(torch.bfloat16)).to(DEV)
+    S = (M + Mc - 1) // Mc
+    PR = S * Mc // 256
+    rm = torch.full((M, C), 7.0, device=DEV, dtype=torch.bfloat16) if dt == 'f32' else None
+    tr = torch.full((S, C, Mc), 7.0, device=DEV, dtype=torch.bfloat16)
+    part = torch.full((PR, C), 7.0, device=DEV)
+    _lib.call('mvf_grad_prep', _lib.F32 if dt == 'f32' else _lib.BF16, xin.data_ptr(), _lib.ptr(rm), tr.data_ptr(), part.data_ptr(),
+              PR, M, C, Mc, _lib.stream())
+    torch.cuda.synchronize()
+    xb = x.to(torch.bfloat16)
+    pad = torch.zeros(S * Mc, C, dtype=torch.bfloat16)
+    pad[:M] = xb
+    assert torch.equal(tr.cpu(), pad.view(S, Mc, C).permute(0, 2, 1).contiguous())
+    if rm is not None:
+        assert torch.equal(rm.cpu(), xb)
+    src = torch.zeros(S * Mc, C, dtype=torch.float64)
+    src[:M] = (x if dt == 'f32' else xb).double()
+    check(part, src.view(PR, 256, C).sum(1), 1e-5, 'colsum partials')
+    # column sums alone (no transposed output): the partial rows stop at M
+    PR2 = (M + 255) // 256
+    part2 = torch.full((PR2, C), 7.0, device=DEV)
+    _lib.call('mvf_grad_prep', _lib.F32 if dt == 'f32' else _lib.BF16, xin.data_ptr(), None, None, part2.data_ptr(), PR2, M, C, 0,
+              _lib.stream())
+    check(part2.sum(0), src.sum(0), 1e-5, 'colsum')
+    with pytest.raises(_lib.MvfError):       # a partial buffer of the wrong height is refused, not overrun
+        _lib.call('mvf_grad_prep', _lib.F32 if dt == 'f32' else _lib.BF16, xin.data_ptr(), None, None, part2.data_ptr(), PR2 + 1, M, C,
+                  0, _lib.stream())
+
+
+def test_gelu_bf16_forward_backward():
+    """exact-erf GELU on bf16 tensors vs fp64 on the same bf16 inputs: the result is the correctly rounded bf16 (<= 1 ulp)"""
+    g = gen(62)
+    u = (torch.randn(3000, 64, generator=g) * 2.5).to(torch.bfloat16)
+    dg = torch.randn(3000, 64, generator=g).to(torch.bfloat16)
+    ud, dd = u.to(DEV), dg.to(DEV)
+    out, du = torch.empty_like(ud), torch.empty_like(ud)
+    _lib.call('mvf_gelu_bf16', ud.data_ptr(), out.data_ptr(), ud.numel(), _lib.stream())
+    _lib.call('mvf_gelu_bwd_bf16', dd.data_ptr(), ud.data_ptr(), du.data_ptr(), ud.numel(), _lib.stream())
+    ur = u.double().requires_grad_(True)
+    yr = torch.nn.functional.gelu(ur)
+    yr.backward(dg.double())
+    check(out.float(), yr, 4e-3, 'gelu bf16')          # one bf16 ulp of the largest value
+    check(du.float(), ur.grad, 4e-3, 'gelu bf16 backward')
+    assert rel_l2(out.float(), yr) < 2.5e-3 and rel_l2(du.float(), ur.grad) < 2.5e-3
+
+
+@pytest.mark.parametrize('rows,D', [(1000, 768), (37, 1024), (64, 1536), (5, 256)])
+def test_ln_bwd_block_vs_autograd(rows, D):
+    """LayerNorm backward of the fused trainable block: statistics recomputed from x, residual gradient added in the same
+    pass, optional bf16 copy, dgamma / dbeta accumulated into the given buffers -- against fp64 autograd."""
+    g = gen(63)
+    x = torch.randn(rows, D, generator=g) * 2 + 0.3
+    gam, bet = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g)
+    dh, dres = torch.randn(rows, D, generator=g), torch.randn(rows, D, generator=g)
+    xr, gr, br = x.double().requires_grad_(True), gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6).backward(dh.double())
+    dx = torch.empty(rows, D, device=DEV)
+    dxb = torch.empty(rows, D, device=DEV, dtype=torch.bfloat16)
+    dg0, db0 = torch.randn(D, generator=g), torch.randn(D, generator=g)       # accumulate on top of existing values
+    dgd, dbd = dg0.to(DEV), db0.to(DEV)
+    dh_d, x_d, gam_d, dres_d = dh.to(DEV), x.to(DEV), gam.to(DEV), dres.to(DEV)
+    _lib.call('mvf_ln_bwd_block', dh_d.data_ptr(), x_d.data_ptr(), gam_d.data_ptr(), dres_d.data_ptr(),
+              dx.data_ptr(), dxb.data_ptr(), dgd.data_ptr(), dbd.data_ptr(), rows, D, 1e-6, _lib.stream())
+    check(dx, xr.grad + dres.double(), 2e-5, 'ln dx + dres')
+    assert torch.equal(dxb, dx.to(torch.bfloat16))
+    check(dgd, gr.grad + dg0.double(), 2e-5, 'ln dgamma')
+    check(dbd, br.grad + db0.double(), 2e-5, 'ln dbeta')
+    dx2 = torch.empty(rows, D, device=DEV)
+    _lib.call('mvf_ln_bwd_block', dh_d.data_ptr(), x_d.data_ptr(), gam_d.data_ptr(), None, dx2.data_ptr(), None,
+              dgd.data_ptr(), dbd.data_ptr(), rows, D, 1e-6, _lib.stream())
+    check(dx2, xr.grad, 2e-5, 'ln dx')
+
+
+@pytest.mark.parametrize('F,N,D,H', [(3, 197, 768, 12), (11, 197, 256, 4), (2, 257, 1024, 16)])
+def test_vit_block_tc_vs_fp32_block(F, N, D, H):
+    """The fused bf16 trainable block (ops.vit_block_tc: bf16 GEMM operands end to end, fp32 residual stream and parameter
+    gradients) against the exact fp32 composition of the same block (models.vit.block_forward, parity mode): output and
+    every gradient within bf16 error (rel-L2; the fp32 composition is itself checked against the oracle elsewhere).
+    F = 11, N = 197: more than one 2048-token chunk in the split-K weight gradients."""
+    from video_rep_learning_amd.models import vit as V
+    torch.manual_seed(5)
+    blk = V._Block(D, False).to(DEV)
+    for n_, p in blk.named_parameters():       # trained-looking parameters: non-trivial LayerNorm affine and biases
+        with torch.no_grad():
+            if p.dim() == 1:
+                p.copy_(torch.randn_like(p) * 0.1 + (1.0 if 'norm' in n_ and 'weight' in n_ else 0.0))
+            else:
+                p.copy_(torch.randn_like(p) * 0.04)
+    x = torch.randn(F, N, D, device=DEV)
+    gy = torch.randn(F, N, D, device=DEV)
+    outs = {}
+    for fast in (False, True):
+        xi = x.clone().requires_grad_(True)
+        blk.zero_grad()
+        y = V.block_forward(blk, xi, H, fast=fast)
+        y.backward(gy)
+        outs[fast] = (y.detach(), xi.grad.detach(), {n_: p.grad.detach().clone() for n_, p in blk.named_parameters()})
+    torch.cuda.synchronize()
+    y32, dx32, g32 = outs[False]
+    y16, dx16, g16 = outs[True]
+    assert rel_l2(y16, y32) < 4e-3, rel_l2(y16, y32)
+    assert rel_l2(dx16, dx32) < 1.5e-2, rel_l2(dx16, dx32)
+    errs = {n_: rel_l2(g16[n_], g32[n_]) for n_ in g32}
+    assert max(errs.values()) < 2e-2, errs
+
+
 # ------------------------------------------------------------------------------------------------ head ops
 def _leaf(t):
     return t.clone().to(DEV).requires_grad_(True)

@@ -26,6 +26,11 @@ SIGNATURES = {
     'mvf_gemm_tc_ln': 'iipipippipipipipipppiiip',
     'mvf_ln_stats_finalize': 'pipiifp',
     'mvf_gemm_tc_f32': 'pipippipiiip',
+    'mvf_gemm_tc_batched_f32': 'pipipiiiiiip',
+    'mvf_gelu_bf16': 'ppzp',
+    'mvf_gelu_bwd_bf16': 'pppzp',
+    'mvf_grad_prep': 'ippppiiiip',
+    'mvf_ln_bwd_block': 'ppppppppiifp',
     'mvf_quant_mxfp8': 'ipzpzpiip',
     'mvf_layernorm_mxfp8': 'pzpppzpiifp',
     'mvf_gemm_fp8': 'ipippipppippipipiiiip',
@@ -39,7 +44,7 @@ SIGNATURES = {
     'mvf_cast_f32_bf16': 'ppzp',
     'mvf_cast_bf16_f32': 'ppzp',
     'mvf_vit_attn_fwd_lse': 'pppiiiip',
-    'mvf_vit_attn_bwd': 'ppppppiiiip',
+    'mvf_vit_attn_bwd': 'ppppppiiiiip',
     'mvf_hgemm': 'pllpllplppllii' + 'iiifiip',
     'mvf_hgemm_ex': 'pllpllplppllii' + 'iiifii' + 'plfuup',
     'mvf_hlinear_bwd': 'plplplplplpiiiip',

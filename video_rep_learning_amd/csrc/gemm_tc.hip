@@ -333,6 +333,14 @@ extern "C" int mvf_gemm_tc_batched(int epi, const void* A, int lda, const void* 
                           K, st, batch_rows, w_batch_rows);
 }
 
+// the same with plain fp32 results (no addend: `out` need not be initialised)
+extern "C" int mvf_gemm_tc_batched_f32(const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K,
+                                       int batch_rows, int w_batch_rows, hipStream_t st) {
+  const MvfGemmLn ln = {nullptr, 0, nullptr, nullptr, nullptr, 2, nullptr};
+  return mvf_gemm_tc_impl(MVF_BF16, EPI_RESID, A, lda, W, ldw, nullptr, nullptr, 0, out, ldo, nullptr, 0, nullptr, nullptr, 1, M, N,
+                          K, st, batch_rows, w_batch_rows, &ln);
+}
+
 extern "C" int mvf_gemm_tc_select(int variant) {
   MVF_CHECK_ARG(variant >= 0 && variant <= 3);
   g_variant = variant;

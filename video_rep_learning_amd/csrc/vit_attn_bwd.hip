@@ -36,11 +36,20 @@ struct BwdArgs {
   const bf16_t* d_o;   // [F*N, D]
   const float* lse;    // [F, H, Npad] log2-domain log-sum-exp of the scaled scores
   float* delta;        // [F, H, Npad]
-  float* dqkv;         // [F*N, 3*D] fp32
+  void* dqkv;          // [F*N, 3*D] fp32 or bf16 (out_bf16)
+  int out_bf16;
   int N, H, D, Npad;
   float scale_log2;    // 64^-0.5 * log2(e)
   float scale;         // 64^-0.5
 };
+
+// four consecutive gradient values -> dqkv[off .. off + 3]
+__device__ __forceinline__ void store4(const BwdArgs& a, size_t off, const f32x4_t& v) {
+  if (a.out_bf16)
+    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.dqkv) + off) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+  else
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.dqkv) + off) = make_float4(v[0], v[1], v[2], v[3]);
+}
 
 // byte offset of logical 16-byte chunk ch (0..7) of image row `row` (128-byte rows, 32-byte chunks swizzled)
 __device__ __forceinline__ int row_off(int row, int ch) {
@@ -195,10 +204,9 @@ __global__ __launch_bounds__(256, 2) void vattn_dq_kernel(BwdArgs a) {
   for (int i = 0; i < 2; ++i) {
     const int q = (qt0 + i) * 16 + c;
     if (q < a.N) {
-      float* row = a.dqkv + ((size_t)f * a.N + q) * ld + h * HD;       // dQ^T[d = 16 dt + 4g + r][query c]
+      const size_t off = ((size_t)f * a.N + q) * ld + h * HD;           // dQ^T[d = 16 dt + 4g + r][query c]
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        *reinterpret_cast<float4*>(row + dt * 16 + 4 * g) = make_float4(dq[i][dt][0], dq[i][dt][1], dq[i][dt][2], dq[i][dt][3]);
+      for (int dt = 0; dt < 4; ++dt) store4(a, off + dt * 16 + 4 * g, dq[i][dt]);
     }
   }
 }
@@ -296,12 +304,11 @@ __global__ __launch_bounds__(256, 2) void vattn_dkv_kernel(BwdArgs a) {
   for (int i = 0; i < 2; ++i) {
     const int key = (kt0 + i) * 16 + c;
     if (key < a.N) {
-      float* row = a.dqkv + ((size_t)f * a.N + key) * ld + h * HD;
+      const size_t off = ((size_t)f * a.N + key) * ld + h * HD;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        *reinterpret_cast<float4*>(row + a.D + dt * 16 + 4 * g) = make_float4(dk[i][dt][0], dk[i][dt][1], dk[i][dt][2], dk[i][dt][3]);
-        *reinterpret_cast<float4*>(row + 2 * a.D + dt * 16 + 4 * g) =
-            make_float4(dv[i][dt][0], dv[i][dt][1], dv[i][dt][2], dv[i][dt][3]);
+        store4(a, off + a.D + dt * 16 + 4 * g, dk[i][dt]);
+        store4(a, off + 2 * a.D + dt * 16 + 4 * g, dv[i][dt]);
       }
     }
   }
@@ -310,13 +317,15 @@ __global__ __launch_bounds__(256, 2) void vattn_dkv_kernel(BwdArgs a) {
 }  // namespace
 
 // workspace-free: delta is caller-owned [F, H, Npad] like lse
-extern "C" int mvf_vit_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, float* dqkv,
-                                int F, int N, int H, int D, hipStream_t st) {
+extern "C" int mvf_vit_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                                int out_dtype, int F, int N, int H, int D, hipStream_t st) {
+  MVF_CHECK_ARG(out_dtype == MVF_F32 || out_dtype == MVF_BF16);
   MVF_CHECK_ARG(qkv && o && d_o && lse && delta && dqkv && F > 0 && N > 1 && H > 0 && D == H * HD);
   MVF_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)o % 16) == 0 && ((uintptr_t)d_o % 16) == 0 &&
                 ((uintptr_t)lse % 16) == 0 && ((uintptr_t)delta % 16) == 0 && ((uintptr_t)dqkv % 16) == 0);
   BwdArgs a;
   a.qkv = (const bf16_t*)qkv; a.o = (const bf16_t*)o; a.d_o = (const bf16_t*)d_o; a.lse = lse; a.delta = delta; a.dqkv = dqkv;
+  a.out_bf16 = out_dtype == MVF_BF16;
   a.N = N; a.H = H; a.D = D; a.Npad = ceil_div(N, 16) * 16;
   a.scale = 0.125f;
   a.scale_log2 = LOG2E * 0.125f;

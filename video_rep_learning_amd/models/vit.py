@@ -137,6 +137,12 @@ def block_forward(blk, x, heads, fast=False):
     the frozen blocks keep the bf16 persistent GEMM path."""
     ls = hasattr(blk, 'ls1')          # DINOv2: x + gamma * f(x) instead of the residual fused into the GEMM epilogue
     F, N, D = x.shape
+    if fast and not ls and blk.attn.qkv.bias is not None and ops.vit_block_tc_supported(D, heads, blk.mlp.fc1.weight.shape[0]):
+        # bf16 mode: the whole block as one autograd node with bf16 GEMM operands end to end (ops._ViTBlockTC)
+        return ops.vit_block_tc(x, heads, blk.norm1.eps, blk.norm2.eps,
+                                (blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight,
+                                 blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
+                                 blk.mlp.fc2.weight, blk.mlp.fc2.bias))
     # bf16 mode: the four GEMMs' forward and input gradient on the bf16 persistent kernel (ops._LinearTC); fp32 mode: exact
     lin = ops.linear_tc if fast else ops.linear
     x2 = x.reshape(F * N, D)

@@ -545,13 +545,177 @@ class _VitAttentionBF16(torch.autograd.Function):
         call('mvf_cast_f32_bf16', ptr(d_o), ptr(d16), d_o.numel(), stream())
         delta = torch.empty_like(lse)
         dqkv = torch.empty(F * N, 3 * D, device=d_o.device, dtype=torch.float32)
-        call('mvf_vit_attn_bwd', ptr(q16), ptr(o16), ptr(d16), ptr(lse), ptr(delta), ptr(dqkv), F, N, H, D, stream())
+        call('mvf_vit_attn_bwd', ptr(q16), ptr(o16), ptr(d16), ptr(lse), ptr(delta), ptr(dqkv), F32, F, N, H, D, stream())
         return dqkv, None, None, None
 
 
 def vit_attention_bf16(qkv, F, N, H):
     """qkv [F*N, 3*D] fp32 (q | k | v column blocks, heads of 64 contiguous inside) -> [F*N, D] fp32."""
     return _VitAttentionBF16.apply(qkv, F, N, H)
+
+
+class _ViTBlockTC(torch.autograd.Function):
+    """One TRAINABLE timm Block (x + proj(attn(norm1 x)); x + fc2(gelu(fc1(norm2 x)))) in bf16 mode as ONE autograd node
+    (ViTBackEnd, reference models/transformer.py:364-392, under fp16 autocast there).  The residual stream stays fp32; every
+    GEMM operand is bf16 and is written once by its producer (LayerNorm, the previous GEMM's epilogue, GELU, attention) --
+    no per-GEMM casts, no zero-filled outputs, no fp32 copies of the wide activations:
+      forward   4 GEMMs on the persistent bf16 kernel (qkv / fc1: bf16 result; proj / fc2: fp32 = residual + result, out of place)
+      backward  per linear layer: dX = dY W (same kernel, W^T cast once), dW = dY^T X split-K over chunks of MC tokens
+                (mvf_grad_prep writes the token-major operands and the bias-gradient partial sums in one pass),
+                bf16 flash-attention backward, LayerNorm backward with the residual gradient added in the same pass.
+    Parameter gradients are fp32 and go straight into the flat-gradient slots when every parameter has one."""
+
+    MC = 2048      # tokens per split-K chunk of the weight gradients
+
+    @staticmethod
+    def _bf(dev, *shape):
+        return torch.empty(*shape, device=dev, dtype=torch.bfloat16)
+
+    @staticmethod
+    def _store(a, w, bias, M, N, K):
+        """bf16 [M, N] = a [M, K] w[N, K]^T + bias"""
+        c = _ViTBlockTC._bf(a.device, M, N)
+        call('mvf_gemm_tc', BF16, _lib.EPI_STORE, ptr(a), K, ptr(w), K, ptr(bias), ptr(c), N, None, 0, None, 0, None, None, 1,
+             M, N, K, stream())
+        return c
+
+    @staticmethod
+    def _f32(a, w, bias, addend, M, N, K):
+        """fp32 [M, N] = a w^T + bias [+ addend]"""
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+        call('mvf_gemm_tc_f32', ptr(a), K, ptr(w), K, ptr(bias), ptr(out), N, ptr(addend), M, N, K, stream())
+        return out
+
+    @staticmethod
+    def _wt(w):
+        """fp32 [N, K] -> bf16 [K, N] (the operand of dX = dY W)"""
+        N, K = w.shape
+        o = _ViTBlockTC._bf(w.device, K, N)
+        call('mvf_transpose_chunks', ptr(w), ptr(o), N, K, N, stream())
+        return o
+
+    @staticmethod
+    def forward(ctx, x, heads, eps1, eps2, *params):
+        n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = params
+        F_, N_, D = x.shape
+        M, Hd = F_ * N_, f1w.shape[0]
+        x = x.contiguous().view(M, D)
+        dev, T = x.device, _ViTBlockTC
+        wq, wp, w1, w2 = (_LinearTC._bf16(w.detach().contiguous()) for w in (qkvw, pw, f1w, f2w))
+        h1 = T._bf(dev, M, D)
+        call('mvf_layernorm_fwd', BF16, ptr(x), D, ptr(n1w), ptr(n1b), ptr(h1), D, M, D, eps1, stream())
+        qkv = T._store(h1, wq, qkvb, M, 3 * D, D)
+        o = T._bf(dev, M, D)
+        lse = torch.empty(F_, heads, (N_ + 15) // 16 * 16, device=dev, dtype=torch.float32)
+        call('mvf_vit_attn_fwd_lse', ptr(qkv), ptr(o), ptr(lse), F_, N_, heads, D, stream())
+        x1 = T._f32(o, wp, pb, x, M, D, D)
+        h2 = T._bf(dev, M, D)
+        call('mvf_layernorm_fwd', BF16, ptr(x1), D, ptr(n2w), ptr(n2b), ptr(h2), D, M, D, eps2, stream())
+        u = T._store(h2, w1, f1b, M, Hd, D)
+        g = T._bf(dev, M, Hd)
+        call('mvf_gelu_bf16', ptr(u), ptr(g), u.numel(), stream())
+        y = T._f32(g, w2, f2b, x1, M, D, Hd)
+        ctx.save_for_backward(x, x1, h1, qkv, o, lse, h2, u, g, *params)
+        ctx.cfg = (F_, N_, heads, eps1, eps2)
+        ctx.use_slots = all(grad_slot(p) is not None for p in params)
+        return y.view(F_, N_, D)
+
+    @staticmethod
+    def _linear_bwd(ctx, dy_t, dy_bpart, xin, w, b, grads, iw, ib, M):
+        """dW (+)= dy^T x from the token-major chunks `dy_t` [S*N, MC] and x's (made here), db from the column-sum partials"""
+        T, MC = _ViTBlockTC, _ViTBlockTC.MC
+        N, K = w.shape
+        S = (M + MC - 1) // MC
+        xt = T._bf(w.device, S * K, MC)
+        call('mvf_grad_prep', BF16, ptr(xin), None, ptr(xt), None, 0, M, K, MC, stream())
+        part = torch.empty(S * N, K, device=w.device, dtype=torch.float32)
+        call('mvf_gemm_tc_batched_f32', ptr(dy_t), MC, ptr(xt), MC, ptr(part), K, S * N, K, MC, N, K, stream())
+        for t, src, n, idx, owner in ((part, S, N * K, iw, w), (dy_bpart, dy_bpart.shape[0], N, ib, b)):
+            if owner is None:
+                continue
+            if ctx.use_slots:
+                call('mvf_sum_batches', ptr(t), grad_slot(owner).data_ptr(), src, n, 1, stream())
+                grad_ready(owner)
+            else:
+                grads[idx] = torch.empty_like(owner)
+                call('mvf_sum_batches', ptr(t), ptr(grads[idx]), src, n, 0, stream())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, x1, h1, qkv, o, lse, h2, u, g = ctx.saved_tensors[:9]
+        params = ctx.saved_tensors[9:]
+        n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = params
+        F_, N_, heads, eps1, eps2 = ctx.cfg
+        M, D = x.shape
+        Hd = f1w.shape[0]
+        dev, T, MC = x.device, _ViTBlockTC, _ViTBlockTC.MC
+        S = (M + MC - 1) // MC
+        PR = S * MC // 256                   # partial column sums: one row per 256 (zero-padded) tokens
+        grads = [None] * 12
+        dy = dy.contiguous().view(M, D)
+
+        def prep(t, dt, C, rowmajor):
+            tt = T._bf(dev, S * C, MC)
+            part = torch.empty(PR, C, device=dev, dtype=torch.float32)
+            rm = T._bf(dev, M, C) if rowmajor else None
+            call('mvf_grad_prep', dt, ptr(t), ptr(rm), ptr(tt), ptr(part), PR, M, C, MC, stream())
+            return rm, tt, part
+
+        def ln_bwd(dh, xin, gam, dres, want_bf16, ig, ib, eps):
+            dx = torch.empty(M, D, device=dev, dtype=torch.float32)
+            dxb = T._bf(dev, M, D) if want_bf16 else None
+            if ctx.use_slots:
+                gg, gb = grad_slot(params[ig]), grad_slot(params[ib])
+            else:
+                gg = grads[ig] = torch.zeros_like(gam)
+                gb = grads[ib] = torch.zeros_like(gam)
+            call('mvf_ln_bwd_block', ptr(dh), ptr(xin), ptr(gam), ptr(dres), ptr(dx), ptr(dxb), gg.data_ptr(), gb.data_ptr(),
+                 M, D, eps, stream())
+            if ctx.use_slots:
+                grad_ready(params[ig], params[ib])
+            return dx, dxb
+
+        # fc2: y = x1 + g W2^T + b2
+        dyb, dyt, dyp = prep(dy, F32, D, True)
+        dg = T._store(dyb, T._wt(f2w), None, M, Hd, D)
+        T._linear_bwd(ctx, dyt, dyp, g, f2w, f2b, grads, 10, 11, M)
+        du = T._bf(dev, M, Hd)
+        call('mvf_gelu_bwd_bf16', ptr(dg), ptr(u), ptr(du), du.numel(), stream())
+        del dg
+        # fc1: u = h2 W1^T + b1
+        _, dut, dup = prep(du, BF16, Hd, False)
+        dh2 = T._f32(du, T._wt(f1w), None, None, M, D, Hd)
+        T._linear_bwd(ctx, dut, dup, h2, f1w, f1b, grads, 8, 9, M)
+        del du, dut
+        # norm2 + the residual branch: dx1 = dy + d LN2
+        dx1, dx1b = ln_bwd(dh2, x1, n2w, dy, True, 6, 7, eps2)
+        # proj: x1 = x + o Wp^T + bp
+        _, dx1t, dx1p = prep(dx1b, BF16, D, False)
+        d_o = T._store(dx1b, T._wt(pw), None, M, D, D)
+        T._linear_bwd(ctx, dx1t, dx1p, o, pw, pb, grads, 4, 5, M)
+        # attention core
+        delta = torch.empty_like(lse)
+        dqkv = T._bf(dev, M, 3 * D)
+        call('mvf_vit_attn_bwd', ptr(qkv), ptr(o), ptr(d_o), ptr(lse), ptr(delta), ptr(dqkv), BF16, F_, N_, heads, D, stream())
+        # qkv: qkv = h1 Wq^T + bq
+        _, dqt, dqp = prep(dqkv, BF16, 3 * D, False)
+        dh1 = T._f32(dqkv, T._wt(qkvw), None, None, M, D, 3 * D)
+        T._linear_bwd(ctx, dqt, dqp, h1, qkvw, qkvb, grads, 2, 3, M)
+        # norm1 + the residual branch
+        dx, _ = ln_bwd(dh1, x, n1w, dx1, False, 0, 1, eps1)
+        return (dx.view(F_, N_, D), None, None, None) + tuple(grads)
+
+
+def vit_block_tc_supported(D, heads, hidden):
+    """Shapes the fused trainable block takes: head dim 64, every GEMM dimension a multiple of the 256-row batch of the split-K
+    weight gradient."""
+    return D == heads * 64 and D % 256 == 0 and hidden % 256 == 0
+
+
+def vit_block_tc(x, heads, eps1, eps2, params):
+    """x [F, N, D] fp32 -> [F, N, D] fp32; params = (norm1.weight, norm1.bias, qkv.weight, qkv.bias, proj.weight, proj.bias,
+    norm2.weight, norm2.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias) of a timm Block without LayerScale."""
+    return _ViTBlockTC.apply(x, heads, eps1, eps2, *params)
 
 
 def temporal_attention(qkv, mask, B, S, H):

@@ -143,6 +143,8 @@ int mvf_debug_xcc_map(int* out, int nblocks, int threads, int lds_bytes, hipStre
 int mvf_gemm_tc_set_cus(int n);
 /* diagnostic build of the 256x256 kernel: per-block s_memtime stamps into buf[blocks][2][8] (NULL = off, the default) */
 int mvf_gemm_tc_debug_stamps(unsigned long long* buf);
+/* diagnostic, stamped build only: A rows are read as (row & mask), so A's footprint is mask + 1 rows (L2-resident feed rate) */
+int mvf_gemm_tc_debug_rowmask(unsigned mask);
 int mvf_patchify(int dtype, const float* frames, void* out, int F, int H, int W, int P, hipStream_t stream);
 int mvf_layernorm_fwd(int out_dtype, const float* x, size_t in_stride, const float* g, const float* b, void* y,
                       size_t out_stride, int rows, int D, float eps, hipStream_t stream);
@@ -271,7 +273,8 @@ int mvf_lstp_reduce_frames(const float* G, float* out, int Bc, int nq, int T, in
 int mvf_token_pool(const void* const* taps_host, int n_taps, int dtype, int D, int F, int N, int mode, float* out,
                    hipStream_t stream);
 /* gradient of the pooling w.r.t. the tokens (partially frozen backbone):
- * dx[t][f*N+n, :] = sum_j W[f,j,n] dpooled[b,j,t,:] + dS[f,j,n] vec[f|0,j,:]; dx_host: HOST array of n_taps fp32 [F*N, D] */
+ * dx[t][f*N+n, :] = sum_j W[f,j,n] dpooled[b,j,t,:] + dS[f,j,n] vec[f|0,j,:]; dx_host: HOST array of n_taps fp32 [F*N, D];
+ * either term is skipped when its pair (w, dpooled) / (ds, vec) is NULL */
 int mvf_lstp_dx(float* const* dx_host, int n_taps, int D, int F, int N, int T, int nq, const float* w, const float* ds,
                 const float* dpooled, const float* vec, int per_frame, hipStream_t stream);
 

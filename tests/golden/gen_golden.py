@@ -132,6 +132,10 @@ HEAD_CASES = {
 HEAD_CASES_FWB = {
     'fwb_train': (dict(SMALL, fwb=True), 3, 8, 16, 3, True, 2001),
     'fwb_eval':  (dict(SMALL, fwb=True, nst=2, nsdt=1, one_hot='none', smart_final='avg'), 2, 8, 16, 0, False, 2002),
+    # SMART_LN_KEYS together with dynamic (per-frame) queries (mvformer.py:365-400)
+    'ln_keys_dyn':       (dict(SMALL, ln_keys=True, nsdt=2, dyn_ctrl='separate'), 2, 8, 16, 2, True, 2003),
+    'ln_keys_dyn_first': (dict(SMALL, ln_keys=True, nst=0, nsdt=3, dyn_ctrl='first', one_hot='none', disjoint=True), 2, 8, 16, 0,
+                          True, 2004),
 }
 
 

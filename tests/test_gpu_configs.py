@@ -147,7 +147,7 @@ def test_config1_full_size_fp32_and_bf16_vs_oracle():
     # bounds: measured on MI355X (profiles/r02/parity.txt) with ~2-3x margin.  The two sides differ by fp32 summation order and
     # by bf16 roundings that flip where a value sits on a rounding boundary (one bf16 ulp of a tap's largest element is 3.9e-3)
     assert r['emb'] <= 5e-2 and r['loss'] <= 5e-3 and r['emb_fp32'] <= 1e-1, r
-    assert r['loss_head'] <= 1e-3 and r['head_grad'] <= 2e-2, r
+    assert r['loss_head'] <= 1e-3 and r['head_grad'] <= 2e-2 and r['head_grad_raw'] <= 0.1, r
     assert r['grad_cos'] >= 0.98, r
 
 

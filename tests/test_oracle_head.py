@@ -86,8 +86,8 @@ def test_head_forward_backward(golden, name):
         if key not in gh.files:
             continue
         g = p.grad if p.grad is not None else torch.zeros_like(p)
-        if full:
-            close(g, gh[key], rtol=1e-3, atol=1e-5)
+        if full:       # atol: gradients that are exactly 0 in exact arithmetic (a bias feeding train-mode BN) are fp32 noise ~1e-5
+            close(g, gh[key], rtol=1e-3, atol=2e-5)
         else:
             ref = gh[key]
             got = C.tensor_digest(g)

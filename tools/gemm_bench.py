@@ -28,6 +28,9 @@ def main():
     p.add_argument('--warm', type=int, default=3)
     p.add_argument('--ln', nargs='?', const='both', default=None, choices=['both', 'xb', 'stats'])
     p.add_argument('--rounds', type=int, default=1)
+    # what happens to the A operand right before every timed launch: nothing (A was evicted by the previous launch's output),
+    # a kernel READING it, or a kernel WRITING it (the real pipeline: the producer ran just before) -- is A cache-resident?
+    p.add_argument('--pre', default='none', choices=['none', 'read', 'write'])
     a = p.parse_args()
     dev = 'cuda'
     M = a.frames * 197
@@ -59,10 +62,26 @@ def main():
                 _lib.call('mvf_gemm_tc_ln', _lib.BF16, epi, A.data_ptr(), k, W.data_ptr(), k, b.data_ptr(), C.data_ptr(), n, None,
                           0, None, 0, None, 197, None, 0, None, mr.data_ptr(), c.data_ptr(), M, n, k, st)
 
+        A2 = A.clone()
+
         def timed(fn):
             for _ in range(a.warm):
                 fn()
             torch.cuda.synchronize()
+            if a.pre != 'none':
+                tot = 0.0
+                for _ in range(a.iters):
+                    if a.pre == 'read':
+                        A.view(torch.int16).max()
+                    else:
+                        A.copy_(A2)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    tot += e0.elapsed_time(e1)
+                return tot / a.iters * 1e-3
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):

@@ -29,12 +29,15 @@ def main():
     for _ in range(3):
         fn()
     _lib.call('mvf_gemm_tc_debug_stamps', buf.data_ptr())
+    # ROWMASK=2047: A rows read as row & 2047 -> A footprint 2048 rows (L2-resident): the K loop's feed rate without misses
+    _lib.call('mvf_gemm_tc_debug_rowmask', int(os.environ.get('ROWMASK', str(0x7fffffff))))
     _lib.call('mvf_gemm_tc_select', int(os.environ.get('VARIANT', '2')))
     for _ in range(2):
         fn()
     _lib.call('mvf_gemm_tc_select', 0)
     torch.cuda.synchronize()
     _lib.call('mvf_gemm_tc_debug_stamps', None)
+    _lib.call('mvf_gemm_tc_debug_rowmask', 0x7fffffff)
     s = buf.cpu().numpy().reshape(nblk, 2, 8).astype(np.int64)
     s = s[s[:, 0, 7] != 0]          # workgroups that ran (persistent launch: one per CU)
     for q in range(1, 7):            # unused stamp slots (fewer than 3 tiles) -> carry forward

@@ -36,6 +36,7 @@ SIGNATURES = {
     'mvf_gemm_fp8': 'ipippipppippipipiiiip',
     'mvf_gemm_tc_select': 'i',
     'mvf_gemm_tc_debug_stamps': 'p',
+    'mvf_gemm_tc_debug_rowmask': 'i',
     'mvf_gemm_tc_set_cus': 'i',
     'mvf_debug_xcc_map': 'piiip',
     'mvf_patchify': 'ippiiiip',

@@ -29,6 +29,7 @@ int g_variant = 0;
 // turns it on (tools/gemm_bench.py --variant 0).
 bool g_tail_split = getenv("MVF_GEMM_TAIL_SPLIT") != nullptr;
 unsigned long long* g_dbg = nullptr;
+unsigned g_dbg_rowmask = 0x7fffffffu;
 
 constexpr int BM = 128, BN = 128, ROWB = 128;
 constexpr int TILE_BYTES = BM * ROWB;          // 16 KiB per operand per stage
@@ -234,7 +235,7 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
   GemmTcArgs a;
   a.A = (const char*)A; a.W = (const char*)W; a.bias = bias; a.C = (char*)C; a.resid = resid; a.tap = (char*)tap;
   a.pos = pos; a.ls = ls; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.ldt = ldt; a.M = M; a.N = N; a.K = K; a.tpf = tpf;
-  a.dbg = g_dbg;
+  a.dbg = g_dbg; a.dbg_rowmask = g_dbg_rowmask;
   a.sched = nullptr;   // set by the persistent gemm_tc256 launch
   a.batch_rows = batch_rows; a.w_batch_rows = w_batch_rows;
   a.row0 = 0;
@@ -310,7 +311,7 @@ int mvf_gemm_fp8_impl(int epi, const void* A, int lda, const unsigned* sa, const
   GemmTcArgs a;
   a.A = (const char*)A; a.W = (const char*)W; a.bias = bias; a.C = (char*)C; a.resid = resid; a.tap = (char*)tap;
   a.pos = nullptr; a.ls = ls; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.ldt = ldt; a.M = M; a.N = N; a.K = K; a.tpf = tpf;
-  a.dbg = nullptr; a.sched = nullptr; a.batch_rows = 0; a.w_batch_rows = 0; a.row0 = 0;
+  a.dbg = nullptr; a.dbg_rowmask = 0x7fffffffu; a.sched = nullptr; a.batch_rows = 0; a.w_batch_rows = 0; a.row0 = 0;
   a.xb = nullptr; a.ldxb = 0; a.stats = nullptr; a.ln_mr = nullptr; a.ln_c = nullptr;
   a.sa = sa; a.sw = sw; a.csc = c_scales; a.radd = resid;
   return mvf_gemm_tc256_launch(epi, a, /*persistent=*/true, st);
@@ -321,6 +322,11 @@ int mvf_gemm_fp8_impl(int epi, const void* A, int lda, const unsigned* sa, const
 // diagnostic: stamps buffer [blocks][2][8] u64 for the gemm_tc256 DBG build (null = product kernels)
 extern "C" int mvf_gemm_tc_debug_stamps(unsigned long long* buf) {
   g_dbg = buf;
+  return MVF_OK;
+}
+// diagnostic (stamped build only): A rows are read as row & mask -- A's footprint shrinks to mask + 1 rows (L2-resident)
+extern "C" int mvf_gemm_tc_debug_rowmask(unsigned mask) {
+  g_dbg_rowmask = mask;
   return MVF_OK;
 }
 

@@ -193,7 +193,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
         const int r = (i * 8 + wave) * 8 + prow;                 // row inside the half-tile, 0..127
         const int am = (r >> 6) * 128 + h * 64 + (r & 63);       // A: wave row r>>6, m-quadrant h
         const int wn = (r >> 5) * 64 + h * 32 + (r & 31);        // W: wave column r>>5, n-quadrant h
-        const int gm = min(tm0 + am, a.M - 1);
+        int gm = min(tm0 + am, a.M - 1);
+        if constexpr (DBG) gm &= (int)a.dbg_rowmask;
         const int gn = wb0 + min(tn0 + wn, a.N - 1);
         // 24-bit multiply (rows and row bytes < 2^24, checked by the launch): one v_mad_u32_u24 -- a full 32-bit
         // product goes through v_mad_u64_u32, whose don't-care high addend register hipcc shares with the ticket's

@@ -22,6 +22,7 @@ struct GemmTcArgs {
   int M, N, K;
   int tpf;  // tokens per frame (1 + patches)
   unsigned long long* dbg;  // diagnostic stamps (gemm_tc256 DBG build only), normally null
+  unsigned dbg_rowmask;     // DBG build only: A row index &= mask (shrinks A's footprint to measure the L2-resident feed rate)
   unsigned* sched;          // gemm_tc256 persistent launch: 16 zeroed counters of this launch's tile scheduler (or null)
   // gemm_tc256 only: A / C rows are `batch_rows`-row batches stacked along M (a multiple of 256), batch b multiplying rows
   // [b * w_batch_rows, b * w_batch_rows + N) of W (split-K weight gradients); batch_rows == 0: one plain GEMM

@@ -357,13 +357,17 @@ __global__ __launch_bounds__(256) void lstp_dx_kernel(DxArgs a) {
     const int n = i / c4n, c = (i - n * c4n) * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j = 0; j < a.nq; ++j) {
-      const float wv = a.w[((size_t)f * a.nq + j) * a.N + n];
-      const float dv = a.ds[((size_t)f * a.nq + j) * a.N + n];
-      const float4 dp = *reinterpret_cast<const float4*>(a.dpooled + (((size_t)b * a.nq + j) * a.T + t) * C + c);
-      const float4 vq = *reinterpret_cast<const float4*>(
-          a.vec + (a.per_frame ? (((size_t)b * a.nq + j) * a.T + t) * C : (size_t)j * C) + c);
-      acc.x += wv * dp.x + dv * vq.x; acc.y += wv * dp.y + dv * vq.y;
-      acc.z += wv * dp.z + dv * vq.z; acc.w += wv * dp.w + dv * vq.w;
+      if (a.dpooled != nullptr) {     // value side (uniform branches: either term may be absent)
+        const float wv = a.w[((size_t)f * a.nq + j) * a.N + n];
+        const float4 dp = *reinterpret_cast<const float4*>(a.dpooled + (((size_t)b * a.nq + j) * a.T + t) * C + c);
+        acc.x += wv * dp.x; acc.y += wv * dp.y; acc.z += wv * dp.z; acc.w += wv * dp.w;
+      }
+      if (a.ds != nullptr) {          // score side
+        const float dv = a.ds[((size_t)f * a.nq + j) * a.N + n];
+        const float4 vq = *reinterpret_cast<const float4*>(
+            a.vec + (a.per_frame ? (((size_t)b * a.nq + j) * a.T + t) * C : (size_t)j * C) + c);
+        acc.x += dv * vq.x; acc.y += dv * vq.y; acc.z += dv * vq.z; acc.w += dv * vq.w;
+      }
     }
     const int tap = c / a.D, cc = c - tap * a.D;
     *reinterpret_cast<float4*>(a.dx[tap] + ((size_t)f * a.N + n) * a.D + cc) = acc;
@@ -385,7 +389,7 @@ extern "C" int mvf_token_pool(const void* const* taps, int n_taps, int dtype, in
 
 extern "C" int mvf_lstp_dx(float* const* dx_host, int n_taps, int D, int F, int N, int T, int nq, const float* w,
                            const float* ds, const float* dpooled, const float* vec, int per_frame, hipStream_t st) {
-  MVF_CHECK_ARG(dx_host && w && ds && dpooled && vec && n_taps > 0 && n_taps <= MAXTAPS && D > 0 && D % 4 == 0 && F > 0 &&
+  MVF_CHECK_ARG(dx_host && ((w && dpooled) || (ds && vec)) && (!dpooled || w) && (!ds || vec) && n_taps > 0 && n_taps <= MAXTAPS && D > 0 && D % 4 == 0 && F > 0 &&
                 N > 0 && T > 0 && F % T == 0 && nq > 0 && nq <= MAXQ);
   DxArgs a{};
   for (int i = 0; i < n_taps; ++i) {

@@ -72,12 +72,13 @@ class LSTPCrossAtt(nn.Module):
         self.attn_holder = nn.Identity()
         self.attn_matrix = None
 
-    def query_vectors(self, dyn_in, n_clips, n_frames):
-        """wq = q W_K: [nq, C] for static-only queries, else [Bc, nq, T, C] (one query set per frame)."""
+    def query_vectors(self, dyn_in, n_clips, n_frames, project=True):
+        """wq = q W_K: [nq, C] for static-only queries, else [Bc, nq, T, C] (one query set per frame); project=False: the
+        queries themselves ([nq, d] / [Bc, nq, T, d])."""
         wk = self.linear_K2d.weight
         qs = (self.Q_s + self.Q_s_b)[0] if self.stat else None            # [nst, d]
         if not self.dyn:
-            return ops.matmul(qs, wk)
+            return ops.matmul(qs, wk) if project else qs
         assert dyn_in is not None
         d = dyn_in.view(n_clips, n_frames, -1)
         if self.dyn_ctrl == 'first':
@@ -89,6 +90,8 @@ class LSTPCrossAtt(nn.Module):
         if self.stat:
             qd = torch.cat([qs.view(1, 1, self.num_s, self.d_model).expand(n_clips, n_frames, -1, -1), qd], 2)
         q = qd.permute(0, 2, 1, 3).reshape(-1, self.d_model)                # rows (clip, query, frame)
+        if not project:
+            return q.view(n_clips, -1, n_frames, self.d_model)
         return ops.matmul(q, wk).view(n_clips, -1, n_frames, wk.shape[1])
 
     def forward(self, taps, dyn_in=None):
@@ -99,11 +102,13 @@ class LSTPCrossAtt(nn.Module):
         if self.ln_keys:
             # SMART_LN_KEYS (mvformer.py:399-400): scores against F.normalize(K).  The normalisation depends on the token,
             # so the keys ARE projected here (one [F*N, C] x [C, d] GEMM on an fp32 copy of the taps) -- the ablation's cost
-            if self.dyn:
-                raise NotImplementedError('SMART_LN_KEYS with dynamic (per-frame) queries is not built')
             xcat = torch.cat([t.float() for t in taps.tensors], 1)
             kn = ops.l2_normalize(ops.linear(xcat, self.linear_K2d.weight, self.linear_K2d.bias))
-            scores = ops.linear(kn, (self.Q_s + self.Q_s_b)[0], None)              # [F*N, nq]
+            q = self.query_vectors(dyn_in, taps.n_clips, taps.n_frames, project=False)
+            if self.dyn:       # one query set per frame (mvformer.py:365-396): scores[f, n, j] = kn[f, n] . q[f, j]
+                scores = ops.frame_scores(kn, q, F, taps.n_tokens, taps.n_frames, nq)
+            else:
+                scores = ops.linear(kn, q, None)                                   # [F*N, nq]
             pooled, rowsum = ops.lstp_pool_from_scores(scores, taps.tensors, F, taps.n_tokens, taps.n_frames, nq,
                                                        self.d_model, disjoint=self.disjoint_att, holder=holder)
         else:

@@ -990,11 +990,42 @@ class _LSTPPoolScores(torch.autograd.Function):
                 raise _lib.MvfError('token gradients need fp32 taps (trainable backbone blocks run in fp32)')
             dtaps = tuple(torch.empty_like(t) for t in taps)
             arr = (ctypes.c_void_p * len(taps))(*[t.data_ptr() for t in dtaps])
-            zero = torch.zeros_like(dS)
-            dummy = torch.zeros(nq, C, device=dev, dtype=torch.float32)
-            call('mvf_lstp_dx', arr, len(taps), D, F, N, T, nq, ptr(Pm if Pm is not None else P), ptr(zero), ptr(dpooled),
-                 ptr(dummy), 0, stream())
+            call('mvf_lstp_dx', arr, len(taps), D, F, N, T, nq, ptr(Pm if Pm is not None else P), None, ptr(dpooled), None, 0,
+                 stream())
         return (dscores, None, None, None, None, None, None, None, None) + dtaps
+
+
+class _FrameScores(torch.autograd.Function):
+    """scores[f*N + n, j] = k[f*N + n, :] . q[b, j, t, :]  (f = b*T + t): per-frame queries against explicit keys
+    (SMART_LN_KEYS with dynamic queries, mvformer.py:365-400).  The pooling kernels with the keys as the only "tap":
+    mvf_lstp_scores forward, mvf_lstp_wsum for dq and mvf_lstp_dx for dk."""
+
+    @staticmethod
+    def forward(ctx, k, q, F, N, T, nq):
+        k, q = k.contiguous(), q.contiguous()
+        d = k.shape[1]
+        scores = torch.empty(F * N, nq, device=k.device, dtype=torch.float32)
+        call('mvf_lstp_scores', _tap_table((k,)), 1, F32, d, F, N, T, nq, ptr(q), 1, ptr(scores), stream())
+        ctx.save_for_backward(k, q)
+        ctx.cfg = (F, N, T, nq, d)
+        return scores
+
+    @staticmethod
+    def backward(ctx, dscores):
+        k, q = ctx.saved_tensors
+        F, N, T, nq, d = ctx.cfg
+        dS = dscores.view(F, N, nq).transpose(1, 2).contiguous()           # the pooling kernels' [F, nq, N] layout
+        dq = torch.empty(F // T, nq, T, d, device=k.device, dtype=torch.float32)
+        call('mvf_lstp_wsum', _tap_table((k,)), 1, F32, d, F, N, T, nq, ptr(dS), ptr(dq), stream())
+        dk = torch.empty_like(k)
+        arr = (ctypes.c_void_p * 1)(dk.data_ptr())
+        call('mvf_lstp_dx', arr, 1, d, F, N, T, nq, None, ptr(dS), None, ptr(q), 1, stream())     # score side only
+        return dk, dq, None, None, None, None
+
+
+def frame_scores(k, q, F, N, T, nq):
+    """k [F*N, d] fp32 keys, q [Bc, nq, T, d] per-frame queries -> raw scores [F*N, nq]."""
+    return _FrameScores.apply(k, q, F, N, T, nq)
 
 
 def lstp_pool_from_scores(scores, taps, F, N, T, nq, d_model, disjoint=False, holder=None):

@@ -144,7 +144,7 @@ int mvf_gemm_tc_set_cus(int n);
 /* diagnostic build of the 256x256 kernel: per-block s_memtime stamps into buf[blocks][2][8] (NULL = off, the default) */
 int mvf_gemm_tc_debug_stamps(unsigned long long* buf);
 /* diagnostic, stamped build only: A rows are read as (row & mask), so A's footprint is mask + 1 rows (L2-resident feed rate) */
-int mvf_gemm_tc_debug_rowmask(unsigned mask);
+int mvf_gemm_tc_debug_rowmask(int mask);
 int mvf_patchify(int dtype, const float* frames, void* out, int F, int H, int W, int P, hipStream_t stream);
 int mvf_layernorm_fwd(int out_dtype, const float* x, size_t in_stride, const float* g, const float* b, void* y,
                       size_t out_stride, int rows, int D, float eps, hipStream_t stream);

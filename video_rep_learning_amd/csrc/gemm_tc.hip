@@ -325,8 +325,8 @@ extern "C" int mvf_gemm_tc_debug_stamps(unsigned long long* buf) {
   return MVF_OK;
 }
 // diagnostic (stamped build only): A rows are read as row & mask -- A's footprint shrinks to mask + 1 rows (L2-resident)
-extern "C" int mvf_gemm_tc_debug_rowmask(unsigned mask) {
-  g_dbg_rowmask = mask;
+extern "C" int mvf_gemm_tc_debug_rowmask(int mask) {
+  g_dbg_rowmask = (unsigned)mask;
   return MVF_OK;
 }
 

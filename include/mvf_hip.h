@@ -145,6 +145,12 @@ int mvf_gemm_tc_set_cus(int n);
 int mvf_gemm_tc_debug_stamps(unsigned long long* buf);
 /* diagnostic, stamped build only: A rows are read as (row & mask), so A's footprint is mask + 1 rows (L2-resident feed rate) */
 int mvf_gemm_tc_debug_rowmask(int mask);
+/* diagnostic, stamped build only: kt >= 0 also stamps every workgroup barrier of K tile kt of each workgroup's second tile
+ * (the stamps buffer then holds [blocks][2][8] + [blocks][2][16] entries) */
+int mvf_gemm_tc_debug_ktile(int kt);
+/* diagnostic, stamped build only: timing ablations (results are garbage): bit 0 no MFMAs, bit 1 no LDS fragment reads, bit 2 no
+ * operand DMAs */
+int mvf_gemm_tc_debug_ablate(int bits);
 int mvf_patchify(int dtype, const float* frames, void* out, int F, int H, int W, int P, hipStream_t stream);
 int mvf_layernorm_fwd(int out_dtype, const float* x, size_t in_stride, const float* g, const float* b, void* y,
                       size_t out_stride, int rows, int D, float eps, hipStream_t stream);

@@ -31,6 +31,9 @@ def main():
     # what happens to the A operand right before every timed launch: nothing (A was evicted by the previous launch's output),
     # a kernel READING it, or a kernel WRITING it (the real pipeline: the producer ran just before) -- is A cache-resident?
     p.add_argument('--pre', default='none', choices=['none', 'read', 'write'])
+    # all-zero operands: the matrix pipe toggles no bits, the chip holds a higher clock -- how much of the gap to the nominal peak
+    # is the clock under load rather than the schedule?
+    p.add_argument('--zeros', action='store_true')
     a = p.parse_args()
     dev = 'cuda'
     M = a.frames * 197
@@ -40,6 +43,9 @@ def main():
         n, k, epi = SHAPES[name]
         A = torch.randn(M, k, device=dev).to(torch.bfloat16)
         W = (torch.randn(n, k, device=dev) * 0.02).to(torch.bfloat16)
+        if a.zeros:
+            A.zero_()
+            W.zero_()
         b = torch.randn(n, device=dev)
         C = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
         R = torch.zeros(M, n, device=dev)

@@ -21,7 +21,8 @@ def main():
     C = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
     nblk = ((M + 255) // 256) * ((n + 255) // 256)
     ntile = nblk
-    buf = torch.zeros(nblk * 2 * 8, device=dev, dtype=torch.int64)
+    buf = torch.zeros(nblk * 48, device=dev, dtype=torch.int64)
+    kt = int(os.environ.get('KT', '-1'))     # KT=5: also stamp every workgroup barrier of K tile 5 (second tile of each workgroup)
 
     def fn():
         _lib.call('mvf_gemm_tc', _lib.BF16, 0, A.data_ptr(), k, W.data_ptr(), k, b.data_ptr(), C.data_ptr(), n,
@@ -29,6 +30,9 @@ def main():
     for _ in range(3):
         fn()
     _lib.call('mvf_gemm_tc_debug_stamps', buf.data_ptr())
+    _lib.call('mvf_gemm_tc_debug_ktile', kt)
+    # ABL: timing ablations of the stamped build (bit 0 no MFMAs, bit 1 no LDS fragment reads, bit 2 no operand DMAs)
+    _lib.call('mvf_gemm_tc_debug_ablate', int(os.environ.get('ABL', '0')))
     # ROWMASK=2047: A rows read as row & 2047 -> A footprint 2048 rows (L2-resident): the K loop's feed rate without misses
     _lib.call('mvf_gemm_tc_debug_rowmask', int(os.environ.get('ROWMASK', str(0x7fffffff))))
     _lib.call('mvf_gemm_tc_select', int(os.environ.get('VARIANT', '2')))
@@ -37,8 +41,21 @@ def main():
     _lib.call('mvf_gemm_tc_select', 0)
     torch.cuda.synchronize()
     _lib.call('mvf_gemm_tc_debug_stamps', None)
+    _lib.call('mvf_gemm_tc_debug_ktile', -1)
+    _lib.call('mvf_gemm_tc_debug_ablate', 0)
     _lib.call('mvf_gemm_tc_debug_rowmask', 0x7fffffff)
-    s = buf.cpu().numpy().reshape(nblk, 2, 8).astype(np.int64)
+    raw = buf.cpu().numpy().astype(np.int64)
+    nwg = int(os.environ.get('NWG', '256')) if int(os.environ.get('VARIANT', '2')) != 3 else nblk
+    s = raw[:nblk * 16].reshape(nblk, 2, 8)
+    if kt >= 0:
+        k2 = raw[nwg * 16:nwg * 48].reshape(nwg, 2, 16)
+        k2 = k2[k2[:, 0, 0] != 0]
+        n_st = int((k2[0, 0] != 0).sum())
+        d2 = np.diff(k2[:, :, :n_st], axis=2)
+        print('K tile %d, barrier-to-barrier ticks (median over %d workgroups; P0 load|mfma, P1 .., P2 .., P3 ..):' % (kt, k2.shape[0]))
+        for wrow in (0, 1):
+            print('  wave row %d: %s   sum %d' % (wrow, ' '.join('%5d' % v for v in np.median(d2[:, wrow], axis=0)),
+                                                 np.median(d2[:, wrow].sum(axis=1))))
     s = s[s[:, 0, 7] != 0]          # workgroups that ran (persistent launch: one per CU)
     for q in range(1, 7):            # unused stamp slots (fewer than 3 tiles) -> carry forward
         s[:, :, q] = np.where(s[:, :, q] == 0, s[:, :, q - 1], s[:, :, q])

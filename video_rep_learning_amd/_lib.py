@@ -37,6 +37,8 @@ SIGNATURES = {
     'mvf_gemm_tc_select': 'i',
     'mvf_gemm_tc_debug_stamps': 'p',
     'mvf_gemm_tc_debug_rowmask': 'i',
+    'mvf_gemm_tc_debug_ktile': 'i',
+    'mvf_gemm_tc_debug_ablate': 'i',
     'mvf_gemm_tc_set_cus': 'i',
     'mvf_debug_xcc_map': 'piiip',
     'mvf_patchify': 'ippiiiip',

@@ -30,6 +30,8 @@ int g_variant = 0;
 bool g_tail_split = getenv("MVF_GEMM_TAIL_SPLIT") != nullptr;
 unsigned long long* g_dbg = nullptr;
 unsigned g_dbg_rowmask = 0x7fffffffu;
+int g_dbg_kt = -1;
+int g_dbg_abl = 0;
 
 constexpr int BM = 128, BN = 128, ROWB = 128;
 constexpr int TILE_BYTES = BM * ROWB;          // 16 KiB per operand per stage
@@ -235,7 +237,7 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
   GemmTcArgs a;
   a.A = (const char*)A; a.W = (const char*)W; a.bias = bias; a.C = (char*)C; a.resid = resid; a.tap = (char*)tap;
   a.pos = pos; a.ls = ls; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.ldt = ldt; a.M = M; a.N = N; a.K = K; a.tpf = tpf;
-  a.dbg = g_dbg; a.dbg_rowmask = g_dbg_rowmask;
+  a.dbg = g_dbg; a.dbg_rowmask = g_dbg_rowmask; a.dbg_kt = g_dbg_kt; a.dbg_abl = g_dbg_abl;
   a.sched = nullptr;   // set by the persistent gemm_tc256 launch
   a.batch_rows = batch_rows; a.w_batch_rows = w_batch_rows;
   a.row0 = 0;
@@ -311,7 +313,7 @@ int mvf_gemm_fp8_impl(int epi, const void* A, int lda, const unsigned* sa, const
   GemmTcArgs a;
   a.A = (const char*)A; a.W = (const char*)W; a.bias = bias; a.C = (char*)C; a.resid = resid; a.tap = (char*)tap;
   a.pos = nullptr; a.ls = ls; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.ldt = ldt; a.M = M; a.N = N; a.K = K; a.tpf = tpf;
-  a.dbg = nullptr; a.dbg_rowmask = 0x7fffffffu; a.sched = nullptr; a.batch_rows = 0; a.w_batch_rows = 0; a.row0 = 0;
+  a.dbg = nullptr; a.dbg_rowmask = 0x7fffffffu; a.dbg_kt = -1; a.dbg_abl = 0; a.sched = nullptr; a.batch_rows = 0; a.w_batch_rows = 0; a.row0 = 0;
   a.xb = nullptr; a.ldxb = 0; a.stats = nullptr; a.ln_mr = nullptr; a.ln_c = nullptr;
   a.sa = sa; a.sw = sw; a.csc = c_scales; a.radd = resid;
   return mvf_gemm_tc256_launch(epi, a, /*persistent=*/true, st);
@@ -325,6 +327,18 @@ extern "C" int mvf_gemm_tc_debug_stamps(unsigned long long* buf) {
   return MVF_OK;
 }
 // diagnostic (stamped build only): A rows are read as row & mask -- A's footprint shrinks to mask + 1 rows (L2-resident)
+// diagnostic (stamped build only): kt >= 0 also stamps every workgroup barrier of K tile kt in each workgroup's second tile;
+// the stamps buffer then needs [blocks][2][8] + [blocks][2][16] entries (blocks = workgroups launched)
+extern "C" int mvf_gemm_tc_debug_ktile(int kt) {
+  g_dbg_kt = kt;
+  return MVF_OK;
+}
+// diagnostic (stamped build only), timing ablations whose results are garbage: bit 0 no MFMAs, bit 1 no LDS fragment reads,
+// bit 2 no operand DMAs -- what is left of the K loop's time when one of its three streams is removed
+extern "C" int mvf_gemm_tc_debug_ablate(int bits) {
+  g_dbg_abl = bits;
+  return MVF_OK;
+}
 extern "C" int mvf_gemm_tc_debug_rowmask(int mask) {
   g_dbg_rowmask = (unsigned)mask;
   return MVF_OK;

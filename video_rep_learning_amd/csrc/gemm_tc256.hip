@@ -50,6 +50,9 @@
 //    their epilogues' residual traffic does not arrive as one chip-wide burst -- 104 -> 104..112 us, 11.6 -> 11.9 ms/step.
 //  * tried and rejected (PMC): rotating the K loop per A row-panel to shorten W's L2 re-use distance -- the L2 hits come
 //    from workgroups reading the SAME slices at the SAME time; rotation cut the hit rate from 74 % to 47 % (fc2).
+//  * tried and rejected (round 2): waiting for every half-tile as late as legal (counted vmcnt(10) in P0 / P1 / P3: five
+//    half-tiles in flight instead of three; MVF_GEMM_DEEP) -- K loop 36.5 k -> 37.9 k ticks; the loop is not feed-bound
+//    (timing ablations: DESIGN.md section 4, tools/gemm_stamps.py ABL=...).
 //  * XCD-aware tile walk: workgroups b, b+8, ... share an XCD (round-robin dispatch, speed only); group x = b & 7 owns a
 //    contiguous chunk of the tile list (tiles of one A row-panel are neighbours).  A workgroup's FIRST tile is static
 //    (chunk start + b/8); every further tile is a ticket from the group's counter (a.sched, agent-scope atomic), so a
@@ -84,6 +87,9 @@ constexpr int SC_OFF = LNMR_OFF + 2 * 2048;     // fp8: two K tiles' scales, [bu
 constexpr int LDS_BYTES = SC_OFF + 2 * 2048;    // 140 KiB -> one workgroup per CU
 constexpr int OFF_A0 = 0, OFF_A1 = HALF_BYTES, OFF_B0 = 2 * HALF_BYTES, OFF_B1 = 3 * HALF_BYTES;
 
+#ifndef MVF_GEMM_DEEP
+#define MVF_GEMM_DEEP 0
+#endif
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -92,6 +98,12 @@ constexpr int OFF_A0 = 0, OFF_A1 = HALF_BYTES, OFF_B0 = 2 * HALF_BYTES, OFF_B1 =
     SCHED_FENCE();                \
     __builtin_amdgcn_s_barrier(); \
     SCHED_FENCE();                \
+  } while (0)
+
+// the second barrier of a phase; ablation bit 4 of the stamped build drops it (what do the barriers cost beside the MFMAs?)
+#define WG_BARRIER_E()                        \
+  do {                                        \
+    if constexpr ((ABL & 16) == 0) WG_BARRIER(); \
   } while (0)
 
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
@@ -117,7 +129,7 @@ __device__ __forceinline__ void mfma_mx(f32x4_t& acc, const i32x8_t& w, const i3
 // times the k: the same matrix-pipe time per K tile for TWICE the FLOPs, from the same bytes (a K tile is 128-byte rows either
 // way, so staging, swizzle and hazards are unchanged).  The K tile's scales (256 + 256 dwords) travel by one more LDS-DMA per
 // wave, issued with A1 (same distance to its consumer, so the counted vmcnt(6) still leaves exactly three half-tiles in flight).
-template <int EPI, bool DBG, bool LN, bool FP8>
+template <int EPI, bool DBG, bool LN, bool FP8, int ABL = 0>   // ABL: timing ablations of the stamped build (dbg_abl)
 __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -125,7 +137,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   unsigned long long stamps[8];
-  int nstamp = 0;
+  unsigned long long kst[16];   // DBG: barrier-by-barrier stamps of ONE K tile (a.dbg_kt) of the workgroup's second tile
+  int nstamp = 0, nk_st = 0, tiles_done = 0;
+#define KSTAMP()                                                                             \
+  if constexpr (DBG && (ABL & 8) != 0) {                                                     \
+    if (t == a.dbg_kt && tiles_done == 1 && nk_st < 16) {                   \
+      unsigned long long t_;                                                                 \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+      kst[nk_st++] = t_;                                                                     \
+    }                                                                                        \
+  }
 #define STAMP()                                                                              \
   if constexpr (DBG) {                                                                       \
     if (nstamp < 7) {                                                                        \
@@ -205,6 +226,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   set_sources(lid);
   const int piece0 = wave * 1024, piece1 = (8 + wave) * 1024;
   auto stage = [&](int buf, int off, const char* gbase, const unsigned (&src)[2], int kt) {
+    if constexpr ((ABL & 4) != 0) return;      // ablation: no operand DMAs
     char* dst = smem + buf * BUF_BYTES + off;
     const unsigned koff = (unsigned)kt * ROWB;
     __builtin_amdgcn_global_load_lds(GLB_PTR(gbase + (size_t)(src[0] + koff)), LDS_PTR(dst + piece0), 16, 0, 0);
@@ -269,7 +291,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   WG_BARRIER();
   STAMP();
 
-  bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
+  bf16x8_t af[4][2] = {}, bf0[2][2] = {}, bf1[2][2] = {};
+  // DEEP: every half-tile is waited for right before the barrier in front of its first read, with a counted vmcnt that leaves the
+  // five younger half-tiles in flight (80 KiB per workgroup), instead of one vmcnt(6) per K tile that makes A1 land within three
+  // phases of its issue.  The issue schedule is unchanged (it always ran this far ahead).  fp8: its scale DMA rides with A1 and
+  // is read one K tile earlier than A1 itself, so it keeps the single wait.
+  constexpr bool DEEP = !FP8 && MVF_GEMM_DEEP;
   // fp8: a fragment is ONE 32-byte operand (8 consecutive registers), filled by two 16-byte LDS reads into its halves
   i32x8_t afq[4], bq0[2], bq1[2];
   unsigned sfa[4], sf0[2], sf1[2];   // fp8: the E8M0 scale of each fragment's 32-k block, in byte 0
@@ -293,6 +320,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
       sfa[i] = *reinterpret_cast<const unsigned*>(sa_rd + sbuf_off + (((OFF) == OFF_A1 ? 64 : 0) + i * 16) * 4);  \
   }
 #define LOAD_A(OFF)                                                                                          \
+  if constexpr ((ABL & 2) == 0)                                                                              \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \
     if constexpr (FP8) {                                                                                     \
       afq[i].lo = *reinterpret_cast<const i32x4_t*>(base + (OFF) + a_rd + i * 16 * ROWB);                    \
@@ -303,6 +331,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     }                                                                                                        \
   }
 #define LOAD_B(BF, BQ, SF, OFF)                                                                              \
+  if constexpr ((ABL & 2) == 0)                                                                              \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                             \
     if constexpr (FP8) {                                                                                     \
       BQ[j].lo = *reinterpret_cast<const i32x4_t*>(base + (OFF) + b_rd + j * 16 * ROWB);                     \
@@ -322,7 +351,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   }
 #define MFMA_QUAD(MQ, NQ, BF, BQ, SF)                                                                        \
   __builtin_amdgcn_s_setprio(1);                                                                             \
-  if constexpr (FP8) {                                                                                       \
+  if constexpr ((ABL & 1) != 0) {                                                                            \
+  } else if constexpr (FP8) {                                                                                       \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
       mfma_mx(acc[(MQ) * 4 + i][(NQ) * 2 + j], BQ[j], afq[i], SF[j], sfa[i]);                                \
@@ -343,6 +373,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     const char* base = smem + (BUF) * BUF_BYTES;                                                             \
     constexpr int sbuf_off = (BUF) * 2048;                                                                   \
     const int t = (T);                                                                                       \
+    KSTAMP();                                                                                                \
     /* P0 */                                                                                                 \
     LOAD_B(bf0, bq0, sf0, OFF_B0);                                                                                \
     LOAD_A_SCALES(OFF_A0);                                                                                   \
@@ -353,8 +384,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
       stage_scales((BUF) ^ 1, t + 1 + kwrap);                                                                \
     }                                                                                                        \
     SCHED_FENCE();                                                                                           \
+    if constexpr (DEEP) { /* B1 of this K tile (read next phase): the five younger half-tiles stay in flight */\
+      if (CAN_ISSUE(1)) { WAIT_VMCNT(10); } else { WAIT_VMCNT(0); }                                          \
+    }                                                                                                        \
     WAIT_LGKM(8); /* everything in front of the eight A reads is back: the B reads (and the fp8 scales) */   \
     WG_BARRIER();                                                                                            \
+    KSTAMP();                                                                                                \
     unsigned tkv = 0;                                                                                        \
     if (dyn && t == 1) tkv = *(volatile __attribute__((address_space(3))) unsigned*)LDS_PTR(smem + SLOT_OFF); \
     WAIT_LGKM(0);                                                                                            \
@@ -365,42 +400,52 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     SCALE_FIX(sf0, 2);                                                                                       \
     SCALE_FIX(sfa, 4);                                                                                       \
     SCHED_FENCE();                                                                                           \
-    MFMA_QUAD(0, 0, bf0, bq0, sf0);                                                                               \
-    WG_BARRIER();                                                                                            \
+    MFMA_QUAD(0, 0, bf0, bq0, sf0);                                                                          \
+    WG_BARRIER_E();                                                                                          \
+    KSTAMP();                                                                                                \
     if ((BUF) == 0 && t == nk - 2 && have_next) { /* from here on the NEXT output tile is staged */          \
       set_sources(lid_next);                                                                                 \
       kwrap = -nk;                                                                                           \
     }                                                                                                        \
     /* P1 */                                                                                                 \
     LOAD_B(bf1, bq1, sf1, OFF_B1);                                                                                \
-    if (CAN_ISSUE(2)) stage((BUF), OFF_B0, a.W, wsrc[0], t + 2 + kwrap);                                          \
+    if (CAN_ISSUE(2)) stage((BUF), OFF_B0, a.W, wsrc[0], t + 2 + kwrap);                                     \
+    if constexpr (DEEP) { /* A1 of this K tile (read next phase) */                                          \
+      if (CAN_ISSUE(2)) { WAIT_VMCNT(10); } else { WAIT_VMCNT(0); }                                          \
+    }                                                                                                        \
     WG_BARRIER();                                                                                            \
+    KSTAMP();                                                                                                \
     WAIT_LGKM(0);                                                                                            \
     SCALE_FIX(sf1, 2);                                                                                       \
     SCHED_FENCE();                                                                                           \
-    MFMA_QUAD(0, 1, bf1, bq1, sf1);                                                                               \
-    WG_BARRIER();                                                                                            \
+    MFMA_QUAD(0, 1, bf1, bq1, sf1);                                                                          \
+    WG_BARRIER_E();                                                                                          \
+    KSTAMP();                                                                                                \
     /* P2 */                                                                                                 \
     LOAD_A_SCALES(OFF_A1);                                                                                   \
     LOAD_A(OFF_A1);                                                                                          \
     if (CAN_ISSUE(2)) stage((BUF), OFF_A0, a.A, asrc[0], t + 2 + kwrap);                                          \
     WG_BARRIER();                                                                                            \
+    KSTAMP();                                                                                                \
     WAIT_LGKM(0);                                                                                            \
     SCALE_FIX(sfa, 4);                                                                                       \
     SCHED_FENCE();                                                                                           \
     MFMA_QUAD(1, 1, bf1, bq1, sf1);                                                                               \
-    WG_BARRIER();                                                                                            \
+    WG_BARRIER_E();                                                                                          \
+    KSTAMP();                                                                                                \
     /* P3 */                                                                                                 \
     if (CAN_ISSUE(2)) {                                                                                      \
       stage((BUF), OFF_B1, a.W, wsrc[1], t + 2 + kwrap);                                                          \
-      WAIT_VMCNT(6);                                                                                         \
+      if constexpr (DEEP) { WAIT_VMCNT(10); } else { WAIT_VMCNT(6); }  /* DEEP: B0, A0 of the next K tile */ \
     } else {                                                                                                 \
       WAIT_VMCNT(0);                                                                                         \
     }                                                                                                        \
     if (dyn && (BUF) == 0 && t == nk - 2 && have_next) fetch_ticket(); /* tile after next, see epilogue */   \
     WG_BARRIER();                                                                                            \
-    MFMA_QUAD(1, 0, bf0, bq0, sf0);                                                                               \
-    WG_BARRIER();                                                                                            \
+    KSTAMP();                                                                                                \
+    MFMA_QUAD(1, 0, bf0, bq0, sf0);                                                                          \
+    WG_BARRIER_E();                                                                                          \
+    KSTAMP();                                                                                                \
   }
 
   for (;;) {
@@ -415,6 +460,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
       K_TILE(1, kt + 1);
     }
     if (wr == 0) WG_BARRIER();  // re-align the wave rows: both run the epilogue in the same interval
+    if constexpr (DBG) ++tiles_done;
     if constexpr (FP8) asm volatile("s_nop 15\n\ts_nop 3");   // last asm MFMA's result -> first VALU read (16-pass: 18 states)
     STAMP();
 
@@ -576,10 +622,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
       SCHED_FENCE();
       stamps[7] = t_;
     }
-    if (a.dbg != nullptr && lane == 0 && (wave == 0 || wave == 4))
+    if (a.dbg != nullptr && lane == 0 && (wave == 0 || wave == 4)) {
       for (int q = 0; q < 8; ++q) a.dbg[((size_t)blockIdx.x * 2 + (wave >> 2)) * 8 + q] = stamps[q];
+      if constexpr ((ABL & 8) != 0) {   // second region of the buffer: [gridDim.x][2][16]
+        unsigned long long* k2 = a.dbg + (size_t)gridDim.x * 16;
+        for (int q = 0; q < 16; ++q) k2[((size_t)blockIdx.x * 2 + (wave >> 2)) * 16 + q] = q < nk_st ? kst[q] : 0ull;
+      }
+    }
   }
 #undef STAMP
+#undef KSTAMP
 }
 
 int g_cu_budget = 0;   // > 0: CUs the caller's stream may use (CU-masked streams), see mvf_gemm_tc_set_cus
@@ -610,14 +662,14 @@ unsigned* sched_slot() {
   return ring == nullptr ? nullptr : ring + (size_t)(next.fetch_add(1) & 1023u) * 16;
 }
 
-template <int EPI, bool DBG = false, bool LN = false, bool FP8 = false>
+template <int EPI, bool DBG = false, bool LN = false, bool FP8 = false, int ABL = 0>
 int launch(const GemmTcArgs& a0, bool persistent, hipStream_t st) {
   GemmTcArgs a = a0;
   static const bool force_static = getenv("MVF_GEMM_STATIC") != nullptr;   // A/B measurements only
   a.sched = persistent && !force_static ? sched_slot() : nullptr;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tc256_kernel<EPI, DBG, LN, FP8>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
@@ -625,7 +677,7 @@ int launch(const GemmTcArgs& a0, bool persistent, hipStream_t st) {
   // persistent: one workgroup per CU (a multiple of 8 so that every XCD gets the same number); otherwise (A/B
   // measurements) one workgroup per tile -- the same kernel, every workgroup then runs the cold prologue
   const int grid = persistent ? std::min(ntiles, std::max(8, num_cus() & ~7)) : ntiles;
-  hipLaunchKernelGGL((gemm_tc256_kernel<EPI, DBG, LN, FP8>), dim3(grid), dim3(512), LDS_BYTES, st, a);
+  hipLaunchKernelGGL((gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL>), dim3(grid), dim3(512), LDS_BYTES, st, a);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }
@@ -661,7 +713,23 @@ int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, bool persistent
     }
     return MVF_ERR_ARG;
   }
-  if (a.dbg != nullptr) return epi == EPI_STORE ? launch<EPI_STORE, true>(a, persistent, st) : MVF_ERR_UNSUPPORTED;
+  if (a.dbg != nullptr) {
+    if (epi != EPI_STORE) return MVF_ERR_UNSUPPORTED;
+    if (a.dbg_kt >= 0) return launch<EPI_STORE, true, false, false, 8>(a, persistent, st);   // per-barrier stamps of one K tile
+    switch (a.dbg_abl) {   // timing ablations are separate instantiations: a run-time test inside the loop changes its schedule
+      case 0: return launch<EPI_STORE, true>(a, persistent, st);
+      case 1: return launch<EPI_STORE, true, false, false, 1>(a, persistent, st);
+      case 2: return launch<EPI_STORE, true, false, false, 2>(a, persistent, st);
+      case 3: return launch<EPI_STORE, true, false, false, 3>(a, persistent, st);
+      case 4: return launch<EPI_STORE, true, false, false, 4>(a, persistent, st);
+      case 5: return launch<EPI_STORE, true, false, false, 5>(a, persistent, st);
+      case 6: return launch<EPI_STORE, true, false, false, 6>(a, persistent, st);
+      case 7: return launch<EPI_STORE, true, false, false, 7>(a, persistent, st);
+      case 22: return launch<EPI_STORE, true, false, false, 22>(a, persistent, st);   // MFMAs + every other barrier
+      case 23: return launch<EPI_STORE, true, false, false, 23>(a, persistent, st);   // every other barrier alone
+    }
+    return MVF_ERR_ARG;
+  }
   if (a.ln_mr != nullptr || a.xb != nullptr || a.stats != nullptr) {   // LN-fold extras (validated by mvf_gemm_tc_impl)
     switch (epi) {
       case EPI_STORE: return launch<EPI_STORE, false, true>(a, persistent, st);

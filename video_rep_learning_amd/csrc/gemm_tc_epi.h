@@ -22,6 +22,8 @@ struct GemmTcArgs {
   int M, N, K;
   int tpf;  // tokens per frame (1 + patches)
   unsigned long long* dbg;  // diagnostic stamps (gemm_tc256 DBG build only), normally null
+  int dbg_abl;              // DBG build only, timing ablations (results are garbage): 1 no MFMAs, 2 no LDS fragment reads, 4 no operand DMAs
+  int dbg_kt;               // DBG build only: >= 0: stamp every barrier of this K tile (second tile of each workgroup)
   unsigned dbg_rowmask;     // DBG build only: A row index &= mask (shrinks A's footprint to measure the L2-resident feed rate)
   unsigned* sched;          // gemm_tc256 persistent launch: 16 zeroed counters of this launch's tile scheduler (or null)
   // gemm_tc256 only: A / C rows are `batch_rows`-row batches stacked along M (a multiple of 256), batch b multiplying rows

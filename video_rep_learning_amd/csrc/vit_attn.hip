@@ -230,6 +230,12 @@ __global__ __launch_bounds__(256, NT < KT ? 3 : 2) void vit_attn_bf16_kernel(Att
   }
 }
 
+// v_max3_f32 / packed fp32 arithmetic (v_pk_fma_f32, v_pk_add_f32: two floats per lane and instruction at the full VALU rate),
+// written so that hipcc selects them itself: inline asm would hide the MFMA-result -> VALU-read wait states from its hazard pass
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ f32x2_t pk_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2_t pk_add(f32x2_t a, f32x2_t b) { return a + b; }
+
 // ------------------------------------------------------------------------------------------------
 // bf16, one key block, TWO query tiles per wave at a time (the ViT-B/16 @ 224 px kernel: N = 197, NT = 13)
 // ------------------------------------------------------------------------------------------------
@@ -261,21 +267,27 @@ __device__ __forceinline__ void attn_tiles(const AttnArgs& a, const char* sk, co
   for (int i = 0; i < NQ; ++i) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) s[i][NT - 1][r] = (NT - 1) * 16 + 4 * g + r < a.N ? s[i][NT - 1][r] : -1e30f;
+    // VALU issue is what this kernel runs out of (PMC: VALU + transcendental issue 55 % of SIMD cycles, MFMA 18 %): the row
+    // maximum as 3-input maxima, the exponent argument and the row sum as packed 2 x fp32 operations -- 26 + 26 + 26 VALU
+    // instructions per query tile instead of 52 + 52 + 52 (the 52 v_exp_f32 stay)
     float mx = -1e30f;
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(s[i][kt][0], s[i][kt][1])), fmaxf(s[i][kt][2], s[i][kt][3]));
+    for (int kt = 0; kt < NT; ++kt) mx = max3f(max3f(mx, s[i][kt][0], s[i][kt][1]), s[i][kt][2], s[i][kt][3]);
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float nm = -mx * a.scale_log2;
-    float ls = 0.f;
+    const f32x2_t sc2 = {a.scale_log2, a.scale_log2}, nm2 = {nm, nm};
+    f32x2_t ls2 = {0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(s[i][kt][r], a.scale_log2, nm));
-        s[i][kt][r] = p;
-        ls += p;
-      }
+    for (int kt = 0; kt < NT; ++kt) {
+      const f32x2_t e0 = pk_fma((f32x2_t){s[i][kt][0], s[i][kt][1]}, sc2, nm2);
+      const f32x2_t e1 = pk_fma((f32x2_t){s[i][kt][2], s[i][kt][3]}, sc2, nm2);
+      const f32x2_t p0 = {__builtin_amdgcn_exp2f(e0[0]), __builtin_amdgcn_exp2f(e0[1])};
+      const f32x2_t p1 = {__builtin_amdgcn_exp2f(e1[0]), __builtin_amdgcn_exp2f(e1[1])};
+      s[i][kt][0] = p0[0]; s[i][kt][1] = p0[1]; s[i][kt][2] = p1[0]; s[i][kt][3] = p1[1];
+      ls2 = pk_add(ls2, pk_add(p0, p1));
+    }
+    float ls = ls2[0] + ls2[1];
     ls += __shfl_xor(ls, 16, 64);
     ls += __shfl_xor(ls, 32, 64);
     inv[i] = 1.0f / ls;
@@ -491,22 +503,25 @@ __global__ __launch_bounds__(NW * 64, OCC) void vit_attn_bf16_flash_kernel(AttnA
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      float mx = -1e30f;
+      float mx = -1e30f;     // 3-input maxima and packed fp32 arithmetic: see attn_tiles
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(s[i][kt][0], s[i][kt][1])), fmaxf(s[i][kt][2], s[i][kt][3]));
+      for (int kt = 0; kt < KT; ++kt) mx = max3f(max3f(mx, s[i][kt][0], s[i][kt][1]), s[i][kt][2], s[i][kt][3]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[i], mx);
       const float nm = -m_new * a.scale_log2;
-      float ls = 0.f;
+      const f32x2_t sc2 = {a.scale_log2, a.scale_log2}, nm2 = {nm, nm};
+      f32x2_t ls2 = {0.f, 0.f};
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[i][kt][r], a.scale_log2, nm));
-          s[i][kt][r] = p;
-          ls += p;
-        }
+      for (int kt = 0; kt < KT; ++kt) {
+        const f32x2_t e0 = pk_fma((f32x2_t){s[i][kt][0], s[i][kt][1]}, sc2, nm2);
+        const f32x2_t e1 = pk_fma((f32x2_t){s[i][kt][2], s[i][kt][3]}, sc2, nm2);
+        const f32x2_t p0 = {__builtin_amdgcn_exp2f(e0[0]), __builtin_amdgcn_exp2f(e0[1])};
+        const f32x2_t p1 = {__builtin_amdgcn_exp2f(e1[0]), __builtin_amdgcn_exp2f(e1[1])};
+        s[i][kt][0] = p0[0]; s[i][kt][1] = p0[1]; s[i][kt][2] = p1[0]; s[i][kt][3] = p1[1];
+        ls2 = pk_add(ls2, pk_add(p0, p1));
+      }
+      float ls = ls2[0] + ls2[1];
       ls += __shfl_xor(ls, 16, 64);
       ls += __shfl_xor(ls, 32, 64);
       const float alpha = __builtin_amdgcn_exp2f((m_run[i] - m_new) * a.scale_log2);   // 0 on the first block

@@ -18,11 +18,11 @@ published algorithm:
 the product's bf16 mode stores bf16 (csrc/vit_fwd.hip, vit_attn.hip, gemm_tc_epi.h): GEMM weights, the im2col'd
 patches, qkv, the softmax probabilities fed to P.V (their row sum stays fp32), the attention output, fc1+GELU output
 and the tapped block outputs; accumulation, biases, position embedding, LayerScale and the residual stream stay fp32.
-LayerNorm is FOLDED into the GEMM that consumes it, as the product does (include/mvf_hip.h qkv_c / fc1_c) -- for every
-norm2 and for norm1 of blocks > 0:   LN(x) W^T + b  ==  rstd * (x W'^T - mean * c) + d   with W' = gamma (.) W,
+LayerNorm is FOLDED into the GEMM that consumes it where the product folds it (include/mvf_hip.h qkv_c / fc1_c; default
+MVF_LN_FOLD=2: norm1 of blocks > 0):   LN(x) W^T + b  ==  rstd * (x W'^T - mean * c) + d   with W' = gamma (.) W,
 c[n] = sum_k W'[n,k], d = b + W beta; the rounding points are then xb = bf16(x) and bf16(W') (c is summed over the
-ROUNDED W').  Block 0's norm1 (and `emulate='bf16_nofold'`, the product with MVF_LN_FOLD=0) rounds the LayerNorm output
-instead.  It is the checker for the benchmarked dtype (tests/test_gpu_*: tight gates instead of "bf16 is somewhere
+ROUNDED W').  Everywhere else (block 0's norm1, every norm2) the LayerNorm output is rounded instead.  The product's other
+settings: `emulate='bf16_fold12'` (MVF_LN_FOLD=1: norm2 folded too), `'bf16_nofold'` (MVF_LN_FOLD=0).  It is the checker for the benchmarked dtype (tests/test_gpu_*: tight gates instead of "bf16 is somewhere
 near fp32").
 
 Weights are a flat dict keyed with timm's state-dict names.  PARITY UNPINNED by
@@ -133,9 +133,9 @@ def mx_quant(t):
 def vit_block(x, w, p, heads, eps=1e-6, emulate=None):
     if emulate == 'fp8':
         return vit_block_bf16(x, w, p, heads, eps, mx=True)
-    if emulate in ('bf16', 'bf16_nofold'):
-        fold = emulate == 'bf16' and x.shape[-1] % 128 == 0
-        return vit_block_bf16(x, w, p, heads, eps, fold1=fold and p != 'blocks.0.', fold2=fold)
+    if emulate in ('bf16', 'bf16_fold12', 'bf16_nofold'):
+        fold = emulate != 'bf16_nofold' and x.shape[-1] % 128 == 0
+        return vit_block_bf16(x, w, p, heads, eps, fold1=fold and p != 'blocks.0.', fold2=fold and emulate == 'bf16_fold12')
     f, n, d = x.shape
     hd = d // heads
     h = layer_norm(x, w[p + 'norm1.weight'], w[p + 'norm1.bias'], eps)
@@ -232,7 +232,7 @@ def vit_forward(img, w, heads, patch, taps=(3, 7, 11), eps=1e-6, first_block=0, 
     """
     depth = 1 + max(int(k.split('.')[1]) for k in w if k.startswith('blocks.'))
     last_block = depth if last_block is None else last_block
-    assert emulate in (None, 'bf16', 'bf16_nofold', 'fp8'), emulate
+    assert emulate in (None, 'bf16', 'bf16_fold12', 'bf16_nofold', 'fp8'), emulate
     x = vit_embed(img, w, patch, emulate) if x_in is None else x_in
     feats = {}
     for i in range(first_block, last_block):

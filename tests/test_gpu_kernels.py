@@ -471,6 +471,15 @@ def test_vit_forward_bf16_error():
     with torch.no_grad():
         feats, cls = OV.vit_forward(x, w, heads, patch, (3, 7, 11))
         feats16, cls16 = OV.vit_forward(x, w, heads, patch, (3, 7, 11), emulate='bf16')
+    # the other LayerNorm-fold settings of the product (MVF_LN_FOLD = 1 / 0) against the oracle's matching emulation: same gates
+    sd = {k: v.to(DEV) for k, v in w.items()}
+    for fold, emu in ((1, 'bf16_fold12'), (0, 'bf16_nofold')):
+        with torch.no_grad():
+            fe, _ = OV.vit_forward(x, w, heads, patch, (3, 7, 11), emulate=emu)
+        got, _ = ops.vit_forward(x.to(DEV), ops.PackedViT(sd, depth, dim, heads, patch, img, (3, 7, 11), 'bf16', ln_fold=fold))
+        ls = [rel_l2(got[j].float(), fe[:, 1:, j * dim:(j + 1) * dim].reshape(-1, dim)) for j in range(3)]
+        record_parity('bf16 ViT-B/16 taps with MVF_LN_FOLD=%d vs oracle emulate=%r: rel-L2 %s' % (fold, emu, ' '.join('%.3e' % e for e in ls)))
+        assert max(ls) < 6e-3, (fold, ls)
     for variant in (0, 1):
         got, gcls = ops.vit_forward(x.to(DEV), _pack(w, depth, dim, heads, patch, img, (3, 7, 11), 'bf16'),
                                     attn_variant=variant)

@@ -37,6 +37,7 @@ TFLOP_PER_CLIP = 1.1925       # algorithmic work of conf
 PEAK_F32_TFLOPS = 157.3       # fp32-input MFMA (= vector) peak, parity mode
 # (epilogue kind, N, K) of the ViT-B/16 GEMMs; M = frames * 197 (patch-embed: frames * 196)
 GEMM_NAMES = {(0, 2304, 768): 'qkv [M,768]x[2304,768]^T', (2, 768, 768): 'proj+resid [M,768]x[768,768]^T',
+              (0, 768, 768): 'proj (bf16 branch output, residual add deferred) [M,768]x[768,768]^T',
               (1, 3072, 768): 'fc1+gelu [M,768]x[3072,768]^T', (2, 768, 3072): 'fc2+resid [M,3072]x[768,3072]^T',
               (3, 768, 768): 'patch-embed+pos [M,768]x[768,768]^T'}
 PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
@@ -54,7 +55,7 @@ def rocprof_names(groups, dtype, ln_fold):
         if dtype != 'bf16':
             parts = [('gemm_tc_kernel<float, %d, false>' % e, 1.0)]
         else:
-            qkv, fc1 = e == 0, e == 1
+            qkv, fc1 = e == 0 and r['n'] > r['k'], e == 1        # (epi 0 with N == K: the proj GEMM of the deferred residual)
             fc2, proj = e == 2 and r['k'] > r['n'], e == 2 and r['k'] == r['n']
             frac = 0.0
             if (qkv or fc2) and ln_fold in (1, 2):

@@ -104,6 +104,17 @@ int mvf_gemm_tc_ln(int dtype, int epi, const void* A, int lda, const void* W, in
                    float* resid, int ldr, void* tap, int ldt, const float* ls, int tokens_per_frame, void* xb, int ldxb,
                    float* stats, const float* ln_mr, const float* ln_c, int M, int N, int K, hipStream_t stream);
 int mvf_ln_stats_finalize(const float* part, int ns, float* mean_rstd, int rows, int D, float eps, hipStream_t stream);
+/* Deferred residual of the attention branch (bf16 mode, timm Block without LayerScale: x = x + proj(attn); x = x + mlp(norm2(x))):
+ * proj stores delta = bf16(A W^T + b) with the plain epilogue (mvf_gemm_tc, epi 0) instead of read-modifying the fp32 residual;
+ *   mvf_layernorm_add_fwd   y = LayerNorm(x + delta)          (x untouched)
+ *   mvf_gemm_tc_resid2      resid += A W^T + bias + addend2   (fc2: addend2 = delta, bf16 [M, ld2]; tap as in mvf_gemm_tc)
+ * -- the branch output is rounded to 16 bits before the add, as under the reference's autocast (models/transformer.py:188) */
+int mvf_layernorm_add_fwd(int out_dtype, const float* x, size_t in_stride, const void* add_bf16, size_t add_stride,
+                          const float* g, const float* b, void* y, size_t out_stride, int rows, int D, float eps,
+                          hipStream_t stream);
+int mvf_gemm_tc_resid2(const void* A, int lda, const void* W, int ldw, const float* bias, float* resid, int ldr,
+                       const void* addend2, int ld2, void* tap, int ldt, int tokens_per_frame, int M, int N, int K,
+                       hipStream_t stream);
 /* out [M, ldo] fp32 = A W^T + bias [+ addend [M, ldo]] with bf16 A [M, K] / W [N, K]: the residual epilogue out of place
  * (addend NULL: none) -- nn.Linear forward / input gradient of the TRAINABLE backbone blocks (transformer.py:364-392) */
 int mvf_gemm_tc_f32(const void* A, int lda, const void* W, int ldw, const float* bias, float* out, int ldo, const float* addend,

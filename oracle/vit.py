@@ -21,7 +21,9 @@ and the tapped block outputs; accumulation, biases, position embedding, LayerSca
 LayerNorm is FOLDED into the GEMM that consumes it where the product folds it (include/mvf_hip.h qkv_c / fc1_c; default
 MVF_LN_FOLD=2: norm1 of blocks > 0):   LN(x) W^T + b  ==  rstd * (x W'^T - mean * c) + d   with W' = gamma (.) W,
 c[n] = sum_k W'[n,k], d = b + W beta; the rounding points are then xb = bf16(x) and bf16(W') (c is summed over the
-ROUNDED W').  Everywhere else (block 0's norm1, every norm2) the LayerNorm output is rounded instead.  The product's other
+ROUNDED W').  Everywhere else (block 0's norm1, every norm2) the LayerNorm output is rounded instead.  Blocks without
+LayerScale also round the attention branch's output (proj + bias) to bf16 before the residual add (the product stores it with
+the plain GEMM epilogue and adds it in LayerNorm 2 and in the fc2 epilogue: csrc/vit_fwd.hip `defer`; D % 128 == 0).  The product's other
 settings: `emulate='bf16_fold12'` (MVF_LN_FOLD=1: norm2 folded too), `'bf16_nofold'` (MVF_LN_FOLD=0).  It is the checker for the benchmarked dtype (tests/test_gpu_*: tight gates instead of "bf16 is somewhere
 near fp32").
 
@@ -135,7 +137,9 @@ def vit_block(x, w, p, heads, eps=1e-6, emulate=None):
         return vit_block_bf16(x, w, p, heads, eps, mx=True)
     if emulate in ('bf16', 'bf16_fold12', 'bf16_nofold'):
         fold = emulate != 'bf16_nofold' and x.shape[-1] % 128 == 0
-        return vit_block_bf16(x, w, p, heads, eps, fold1=fold and p != 'blocks.0.', fold2=fold and emulate == 'bf16_fold12')
+        # the product defers the attention branch's residual add (bf16-rounded proj output) unless norm2 is folded / LayerScale
+        return vit_block_bf16(x, w, p, heads, eps, fold1=fold and p != 'blocks.0.', fold2=fold and emulate == 'bf16_fold12',
+                              defer_proj=emulate != 'bf16_fold12' and x.shape[-1] % 128 == 0)
     f, n, d = x.shape
     hd = d // heads
     h = layer_norm(x, w[p + 'norm1.weight'], w[p + 'norm1.bias'], eps)
@@ -172,7 +176,7 @@ def ln_linear_bf16(x, g, beta, W, b, eps, fold):
     return rstd * (r(x) @ Wp.t() - mean * c) + d
 
 
-def vit_block_bf16(x, w, p, heads, eps=1e-6, fold1=False, fold2=False, mx=False):
+def vit_block_bf16(x, w, p, heads, eps=1e-6, fold1=False, fold2=False, mx=False, defer_proj=False):
     """vit_block with the bf16 mode's rounding points (module docstring); x is the fp32 residual stream.
     mx: the product's fp8 mode -- both operands of the four GEMMs quantised to MX-fp8 (mx_quant along k: LayerNorm outputs,
     attention output and fc1+GELU output after their bf16 rounding, weights once), everything else as in bf16 mode, no fold."""
@@ -196,6 +200,8 @@ def vit_block_bf16(x, w, p, heads, eps=1e-6, fold1=False, fold2=False, mx=False)
     a = r((r(pr) @ v) / pr.sum(-1, keepdim=True))          # P in bf16 for P.V, its row sum in fp32
     a = a.transpose(1, 2).reshape(f, n, d)
     a = lin(a, 'attn.proj.weight', 'attn.proj.bias')
+    if defer_proj and not mx and p + 'ls1.gamma' not in w:
+        a = r(a)          # deferred residual: the branch output is stored as bf16 before it is added (module docstring)
     if p + 'ls1.gamma' in w:
         a = a * w[p + 'ls1.gamma']
     x = x + a

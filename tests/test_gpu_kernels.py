@@ -499,6 +499,40 @@ def test_vit_forward_bf16_error():
         assert ec < 1e-2, ec
 
 
+@pytest.mark.parametrize('M,D,K', [(1000, 768, 3072), (300, 256, 256), (513, 1024, 1024)])
+def test_deferred_residual_layernorm_add_and_second_addend(M, D, K):
+    """The two consumers of the deferred attention-branch output: LayerNorm(x + delta) with a bf16 delta (x untouched) and the
+    residual epilogue with a second, bf16 addend (resid += A W^T + b + delta), on the 256x256 kernel and on the 128x128 one."""
+    g = gen(71)
+    x = torch.randn(M, D, generator=g) * 2
+    delta = (torch.randn(M, D, generator=g) * 0.5).to(torch.bfloat16)
+    gam, bet = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g)
+    xd, dd, gd, bd = x.to(DEV), delta.to(DEV), gam.to(DEV), bet.to(DEV)
+    ref = torch.nn.functional.layer_norm(x.double() + delta.double(), (D,), gam.double(), bet.double(), 1e-6)
+    for dt, tdt, tol in ((_lib.F32, torch.float32, 2e-5), (_lib.BF16, torch.bfloat16, 4e-3)):
+        y = torch.empty(M, D, device=DEV, dtype=tdt)
+        _lib.call('mvf_layernorm_add_fwd', dt, xd.data_ptr(), D, dd.data_ptr(), D, gd.data_ptr(), bd.data_ptr(), y.data_ptr(), D, M,
+                  D, 1e-6, S())
+        check(y.float(), ref, tol, 'LayerNorm(x + delta)')
+    assert torch.equal(xd.cpu(), x)
+    A = (torch.randn(M, K, generator=g)).to(torch.bfloat16)
+    W = (torch.randn(D, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    b = torch.randn(D, generator=g)
+    want = x.double() + A.double() @ W.double().t() + b.double() + delta.double()
+    Ad, Wd, bb = A.to(DEV), W.to(DEV), b.to(DEV)
+    outs = []
+    for variant in (2, 1):       # 256x256 persistent kernel, 128x128 kernel
+        _lib.call('mvf_gemm_tc_select', variant)
+        r = x.clone().to(DEV)
+        _lib.call('mvf_gemm_tc_resid2', Ad.data_ptr(), K, Wd.data_ptr(), K, bb.data_ptr(), r.data_ptr(), D, dd.data_ptr(), D, None, 0,
+                  197, M, D, K, S())
+        torch.cuda.synchronize()
+        outs.append(r)
+        check(r, want, 2e-5, 'resid + A W^T + b + delta (variant %d)' % variant)
+    _lib.call('mvf_gemm_tc_select', 0)
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize('F,N,H', [(3, 197, 2), (2, 257, 2), (1, 50, 1), (2, 577, 1), (1, 224, 1), (1, 225, 3)])
 def test_vit_attention_bf16_forward_backward(F, N, H):
     """Attention core of a trainable ViT block in bf16 (ops.vit_attention_bf16: streamed flash forward keeping the

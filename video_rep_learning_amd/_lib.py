@@ -25,6 +25,8 @@ SIGNATURES = {
     'mvf_gemm_tc_batched': 'ipipipipiiiiiip',
     'mvf_gemm_tc_ln': 'iipipippipipipipipppiiip',
     'mvf_ln_stats_finalize': 'pipiifp',
+    'mvf_layernorm_add_fwd': 'ipzpzpppziifp',
+    'mvf_gemm_tc_resid2': 'pipippipipiiiiip',
     'mvf_gemm_tc_f32': 'pipippipiiip',
     'mvf_gemm_tc_batched_f32': 'pipipiiiiiip',
     'mvf_gelu_bf16': 'ppzp',

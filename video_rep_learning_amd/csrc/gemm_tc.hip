@@ -244,6 +244,11 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
   a.xb = nullptr; a.ldxb = 0; a.stats = nullptr; a.ln_mr = nullptr; a.ln_c = nullptr;
   a.sa = nullptr; a.sw = nullptr; a.csc = nullptr;
   a.radd = resid;
+  a.radd2 = nullptr; a.ldr2 = 0;
+  if (ln != nullptr && ln->addend2 != nullptr) {
+    MVF_CHECK_ARG(epi == EPI_RESID && dtype == MVF_BF16 && ((uintptr_t)ln->addend2 % 8) == 0 && ln->ld2 % 4 == 0 && ln->ld2 >= N);
+    a.radd2 = (const bf16_t*)ln->addend2; a.ldr2 = ln->ld2;
+  }
   if (ln != nullptr && ln->addend_mode != 0) {
     MVF_CHECK_ARG(epi == EPI_RESID && (ln->addend_mode == 2 || (ln->addend_mode == 1 && ln->addend && ((uintptr_t)ln->addend % 16) == 0)));
     a.radd = ln->addend_mode == 1 ? ln->addend : nullptr;
@@ -315,7 +320,7 @@ int mvf_gemm_fp8_impl(int epi, const void* A, int lda, const unsigned* sa, const
   a.pos = nullptr; a.ls = ls; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.ldt = ldt; a.M = M; a.N = N; a.K = K; a.tpf = tpf;
   a.dbg = nullptr; a.dbg_rowmask = 0x7fffffffu; a.dbg_kt = -1; a.dbg_abl = 0; a.sched = nullptr; a.batch_rows = 0; a.w_batch_rows = 0; a.row0 = 0;
   a.xb = nullptr; a.ldxb = 0; a.stats = nullptr; a.ln_mr = nullptr; a.ln_c = nullptr;
-  a.sa = sa; a.sw = sw; a.csc = c_scales; a.radd = resid;
+  a.sa = sa; a.sw = sw; a.csc = c_scales; a.radd = resid; a.radd2 = nullptr; a.ldr2 = 0;
   return mvf_gemm_tc256_launch(epi, a, /*persistent=*/true, st);
 }
 

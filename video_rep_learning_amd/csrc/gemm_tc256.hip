@@ -129,7 +129,9 @@ __device__ __forceinline__ void mfma_mx(f32x4_t& acc, const i32x8_t& w, const i3
 // times the k: the same matrix-pipe time per K tile for TWICE the FLOPs, from the same bytes (a K tile is 128-byte rows either
 // way, so staging, swizzle and hazards are unchanged).  The K tile's scales (256 + 256 dwords) travel by one more LDS-DMA per
 // wave, issued with A1 (same distance to its consumer, so the counted vmcnt(6) still leaves exactly three half-tiles in flight).
-template <int EPI, bool DBG, bool LN, bool FP8, int ABL = 0>   // ABL: timing ablations of the stamped build (dbg_abl)
+// ADD2: EPI_RESID with the second, bf16 addend (a.radd2): an instantiation of its own, one accumulator row per fetch batch,
+// so that the plain read-modify epilogues keep their register budget (the run-time form spilled two registers in both)
+template <int EPI, bool DBG, bool LN, bool FP8, int ABL = 0, bool ADD2 = false>   // ABL: timing ablations (dbg_abl)
 __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -495,8 +497,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
 #ifndef MVF_EPI_PIPE
 #define MVF_EPI_PIPE 0
 #endif
-    constexpr int EB = MVF_EPI_EB, NB = 8 / EB;
+    constexpr int EB = ADD2 ? 1 : MVF_EPI_EB, NB = 8 / EB;
     float4 add[2][EB][4];
+    uint2 add2[EB][4];
     auto prefetch = [&](int b) {
       if constexpr (kReadModify) {
 #pragma unroll
@@ -504,6 +507,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
           const int i = b * EB + ii;
           const int m = m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + frow;
           epilogue_prefetch<EPI>(a, m, m < a.M, n0 + wc * 64, fgrp, add[MVF_EPI_PIPE ? (b & 1) : 0][ii]);
+          if constexpr (ADD2) epilogue_prefetch2(a, m, m < a.M, n0 + wc * 64, fgrp, add2[ii]);
         }
       }
     };
@@ -534,11 +538,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     for (int ih = 0; ih < NB; ++ih) {
       if (!MVF_EPI_PIPE) prefetch(ih);
       else if (ih + 1 < NB) prefetch(ih + 1);
-      const float4(&addb)[EB][4] = add[MVF_EPI_PIPE ? (ih & 1) : 0];
+      float4(&addb)[EB][4] = add[MVF_EPI_PIPE ? (ih & 1) : 0];
 #pragma unroll
       for (int ii = 0; ii < EB; ++ii) {
         const int i = ih * EB + ii;
         const int m = m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + frow;
+        if constexpr (ADD2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) addb[ii][j] = add_bf16x4(addb[ii][j], add2[ii][j]);
+        }
         if constexpr (EPI == EPI_GELU_Q) {
           // the wave's 64 columns of row m = two MX blocks: quantise each, then one 2-byte store of both scales into the
           // row's dword of K tile (n0 + 64 wc) / 128 of the NEXT GEMM (bytes 2 (wc & 1), 2 (wc & 1) + 1)
@@ -662,14 +670,14 @@ unsigned* sched_slot() {
   return ring == nullptr ? nullptr : ring + (size_t)(next.fetch_add(1) & 1023u) * 16;
 }
 
-template <int EPI, bool DBG = false, bool LN = false, bool FP8 = false, int ABL = 0>
+template <int EPI, bool DBG = false, bool LN = false, bool FP8 = false, int ABL = 0, bool ADD2 = false>
 int launch(const GemmTcArgs& a0, bool persistent, hipStream_t st) {
   GemmTcArgs a = a0;
   static const bool force_static = getenv("MVF_GEMM_STATIC") != nullptr;   // A/B measurements only
   a.sched = persistent && !force_static ? sched_slot() : nullptr;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
@@ -677,7 +685,7 @@ int launch(const GemmTcArgs& a0, bool persistent, hipStream_t st) {
   // persistent: one workgroup per CU (a multiple of 8 so that every XCD gets the same number); otherwise (A/B
   // measurements) one workgroup per tile -- the same kernel, every workgroup then runs the cold prologue
   const int grid = persistent ? std::min(ntiles, std::max(8, num_cus() & ~7)) : ntiles;
-  hipLaunchKernelGGL((gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL>), dim3(grid), dim3(512), LDS_BYTES, st, a);
+  hipLaunchKernelGGL((gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2>), dim3(grid), dim3(512), LDS_BYTES, st, a);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }
@@ -734,14 +742,17 @@ int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, bool persistent
     switch (epi) {
       case EPI_STORE: return launch<EPI_STORE, false, true>(a, persistent, st);
       case EPI_GELU: return launch<EPI_GELU, false, true>(a, persistent, st);
-      case EPI_RESID: return launch<EPI_RESID, false, true>(a, persistent, st);
+      case EPI_RESID:
+        return a.radd2 != nullptr ? launch<EPI_RESID, false, true, false, 0, true>(a, persistent, st)
+                                  : launch<EPI_RESID, false, true>(a, persistent, st);
     }
     return MVF_ERR_ARG;
   }
   switch (epi) {
     case EPI_STORE: return launch<EPI_STORE>(a, persistent, st);
     case EPI_GELU: return launch<EPI_GELU>(a, persistent, st);
-    case EPI_RESID: return launch<EPI_RESID>(a, persistent, st);
+    case EPI_RESID:
+      return a.radd2 != nullptr ? launch<EPI_RESID, false, false, false, 0, true>(a, persistent, st) : launch<EPI_RESID>(a, persistent, st);
     case EPI_PATCH: return launch<EPI_PATCH>(a, persistent, st);
   }
   return MVF_ERR_ARG;

@@ -51,6 +51,10 @@ struct GemmTcArgs {
   // (out of place: trainable blocks, whose LayerNorm saved the old residual for its backward) or NULL (no addend: a plain fp32
   // result -- forward of qkv / fc1, input gradients, split-K partials -- without a zero-fill + read-modify-write)
   const float* radd;
+  // EPI_RESID: a second addend, bf16 [M, ldr2] (NULL: none) -- the attention branch's output when the proj GEMM stored it
+  // instead of read-modifying the residual (deferred residual: vit_fwd.hip); added to the fp32 addend as it is fetched
+  const bf16_t* radd2;
+  int ldr2;
   // EPI_GELU_Q: C holds e4m3 bytes [M, ldc] and csc [N/128][M] the output's block scales (same layout as sa)
   unsigned* csc;
 };
@@ -91,6 +95,8 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   const float erf_abs = fmaf(-p, e, 1.0f);                 // erf(|x|/sqrt2)
   return 0.5f * x + 0.5f * fabsf(x) * erf_abs;             // 0.5 x (1 + sign(x) erf_abs)
 }
+
+__device__ __forceinline__ float4 add_bf16x4(float4 v, uint2 u);
 
 template <typename T>
 __device__ __forceinline__ void store4(char* base, size_t elem_off, const float (&v)[4]);
@@ -139,7 +145,9 @@ __device__ __forceinline__ void epilogue4(const GemmTcArgs& a, int m, int n, con
       v[0] *= gm.x; v[1] *= gm.y; v[2] *= gm.z; v[3] *= gm.w;
     }
     if (a.radd != nullptr) {
-      const float4 o = *reinterpret_cast<const float4*>(a.radd + out_row * a.ldr + n);
+      float4 o = *reinterpret_cast<const float4*>(a.radd + out_row * a.ldr + n);
+      if (a.radd2 != nullptr)     // (radd + radd2) first, as the 256x256 kernel associates them
+        o = add_bf16x4(o, *reinterpret_cast<const uint2*>(a.radd2 + out_row * a.ldr2 + n));
       v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
     }
     *reinterpret_cast<float4*>(rp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -202,6 +210,21 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmTcArgs& a, int m, bo
     const int n = nw + j * 16 + fgrp * 4;
     add[j] = (ok && n < a.N) ? *reinterpret_cast<const float4*>(src + n) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+}
+
+// the second (bf16) addend of EPI_RESID, fetched raw beside the fp32 one and added to it when the row is stored (an add at
+// fetch time would wait for both loads there)
+__device__ __forceinline__ void epilogue_prefetch2(const GemmTcArgs& a, int m, bool ok, int nw, int fgrp, uint2 (&raw)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = nw + j * 16 + fgrp * 4;
+    raw[j] = (ok && n < a.N) ? *reinterpret_cast<const uint2*>(a.radd2 + (size_t)m * a.ldr2 + n) : make_uint2(0u, 0u);
+  }
+}
+__device__ __forceinline__ float4 add_bf16x4(float4 v, uint2 u) {
+  v.x += __uint_as_float(u.x << 16); v.y += __uint_as_float(u.x & 0xffff0000u);
+  v.z += __uint_as_float(u.y << 16); v.w += __uint_as_float(u.y & 0xffff0000u);
+  return v;
 }
 
 // add0/add1: the prefetched addends of the two tiles (EPI_RESID / EPI_PATCH), g0/g1: LayerScale (EPI_RESID with a.ls).

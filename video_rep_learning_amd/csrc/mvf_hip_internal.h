@@ -17,6 +17,9 @@ struct MvfGemmLn {
   // epi 2: 0 = the addend is `resid` itself (in place), 1 = read it from `addend` [M, ldr], 2 = no addend
   int addend_mode;
   const float* addend;
+  // epi 2: a second addend, bf16 [M, ld2] (NULL: none): the attention branch's output stored by the proj GEMM (deferred residual)
+  const void* addend2;
+  int ld2;
 };
 int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C,
                      int ldc, float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tpf, int M,
@@ -35,7 +38,7 @@ int mvf_im2col_impl(int dtype, const float* img, void* out, int F, int H, int W,
 static inline int mvf_patch_k(int P) { return (3 * P * P + 127) / 128 * 128; }
 int mvf_cls_row_impl(float* x, const float* cls, const float* pos, int F, int tpf, int D, hipStream_t st);
 int mvf_layernorm_impl(int out_dtype, const float* x, size_t in_stride, const float* g, const float* b, void* y,
-                       size_t out_stride, int rows, int D, float eps, hipStream_t st);
+                       size_t out_stride, int rows, int D, float eps, hipStream_t st, const void* add_bf16 = nullptr, size_t add_stride = 0);
 int mvf_cast_bf16_impl(const float* in, void* out, size_t n, hipStream_t st);
 int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t st);
 

@@ -6,10 +6,14 @@
 // reshape copies of CARL_MVF/models/transformer.py:186-214, 306-333.
 #include "common.h"
 #include "mvf_hip_internal.h"
+#include <cstdlib>
 #include <vector>
 
 namespace {
 enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
+
+// MVF_PROJ_DEFER=0: keep the proj GEMM's read-modify epilogue (A/B measurements)
+const bool g_proj_defer = []{ const char* e = getenv("MVF_PROJ_DEFER"); return e == nullptr || e[0] != '0'; }();
 
 struct Ws {
   float* x;     // residual stream  [Mc, D] fp32
@@ -18,6 +22,7 @@ struct Ws {
   char* hid;    // [Mc, 4D] T   (also holds the patch rows before the embed GEMM)
   // LN fold (bf16): bf16 copy of the residual stream, row partial sums from the residual epilogues, (mean, rstd) per row
   char* xb;     // [Mc, D] bf16
+  char* delta;  // [Mc, D] bf16: the attention branch's output (proj GEMM) while its residual add is deferred to LN2 / fc2
   float* stats; // [D/64, Mc, 2]
   float* mr;    // [Mc, 2]
   // MX-fp8 mode: the A operands of the four GEMMs (LayerNorm output / attention output share hq; fc1+GELU output -> hidq)
@@ -90,10 +95,12 @@ size_t carve(int dtype, int fc, int N, int D, int P, Ws* w, char* base) {
   const size_t patch_bytes = (size_t)fc * (N - 1) * mvf_patch_k(P) * esz;
   char* hid = take(std::max(Mc * 4 * D * esz, patch_bytes));
   char* xb = nullptr;
+  char* delta = nullptr;
   char* stats = nullptr;
   char* mr = nullptr;
   if (dtype == MVF_BF16 && D % 64 == 0) {
     xb = take(Mc * D * 2);
+    delta = take(Mc * D * 2);
     stats = take(Mc * (size_t)(D / 64) * 2 * 4);
     mr = take(Mc * 2 * 4);
   }
@@ -105,7 +112,7 @@ size_t carve(int dtype, int fc, int N, int D, int P, Ws* w, char* base) {
     hids = take((size_t)(4 * D / 128) * Mc * 4);
   }
   if (w) {
-    w->x = (float*)x; w->h = h; w->qkv = qkv; w->hid = hid; w->xb = xb; w->stats = (float*)stats; w->mr = (float*)mr;
+    w->x = (float*)x; w->h = h; w->qkv = qkv; w->hid = hid; w->xb = xb; w->delta = delta; w->stats = (float*)stats; w->mr = (float*)mr;
     w->hq = hq; w->hs = (unsigned*)hs; w->hidq = hidq; w->hids = (unsigned*)hids;
   }
   return off;
@@ -205,7 +212,15 @@ extern "C" int mvf_vit_fwd_x(const MvfVitWeights* w, int dtype, const float* fra
       }
       RUN(mvf_vit_attn_impl(dtype, ws.qkv, ws.h, fc, N, H, D, attn_variant, st));
       const bool fold2 = folded(w->fc1_c, l);
-      {
+      // Deferred residual (bf16, no LayerScale, norm2 not folded): proj stores its result (+ bias) as bf16 with the plain
+      // epilogue instead of read-modifying the fp32 residual (310 MB per launch with the matrix cores idle); LayerNorm 2
+      // normalises x + delta and the fc2 epilogue adds delta with its own residual update.  The branch output is rounded to
+      // bf16 before the add -- what the reference's autocast does to it (fp16 there; transformer.py:188).
+      const bool defer = g_proj_defer && dtype == MVF_BF16 && ws.delta != nullptr && !fold2 && w->ls1 == nullptr && D % 128 == 0;
+      if (defer) {
+        RUN(timed_gemm(dtype, EPI_STORE, ws.h, D, w->proj_w[l], D, w->proj_b[l], ws.delta, D, nullptr, 0, nullptr, 0, nullptr,
+                       nullptr, N, Mc, D, D, st));
+      } else {
         const MvfGemmLn ln = {fold2 ? ws.xb : nullptr, D, fold2 ? ws.stats : nullptr, nullptr, nullptr, 0, nullptr};
         RUN(timed_gemm(dtype, EPI_RESID, ws.h, D, w->proj_w[l], D, w->proj_b[l], nullptr, 0, ws.x, D, nullptr, 0,
                        nullptr, w->ls1 ? w->ls1[l] : nullptr, N, Mc, D, D, st, fold2 ? &ln : nullptr));
@@ -216,7 +231,7 @@ extern "C" int mvf_vit_fwd_x(const MvfVitWeights* w, int dtype, const float* fra
         RUN(timed_gemm(dtype, EPI_GELU, ws.xb, D, w->fc1_w[l], D, w->fc1_b[l], ws.hid, 4 * D, nullptr, 0, nullptr, 0,
                        nullptr, nullptr, N, Mc, 4 * D, D, st, &ln));
       } else {
-        RUN(mvf_layernorm_impl(dtype, ws.x, D, w->ln2_w[l], w->ln2_b[l], ws.h, D, Mc, D, w->ln_eps, st));
+        RUN(mvf_layernorm_impl(dtype, ws.x, D, w->ln2_w[l], w->ln2_b[l], ws.h, D, Mc, D, w->ln_eps, st, defer ? ws.delta : nullptr, D));
         RUN(timed_gemm(dtype, EPI_GELU, ws.h, D, w->fc1_w[l], D, w->fc1_b[l], ws.hid, 4 * D, nullptr, 0, nullptr, 0,
                        nullptr, nullptr, N, Mc, 4 * D, D, st));
       }
@@ -224,9 +239,10 @@ extern "C" int mvf_vit_fwd_x(const MvfVitWeights* w, int dtype, const float* fra
       if (tap >= 0 && taps_out && taps_out[tap]) tap_ptr = (char*)taps_out[tap] + (size_t)f0 * np * D * esz;
       const bool fold_next = folded(w->qkv_c, l + 1);
       {
-        const MvfGemmLn ln = {fold_next ? ws.xb : nullptr, D, fold_next ? ws.stats : nullptr, nullptr, nullptr, 0, nullptr};
+        const MvfGemmLn ln = {fold_next ? ws.xb : nullptr, D, fold_next ? ws.stats : nullptr, nullptr, nullptr, 0, nullptr,
+                              defer ? ws.delta : nullptr, D};
         RUN(timed_gemm(dtype, EPI_RESID, ws.hid, 4 * D, w->fc2_w[l], 4 * D, w->fc2_b[l], nullptr, 0, ws.x, D, tap_ptr,
-                       D, nullptr, w->ls2 ? w->ls2[l] : nullptr, N, Mc, D, 4 * D, st, fold_next ? &ln : nullptr));
+                       D, nullptr, w->ls2 ? w->ls2[l] : nullptr, N, Mc, D, 4 * D, st, (fold_next || defer) ? &ln : nullptr));
       }
     }
     if (x_out && hipMemcpyAsync(x_out + (size_t)f0 * N * D, ws.x, (size_t)Mc * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -293,6 +309,13 @@ extern "C" int mvf_gemm_tc_f32(const void* A, int lda, const void* W, int ldw, c
                                const float* addend, int M, int N, int K, hipStream_t st) {
   const MvfGemmLn ln = {nullptr, 0, nullptr, nullptr, nullptr, addend ? 1 : 2, addend};
   return mvf_gemm_tc_impl(MVF_BF16, EPI_RESID, A, lda, W, ldw, bias, nullptr, 0, out, ldo, nullptr, 0, nullptr, nullptr, 1, M, N, K,
+                          st, 0, 0, &ln);
+}
+// the fc2 step of the deferred residual on its own: resid += A W^T + bias + addend2 (bf16 [M, ld2]); tap as in mvf_gemm_tc
+extern "C" int mvf_gemm_tc_resid2(const void* A, int lda, const void* W, int ldw, const float* bias, float* resid, int ldr,
+                                  const void* addend2, int ld2, void* tap, int ldt, int tpf, int M, int N, int K, hipStream_t st) {
+  const MvfGemmLn ln = {nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, addend2, ld2};
+  return mvf_gemm_tc_impl(MVF_BF16, EPI_RESID, A, lda, W, ldw, bias, nullptr, 0, resid, ldr, tap, ldt, nullptr, nullptr, tpf, M, N, K,
                           st, 0, 0, &ln);
 }
 extern "C" int mvf_ln_stats_finalize(const float* part, int ns, float* mean_rstd, int rows, int D, float eps, hipStream_t st) {

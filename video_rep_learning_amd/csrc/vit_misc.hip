@@ -50,10 +50,13 @@ __global__ void cls_row_kernel(float* __restrict__ x, const float* __restrict__ 
 
 // LayerNorm over the last dim, one wave per row, row cached in registers (D <= 64*4*MAXV).
 // in: fp32 rows with stride `in_stride` rows apart (lets the final norm touch only CLS rows).
+// add != NULL: the row normalised is x + add (bf16 [rows, add_stride]: the attention branch's output that the proj GEMM stored
+// instead of read-modifying the fp32 residual; x itself is not updated here -- the fc2 epilogue adds the same values)
 template <typename TO, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, size_t in_stride,
                                                         const float* __restrict__ g, const float* __restrict__ b,
-                                                        TO* __restrict__ y, size_t out_stride, int rows, int D, float eps) {
+                                                        TO* __restrict__ y, size_t out_stride, int rows, int D, float eps,
+                                                        const bf16_t* __restrict__ add, size_t add_stride) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -66,6 +69,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int q = lane + i * 64;
     if (q < nv) {
       v[i] = *reinterpret_cast<const float4*>(xr + q * 4);
+      if (add != nullptr) {
+        const uint2 u = *reinterpret_cast<const uint2*>(add + (size_t)row * add_stride + q * 4);
+        v[i].x += __uint_as_float(u.x << 16); v[i].y += __uint_as_float(u.x & 0xffff0000u);
+        v[i].z += __uint_as_float(u.y << 16); v[i].w += __uint_as_float(u.y & 0xffff0000u);
+      }
       s += v[i].x + v[i].y + v[i].z + v[i].w;
     }
   }
@@ -188,13 +196,14 @@ int mvf_cls_row_impl(float* x, const float* cls, const float* pos, int F, int tp
 }
 
 int mvf_layernorm_impl(int out_dtype, const float* x, size_t in_stride, const float* g, const float* b, void* y,
-                       size_t out_stride, int rows, int D, float eps, hipStream_t st) {
+                       size_t out_stride, int rows, int D, float eps, hipStream_t st, const void* add_bf16, size_t add_stride) {
   MVF_CHECK_ARG(x && g && b && y && rows > 0 && D % 4 == 0 && D <= 64 * 4 * 8);
-  MVF_CHECK_ARG(in_stride % 4 == 0 && out_stride % 4 == 0);
+  MVF_CHECK_ARG(in_stride % 4 == 0 && out_stride % 4 == 0 && add_stride % 4 == 0 && ((uintptr_t)add_bf16 % 8) == 0);
+  const bf16_t* add = (const bf16_t*)add_bf16;
   const int grid = ceil_div(rows, 4);
   const int nv = ceil_div(D / 4, 64);
 #define LN_LAUNCH(TO, MV) \
-  hipLaunchKernelGGL((layernorm_kernel<TO, MV>), dim3(grid), dim3(256), 0, st, x, in_stride, g, b, (TO*)y, out_stride, rows, D, eps)
+  hipLaunchKernelGGL((layernorm_kernel<TO, MV>), dim3(grid), dim3(256), 0, st, x, in_stride, g, b, (TO*)y, out_stride, rows, D, eps, add, add_stride)
   if (out_dtype == MVF_BF16) {
     if (nv <= 1) LN_LAUNCH(bf16_t, 1); else if (nv <= 2) LN_LAUNCH(bf16_t, 2); else if (nv <= 4) LN_LAUNCH(bf16_t, 4); else LN_LAUNCH(bf16_t, 8);
   } else {
@@ -221,6 +230,14 @@ int mvf_ln_stats_finalize_impl(const float* part, int ns, float* mr, int rows, i
                      eps);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
+}
+
+// LayerNorm(x + add) with a bf16 addend (the LN2 step of the deferred residual); x is not modified
+extern "C" int mvf_layernorm_add_fwd(int out_dtype, const float* x, size_t in_stride, const void* add_bf16, size_t add_stride,
+                                     const float* g, const float* b, void* y, size_t out_stride, int rows, int D, float eps,
+                                     hipStream_t st) {
+  MVF_CHECK_ARG(add_bf16 != nullptr && (out_dtype == MVF_F32 || out_dtype == MVF_BF16));
+  return mvf_layernorm_impl(out_dtype, x, in_stride, g, b, y, out_stride, rows, D, eps, st, add_bf16, add_stride);
 }
 
 extern "C" int mvf_cast_bf16_f32(const void* in, float* out, size_t n, hipStream_t st) {

@@ -43,12 +43,13 @@ GEMM_NAMES = {(0, 2304, 768): 'qkv [M,768]x[2304,768]^T', (2, 768, 768): 'proj+r
 PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
 
 
-def rocprof_names(groups, dtype, ln_fold):
-    """The same launches under the kernel names rocprofv3 prints, gemm_tc256_kernel<EPI, DBG, LN, FP8>: one kernel per
-    epilogue, so proj and fc2 share <2, ...>.  LN = true for the launches that carry the LN-fold extras: of a shape's 12
-    launches per forward, 11 in fold mode 2 for qkv (blocks 1..11 consume the folded norm1) and for fc2 (blocks 0..10 produce
-    bf16(x) + the row sums); 12 for fc1 / proj in the modes that fold norm2.  Averages are per shape group (HIP events cannot
-    tell the two names of one shape apart)."""
+def rocprof_names(groups, dtype, ln_fold, defer=True):
+    """The same launches under the kernel names rocprofv3 prints, gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2>: one kernel
+    per epilogue flavour.  LN = true for the launches that carry the LN-fold extras: of a shape's 12 launches per forward, 11 in
+    fold mode 2 for qkv (blocks 1..11 consume the folded norm1) and for fc2 (blocks 0..10 produce bf16(x) + the row sums); 12
+    for fc1 / proj in the modes that fold norm2.  ADD2 = true for fc2 when the attention branch's residual add is deferred
+    (then proj is a plain store, <0, ...>, the name it shares with block 0's unfolded qkv).  Averages are per shape group
+    (HIP events cannot tell the two names of one shape apart)."""
     by = {}
     for r in groups:
         e = r['epi']
@@ -62,7 +63,9 @@ def rocprof_names(groups, dtype, ln_fold):
                 frac = 11.0 / 12.0
             if (fc1 or proj) and ln_fold in (1, 3):
                 frac = 1.0
-            parts = [('gemm_tc256_kernel<%d, false, true, false>' % e, frac), ('gemm_tc256_kernel<%d, false, false, false>' % e, 1.0 - frac)]
+            add2 = 'true' if (fc2 and defer and ln_fold in (0, 2)) else 'false'
+            parts = [('gemm_tc256_kernel<%d, false, true, false, 0, %s>' % (e, add2), frac),
+                     ('gemm_tc256_kernel<%d, false, false, false, 0, %s>' % (e, add2), 1.0 - frac)]
         for k, f in parts:
             if f > 0:
                 d = by.setdefault(k, {'launches': 0.0, 'ms': 0.0})
@@ -177,7 +180,9 @@ def parity_block(model, batch, nv, dev):
         if mode == 'bf16':     # the dtype's own error: bf16 HIP against the plain fp32 oracle
             out['loss_rel_bf16_vs_fp32_oracle'] = float('%.3e' % T.relerr(loss, ref['fp32'][1]))
             out['emb_maxrel_bf16_vs_fp32_oracle'] = float('%.3e' % T.relerr(emb, ref['fp32'][0]))
-    out['gate'] = 'fp32 loss and embeddings <= 1e-3 rel (north star); bf16 columns are against the bf16-emulating oracle'
+    out['gate'] = ('fp32 loss and embeddings <= 1e-3 rel (north star); bf16 columns are against the bf16-emulating oracle. The '
+                   'embeddings are eval-mode outputs: after the benchmark\'s training steps the BatchNorm running variances are small '
+                   'and amplify the 4e-3 tap-level rounding noise about tenfold (a freshly initialised head: 6e-4, tests/test_gpu_configs.py)')
     out['ok'] = bool(out['loss_rel_fp32'] <= 1e-3 and out['emb_maxrel_fp32'] <= 1e-3)
     return out
 
@@ -330,7 +335,7 @@ def main():
                               for r in groups},
                 # the same launches under the names rocprofv3 prints: one kernel per epilogue, so proj and fc2 (and
                 # nothing else) share `gemm_tc256_kernel<2, false>`; compare with `bench.py --serial` under rocprofv3
-                'rocprof_kernels': rocprof_names(groups, a.dtype, ops.VIT_LN_FOLD),
+                'rocprof_kernels': rocprof_names(groups, a.dtype, ops.VIT_LN_FOLD, os.environ.get('MVF_PROJ_DEFER', '1') != '0'),
                 'ln_fold': {0: 'off', 1: 'norm1 (blocks 1..) and norm2 folded into qkv / fc1', 2: 'norm1 of blocks 1.. folded into the qkv GEMM (default)', 3: 'norm2 folded into fc1'}[ops.VIT_LN_FOLD]}
     if world > 1:
         dist.barrier()

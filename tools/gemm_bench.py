@@ -16,7 +16,10 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from video_rep_learning_amd import _lib  # noqa: E402
 
-SHAPES = {'qkv': (2304, 768, 0), 'proj': (768, 768, 2), 'fc1': (3072, 768, 1), 'fc2': (768, 3072, 2)}
+# the product's forms (bf16, deferred attention-branch residual): proj = plain bf16 store, fc2 = residual epilogue with the bf16
+# second addend; 'proj_rm' / 'fc2_rm' = the read-modify forms without the deferral (fp32 / LayerScale / MVF_PROJ_DEFER=0)
+SHAPES = {'qkv': (2304, 768, 0), 'proj': (768, 768, 0), 'fc1': (3072, 768, 1), 'fc2': (768, 3072, 2), 'proj_rm': (768, 768, 2),
+          'fc2_rm': (768, 3072, 2)}
 
 
 def main():
@@ -55,7 +58,13 @@ def main():
         mr = torch.stack([torch.randn(M, device=dev) * 0.1, 1.0 + 0.1 * torch.rand(M, device=dev)], 1).contiguous()
         c = torch.randn(n, device=dev)
 
+        delta = torch.randn(M, n, device=dev).to(torch.bfloat16) if name == 'fc2' else None
+
         def plain():
+            if name == 'fc2':
+                _lib.call('mvf_gemm_tc_resid2', A.data_ptr(), k, W.data_ptr(), k, b.data_ptr(), R.data_ptr(), n, delta.data_ptr(), n,
+                          None, 0, 197, M, n, k, st)
+                return
             _lib.call('mvf_gemm_tc', _lib.BF16, epi, A.data_ptr(), k, W.data_ptr(), k, b.data_ptr(), C.data_ptr(), n,
                       R.data_ptr(), n, None, 0, None, None, 197, M, n, k, st)
 

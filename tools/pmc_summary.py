@@ -16,7 +16,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import GEMM_NAMES  # noqa: E402
 
-ORDER = [('qkv', (0, 2304, 768)), ('proj', (2, 768, 768)), ('fc1', (1, 3072, 768)), ('fc2', (2, 768, 3072))]
+ORDER = [('qkv', (0, 2304, 768)), ('proj', (0, 768, 768)), ('fc1', (1, 3072, 768)), ('fc2', (2, 768, 3072))]
 FRAMES, TOKENS = 256, 197
 
 
@@ -39,7 +39,8 @@ def main():
     M = FRAMES * TOKENS
     for short, key in ORDER:
         epi, n, k = key
-        out_bytes = M * n * (4 + 4 if epi == 2 else 2)        # resid epilogue reads+writes fp32; others write bf16
+        # resid epilogue (fc2) reads + writes fp32 and reads the bf16 deferred attention-branch output; the others write bf16
+        out_bytes = M * n * (4 + 4 + 2 if epi == 2 else 2)
         algo = M * k * 2 + n * k * 2 + out_bytes
         hbm = (2.0 * fe[key] + wr[key]) * 1024.0
         res[GEMM_NAMES[key]] = {'fetch_size_kb': fe[key], 'write_size_kb': wr[key], 'hbm_bytes_per_launch': hbm,

@@ -21,9 +21,10 @@ and the tapped block outputs; accumulation, biases, position embedding, LayerSca
 LayerNorm is FOLDED into the GEMM that consumes it where the product folds it (include/mvf_hip.h qkv_c / fc1_c; default
 MVF_LN_FOLD=2: norm1 of blocks > 0):   LN(x) W^T + b  ==  rstd * (x W'^T - mean * c) + d   with W' = gamma (.) W,
 c[n] = sum_k W'[n,k], d = b + W beta; the rounding points are then xb = bf16(x) and bf16(W') (c is summed over the
-ROUNDED W').  Everywhere else (block 0's norm1, every norm2) the LayerNorm output is rounded instead.  Blocks without
-LayerScale also round the attention branch's output (proj + bias) to bf16 before the residual add (the product stores it with
-the plain GEMM epilogue and adds it in LayerNorm 2 and in the fc2 epilogue: csrc/vit_fwd.hip `defer`; D % 128 == 0).  The product's other
+ROUNDED W').  Everywhere else (block 0's norm1, every norm2) the LayerNorm output is rounded instead.  The attention branch's
+output (proj + bias, LayerScale gamma_1 folded into proj's weights and bias BEFORE their rounding / quantisation) is rounded to
+bf16 before the residual add (the product stores it with the plain GEMM epilogue and adds it in LayerNorm 2 and in the fc2
+epilogue: csrc/vit_fwd.hip `defer`; D % 128 == 0; also in fp8 mode).  The product's other
 settings: `emulate='bf16_fold12'` (MVF_LN_FOLD=1: norm2 folded too), `'bf16_nofold'` (MVF_LN_FOLD=0).  It is the checker for the benchmarked dtype (tests/test_gpu_*: tight gates instead of "bf16 is somewhere
 near fp32").
 
@@ -134,7 +135,7 @@ def mx_quant(t):
 
 def vit_block(x, w, p, heads, eps=1e-6, emulate=None):
     if emulate == 'fp8':
-        return vit_block_bf16(x, w, p, heads, eps, mx=True)
+        return vit_block_bf16(x, w, p, heads, eps, mx=True, defer_proj=True)   # (fp8 mode needs D % 256 == 0 anyway)
     if emulate in ('bf16', 'bf16_fold12', 'bf16_nofold'):
         fold = emulate != 'bf16_nofold' and x.shape[-1] % 128 == 0
         # the product defers the attention branch's residual add (bf16-rounded proj output) unless norm2 is folded / LayerScale
@@ -184,10 +185,13 @@ def vit_block_bf16(x, w, p, heads, eps=1e-6, fold1=False, fold2=False, mx=False,
     f, n, d = x.shape
     hd = d // heads
 
-    def lin(a, wn, bn):
+    def lin(a, wn, bn, row_scale=None):
+        W, b = w[p + wn], w[p + bn]
+        if row_scale is not None:         # LayerScale folded into the layer: (gamma (.) W, gamma (.) b), rounded AFTER the fold
+            W, b = W * row_scale[:, None], b * row_scale
         if mx:
-            return mx_quant(a) @ mx_quant(w[p + wn]).t() + w[p + bn]
-        return a @ r(w[p + wn]).t() + w[p + bn]
+            return mx_quant(a) @ mx_quant(W).t() + b
+        return a @ r(W).t() + b
     if mx:
         qkv = r(lin(layer_norm(x, w[p + 'norm1.weight'], w[p + 'norm1.bias'], eps), 'attn.qkv.weight', 'attn.qkv.bias'))
     else:
@@ -199,12 +203,15 @@ def vit_block_bf16(x, w, p, heads, eps=1e-6, fold1=False, fold2=False, mx=False,
     pr = torch.exp(s - s.max(-1, keepdim=True)[0])
     a = r((r(pr) @ v) / pr.sum(-1, keepdim=True))          # P in bf16 for P.V, its row sum in fp32
     a = a.transpose(1, 2).reshape(f, n, d)
-    a = lin(a, 'attn.proj.weight', 'attn.proj.bias')
-    if defer_proj and not mx and p + 'ls1.gamma' not in w:
-        a = r(a)          # deferred residual: the branch output is stored as bf16 before it is added (module docstring)
-    if p + 'ls1.gamma' in w:
-        a = a * w[p + 'ls1.gamma']
-    x = x + a
+    if defer_proj:
+        # deferred residual: the branch output (LayerScale folded into proj's weights and bias) is stored as bf16 before it is
+        # added (module docstring)
+        x = x + r(lin(a, 'attn.proj.weight', 'attn.proj.bias', w.get(p + 'ls1.gamma')))
+    else:
+        a = lin(a, 'attn.proj.weight', 'attn.proj.bias')
+        if p + 'ls1.gamma' in w:
+            a = a * w[p + 'ls1.gamma']
+        x = x + a
     if mx:   # quantised straight from the fp32 GELU value in fc1's epilogue (lin() applies mx_quant): no bf16 rounding
         h = gelu_erf(lin(layer_norm(x, w[p + 'norm2.weight'], w[p + 'norm2.bias'], eps), 'mlp.fc1.weight', 'mlp.fc1.bias'))
     else:

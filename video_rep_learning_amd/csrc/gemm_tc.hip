@@ -304,7 +304,7 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
 // MX-fp8 operands: the 256x256 kernel's FP8 variants only (no 128x128 fallback: sizes beyond its 32-bit offsets are refused)
 int mvf_gemm_fp8_impl(int epi, const void* A, int lda, const unsigned* sa, const void* W, int ldw, const unsigned* sw,
                       const float* bias, void* C, int ldc, unsigned* c_scales, float* resid, int ldr, void* tap, int ldt,
-                      const float* ls, int tpf, int M, int N, int K, hipStream_t st) {
+                      const float* ls, int tpf, int M, int N, int K, hipStream_t st, const void* addend2, int ld2) {
   MVF_CHECK_ARG(A && W && sa && sw && M > 0 && N > 0 && K > 0 && K % 256 == 0 && N % 32 == 0);
   if (c_scales != nullptr) {   // epi 1 with an MX-fp8 result: C = e4m3 bytes, c_scales [N/128][M]
     MVF_CHECK_ARG(epi == EPI_GELU && C && N % 128 == 0 && ldc % 8 == 0 && ((uintptr_t)C % 8) == 0 && ((uintptr_t)c_scales % 4) == 0);
@@ -321,6 +321,10 @@ int mvf_gemm_fp8_impl(int epi, const void* A, int lda, const unsigned* sa, const
   a.dbg = nullptr; a.dbg_rowmask = 0x7fffffffu; a.dbg_kt = -1; a.dbg_abl = 0; a.sched = nullptr; a.batch_rows = 0; a.w_batch_rows = 0; a.row0 = 0;
   a.xb = nullptr; a.ldxb = 0; a.stats = nullptr; a.ln_mr = nullptr; a.ln_c = nullptr;
   a.sa = sa; a.sw = sw; a.csc = c_scales; a.radd = resid; a.radd2 = nullptr; a.ldr2 = 0;
+  if (addend2 != nullptr) {
+    MVF_CHECK_ARG(epi == EPI_RESID && ((uintptr_t)addend2 % 8) == 0 && ld2 % 4 == 0 && ld2 >= N);
+    a.radd2 = (const bf16_t*)addend2; a.ldr2 = ld2;
+  }
   return mvf_gemm_tc256_launch(epi, a, /*persistent=*/true, st);
 }
 

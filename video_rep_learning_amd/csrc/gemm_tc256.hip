@@ -717,7 +717,9 @@ int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, bool persistent
       case EPI_STORE: return launch<EPI_STORE, false, false, true>(a, persistent, st);
       case EPI_GELU: return launch<EPI_GELU, false, false, true>(a, persistent, st);
       case EPI_GELU_Q: return a.csc != nullptr && a.N % 128 == 0 ? launch<EPI_GELU_Q, false, false, true>(a, persistent, st) : MVF_ERR_ARG;
-      case EPI_RESID: return launch<EPI_RESID, false, false, true>(a, persistent, st);
+      case EPI_RESID:
+        return a.radd2 != nullptr ? launch<EPI_RESID, false, false, true, 0, true>(a, persistent, st)
+                                  : launch<EPI_RESID, false, false, true>(a, persistent, st);
     }
     return MVF_ERR_ARG;
   }

@@ -66,7 +66,8 @@ template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_mxfp8_kernel(const float* __restrict__ x, size_t in_stride,
                                                               const float* __restrict__ g, const float* __restrict__ b,
                                                               unsigned char* __restrict__ q, size_t ldq,
-                                                              unsigned* __restrict__ scales, int rows, int D, float eps) {
+                                                              unsigned* __restrict__ scales, int rows, int D, float eps,
+                                                              const bf16_t* __restrict__ add, size_t add_stride) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;     // whole wave
@@ -79,6 +80,11 @@ __global__ __launch_bounds__(256) void layernorm_mxfp8_kernel(const float* __res
     const int e = lane + i * 64;
     if (e < nv) {
       v[i] = *reinterpret_cast<const float4*>(xr + e * 4);
+      if (add != nullptr) {     // the deferred attention-branch output (vit_fwd.hip): the row normalised is x + add
+        const uint2 u = *reinterpret_cast<const uint2*>(add + (size_t)row * add_stride + e * 4);
+        v[i].x += __uint_as_float(u.x << 16); v[i].y += __uint_as_float(u.x & 0xffff0000u);
+        v[i].z += __uint_as_float(u.y << 16); v[i].w += __uint_as_float(u.y & 0xffff0000u);
+      }
       s += v[i].x + v[i].y + v[i].z + v[i].w;
     }
   }
@@ -138,14 +144,16 @@ int mvf_quant_mxfp8_impl(int in_dtype, const void* x, size_t ldx, void* q, size_
 }
 
 int mvf_layernorm_mxfp8_impl(const float* x, size_t in_stride, const float* g, const float* b, void* q, size_t ldq,
-                             unsigned* scales, int rows, int D, float eps, hipStream_t st) {
+                             unsigned* scales, int rows, int D, float eps, hipStream_t st, const void* add_bf16, size_t add_stride) {
   MVF_CHECK_ARG(x && g && b && q && scales && rows > 0 && D > 0 && D % 256 == 0 && D <= 64 * 4 * 8 && ldq % 4 == 0);
+  MVF_CHECK_ARG(add_stride % 4 == 0 && ((uintptr_t)add_bf16 % 8) == 0);
+  const bf16_t* add = (const bf16_t*)add_bf16;
   const dim3 grid((rows + 3) / 4);
   unsigned char* qq = (unsigned char*)q;
   if (D <= 1024)
-    hipLaunchKernelGGL(layernorm_mxfp8_kernel<4>, grid, dim3(256), 0, st, x, in_stride, g, b, qq, ldq, scales, rows, D, eps);
+    hipLaunchKernelGGL(layernorm_mxfp8_kernel<4>, grid, dim3(256), 0, st, x, in_stride, g, b, qq, ldq, scales, rows, D, eps, add, add_stride);
   else
-    hipLaunchKernelGGL(layernorm_mxfp8_kernel<8>, grid, dim3(256), 0, st, x, in_stride, g, b, qq, ldq, scales, rows, D, eps);
+    hipLaunchKernelGGL(layernorm_mxfp8_kernel<8>, grid, dim3(256), 0, st, x, in_stride, g, b, qq, ldq, scales, rows, D, eps, add, add_stride);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }
@@ -156,5 +164,5 @@ extern "C" int mvf_quant_mxfp8(int in_dtype, const void* x, size_t ldx, void* q,
 }
 extern "C" int mvf_layernorm_mxfp8(const float* x, size_t in_stride, const float* g, const float* b, void* q, size_t ldq,
                                    unsigned* scales, int rows, int D, float eps, hipStream_t st) {
-  return mvf_layernorm_mxfp8_impl(x, in_stride, g, b, q, ldq, scales, rows, D, eps, st);
+  return mvf_layernorm_mxfp8_impl(x, in_stride, g, b, q, ldq, scales, rows, D, eps, st, nullptr, 0);
 }

@@ -47,6 +47,8 @@ struct Fp8Scales {   // non-null: MX-fp8 operands (mvf_gemm_fp8_impl)
   const unsigned* sa;
   const unsigned* sw;
   unsigned* csc;       // epi 1: quantise the output too (C = e4m3 bytes, csc its block scales), or NULL
+  const void* addend2; // epi 2: the deferred attention-branch output (bf16 [M, ld2]), or NULL
+  int ld2;
 };
 
 int timed_gemm(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
@@ -73,7 +75,8 @@ int timed_gemm(int dtype, int epi, const void* A, int lda, const void* W, int ld
     (void)hipEventRecord(g_prof.ev[2 * slot], st);
   }
   const int rc = f8 != nullptr
-                     ? mvf_gemm_fp8_impl(epi, A, lda, f8->sa, W, ldw, f8->sw, bias, C, ldc, f8->csc, resid, ldr, tap, ldt, ls, tpf, M, N, K, st)
+                     ? mvf_gemm_fp8_impl(epi, A, lda, f8->sa, W, ldw, f8->sw, bias, C, ldc, f8->csc, resid, ldr, tap, ldt, ls, tpf, M, N, K, st,
+                                         f8->addend2, f8->ld2)
                      : mvf_gemm_tc_impl(dtype, epi, A, lda, W, ldw, bias, C, ldc, resid, ldr, tap, ldt, pos, ls, tpf, M, N, K, st, 0,
                                         0, ln);
   if (rec) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
@@ -98,6 +101,7 @@ size_t carve(int dtype, int fc, int N, int D, int P, Ws* w, char* base) {
   char* delta = nullptr;
   char* stats = nullptr;
   char* mr = nullptr;
+  if (dtype == MVF_FP8 && D % 64 == 0) delta = take(Mc * D * 2);
   if (dtype == MVF_BF16 && D % 64 == 0) {
     xb = take(Mc * D * 2);
     delta = take(Mc * D * 2);
@@ -182,16 +186,25 @@ extern "C" int mvf_vit_fwd_x(const MvfVitWeights* w, int dtype, const float* fra
         // directly; the attention output is bf16 and goes through mvf_quant_mxfp8)
         void* tap_ptr = nullptr;
         if (tap >= 0 && taps_out && taps_out[tap]) tap_ptr = (char*)taps_out[tap] + (size_t)f0 * np * D * 2;
-        const Fp8Scales sq = {ws.hs, w->qkv_s[l], nullptr}, sp = {ws.hs, w->proj_s[l], nullptr},
-                        s1 = {ws.hs, w->fc1_s[l], ws.hids}, s2 = {ws.hids, w->fc2_s[l], nullptr};
+        // deferred residual as in the bf16 path below (LayerScale models: the packer folds gamma_1 into proj's weights and bias
+        // and leaves ls1 NULL)
+        const bool defer8 = g_proj_defer && ws.delta != nullptr && w->ls1 == nullptr;
+        const Fp8Scales sq = {ws.hs, w->qkv_s[l], nullptr, nullptr, 0}, sp = {ws.hs, w->proj_s[l], nullptr, nullptr, 0},
+                        s1 = {ws.hs, w->fc1_s[l], ws.hids, nullptr, 0},
+                        s2 = {ws.hids, w->fc2_s[l], nullptr, defer8 ? ws.delta : nullptr, D};
         RUN(mvf_layernorm_mxfp8_impl(ws.x, D, w->ln1_w[l], w->ln1_b[l], ws.hq, D, ws.hs, Mc, D, w->ln_eps, st));
         RUN(timed_gemm(dtype, EPI_STORE, ws.hq, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0, nullptr,
                        nullptr, N, Mc, 3 * D, D, st, nullptr, &sq));
         RUN(mvf_vit_attn_impl(dtype, ws.qkv, ws.h, fc, N, H, D, attn_variant, st));
         RUN(mvf_quant_mxfp8_impl(MVF_BF16, ws.h, D, ws.hq, D, ws.hs, Mc, D, st));
-        RUN(timed_gemm(dtype, EPI_RESID, ws.hq, D, w->proj_w[l], D, w->proj_b[l], nullptr, 0, ws.x, D, nullptr, 0, nullptr,
-                       w->ls1 ? w->ls1[l] : nullptr, N, Mc, D, D, st, nullptr, &sp));
-        RUN(mvf_layernorm_mxfp8_impl(ws.x, D, w->ln2_w[l], w->ln2_b[l], ws.hq, D, ws.hs, Mc, D, w->ln_eps, st));
+        if (defer8)
+          RUN(timed_gemm(dtype, EPI_STORE, ws.hq, D, w->proj_w[l], D, w->proj_b[l], ws.delta, D, nullptr, 0, nullptr, 0, nullptr,
+                         nullptr, N, Mc, D, D, st, nullptr, &sp));
+        else
+          RUN(timed_gemm(dtype, EPI_RESID, ws.hq, D, w->proj_w[l], D, w->proj_b[l], nullptr, 0, ws.x, D, nullptr, 0, nullptr,
+                         w->ls1 ? w->ls1[l] : nullptr, N, Mc, D, D, st, nullptr, &sp));
+        RUN(mvf_layernorm_mxfp8_impl(ws.x, D, w->ln2_w[l], w->ln2_b[l], ws.hq, D, ws.hs, Mc, D, w->ln_eps, st,
+                                     defer8 ? ws.delta : nullptr, D));
         // fc1 + GELU with the MX-fp8 quantisation in its epilogue: hidq / hids straight out of the GEMM (no bf16 hid)
         RUN(timed_gemm(dtype, EPI_GELU, ws.hq, D, w->fc1_w[l], D, w->fc1_b[l], ws.hidq, 4 * D, nullptr, 0, nullptr, 0, nullptr,
                        nullptr, N, Mc, 4 * D, D, st, nullptr, &s1));

@@ -565,7 +565,7 @@ class _ViTBlockTC(torch.autograd.Function):
                 bf16 flash-attention backward, LayerNorm backward with the residual gradient added in the same pass.
     Parameter gradients are fp32 and go straight into the flat-gradient slots when every parameter has one."""
 
-    MC = 2048      # tokens per split-K chunk of the weight gradients
+    MC = int(os.environ.get('MVF_BLOCK_MC', '2048'))      # tokens per split-K chunk of the weight gradients
 
     @staticmethod
     def _bf(dev, *shape):
@@ -1154,11 +1154,14 @@ class PackedViT:
             self.keep.append(arr)
             return ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p))
 
-        def mx_tables(fmt):
-            """Frozen weights [N, K] -> MX-fp8 (e4m3 bytes + E8M0 block scales [K/128][N]) with the device quantiser, once."""
+        def mx_tables(fmt, row_scale=None):
+            """Frozen weights [N, K] -> MX-fp8 (e4m3 bytes + E8M0 block scales [K/128][N]) with the device quantiser, once.
+            row_scale: per-layer key of a [N] vector multiplied into the rows first (LayerScale folded into proj)."""
             wp, sp = [], []
             for i in range(depth):
                 W = sd[fmt % i].detach().float().contiguous()
+                if row_scale is not None:
+                    W = (W * sd[row_scale % i].detach().float()[:, None]).contiguous()
                 n, k = W.shape
                 if k % 256 != 0:
                     raise _lib.MvfError('fp8 mode needs GEMM K %% 256 == 0 (got %d)' % k)
@@ -1189,13 +1192,27 @@ class PackedViT:
 
         fold = int(VIT_LN_FOLD if ln_fold is None else ln_fold) if (self.code == BF16 and dim % 128 == 0 and depth > 0) else 0
         self.ln_fold = fold
+        # Deferred residual of the attention branch (csrc/vit_fwd.hip) for LayerScale models: x + gamma_1 (.) (o W^T + b) =
+        # x + o (gamma_1 (.) W)^T + gamma_1 (.) b -- gamma_1 goes into proj's weights and bias here and ls1 stays NULL, so the
+        # device takes the deferred path (plain-store proj, branch output added in LayerNorm 2 and the fc2 epilogue)
+        has_ls = 'blocks.0.ls1.gamma' in sd
+        self.ls1_folded = bool(has_ls and depth > 0 and self.code in (BF16, FP8) and dim % 128 == 0 and fold not in (1, 3)
+                               and os.environ.get('MVF_PROJ_DEFER', '1') != '0')
+
+        def proj_w(t, i):
+            return t * sd['blocks.%d.ls1.gamma' % i].detach().to(t.dtype)[:, None] if self.ls1_folded else t
+
+        def proj_b(t, i):
+            return t * sd['blocks.%d.ls1.gamma' % i].detach().to(t.dtype) if self.ls1_folded else t
         w.ln1_w, w.ln1_b = table('blocks.%d.norm1.weight', f32), table('blocks.%d.norm1.bias', f32)
-        w.proj_b, w.fc2_b = table('blocks.%d.attn.proj.bias', f32), table('blocks.%d.mlp.fc2.bias', f32)
+        w.proj_b = ptr_table([f32(proj_b(sd['blocks.%d.attn.proj.bias' % i].detach().float(), i)) for i in range(depth)])
+        w.fc2_b = table('blocks.%d.mlp.fc2.bias', f32)
         w.ln2_w, w.ln2_b = table('blocks.%d.norm2.weight', f32), table('blocks.%d.norm2.bias', f32)
         if self.code != FP8:
-            w.proj_w, w.fc2_w = table('blocks.%d.attn.proj.weight', mat), table('blocks.%d.mlp.fc2.weight', mat)
+            w.proj_w = ptr_table([mat(proj_w(sd['blocks.%d.attn.proj.weight' % i].detach().float(), i)) for i in range(depth)])
+            w.fc2_w = table('blocks.%d.mlp.fc2.weight', mat)
         if self.code == FP8:
-            w.proj_w, w.proj_s = mx_tables('blocks.%d.attn.proj.weight')
+            w.proj_w, w.proj_s = mx_tables('blocks.%d.attn.proj.weight', 'blocks.%d.ls1.gamma' if self.ls1_folded else None)
             w.fc2_w, w.fc2_s = mx_tables('blocks.%d.mlp.fc2.weight')
             w.qkv_w, w.qkv_s = mx_tables('blocks.%d.attn.qkv.weight')
             w.fc1_w, w.fc1_s = mx_tables('blocks.%d.mlp.fc1.weight')
@@ -1209,8 +1226,10 @@ class PackedViT:
                 w.fc1_w, w.fc1_b, w.fc1_c = folded('mlp.fc1', 'norm2', skip0=False)
             else:
                 w.fc1_w, w.fc1_b = table('blocks.%d.mlp.fc1.weight', mat), table('blocks.%d.mlp.fc1.bias', f32)
-        if 'blocks.0.ls1.gamma' in sd:
-            w.ls1, w.ls2 = table('blocks.%d.ls1.gamma', f32), table('blocks.%d.ls2.gamma', f32)
+        if has_ls:
+            if not self.ls1_folded:
+                w.ls1 = table('blocks.%d.ls1.gamma', f32)
+            w.ls2 = table('blocks.%d.ls2.gamma', f32)
         self.struct = w
         self.ws = {}
         self.ws_key = None

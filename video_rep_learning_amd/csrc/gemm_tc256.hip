@@ -53,6 +53,9 @@
 //  * tried and rejected (round 2): waiting for every half-tile as late as legal (counted vmcnt(10) in P0 / P1 / P3: five
 //    half-tiles in flight instead of three; MVF_GEMM_DEEP) -- K loop 36.5 k -> 37.9 k ticks; the loop is not feed-bound
 //    (timing ablations: DESIGN.md section 4, tools/gemm_stamps.py ABL=...).
+//  * tried and rejected (round 2): every second workgroup of an XCD sleeping 0.15 .. 0.65 of a tile time before its first tile
+//    (fc2, K = 3072) so that the read-modify epilogues of half the chip meet the other half's K loops instead of each other:
+//    306.5 -> 307 .. 313 us.
 //  * XCD-aware tile walk: workgroups b, b+8, ... share an XCD (round-robin dispatch, speed only); group x = b & 7 owns a
 //    contiguous chunk of the tile list (tiles of one A row-panel are neighbours).  A workgroup's FIRST tile is static
 //    (chunk start + b/8); every further tile is a ticket from the group's counter (a.sched, agent-scope atomic), so a

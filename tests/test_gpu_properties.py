@@ -28,10 +28,11 @@ def _packed(dtype='bf16'):
     return ops.PackedViT({k: v.to(DEV) for k, v in w.items()}, DEPTH, DIM, HEADS, PATCH, IMG, TAPS, dtype)
 
 
-def test_backbone_is_frame_permutation_equivariant_and_split_invariant_at_256_frames():
+@pytest.mark.parametrize('dtype', ['bf16', 'fp8'])
+def test_backbone_is_frame_permutation_equivariant_and_split_invariant_at_256_frames(dtype):
     F = 256
     np_ = (IMG // PATCH) ** 2
-    pk = _packed()
+    pk = _packed(dtype)
     g = torch.Generator().manual_seed(31)
     x = torch.randn(F, 3, IMG, IMG, generator=g).to(DEV)
     perm = torch.randperm(F, generator=g).to(DEV)

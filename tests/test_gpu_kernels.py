@@ -79,10 +79,10 @@ def test_gemm_tc256_equals_tc128_bitwise(M, N, K, epi):
         return Cd, R, tap
 
     ref = run(1)
-    for rep in range(7):
-        # persistent / one workgroup per tile / the automatic choice (product form: whole rounds on the 256x256 kernel, the
-        # rows of a mostly empty last round on the 128x128 kernel)
-        got = run(0 if rep == 6 else (2 if rep % 2 == 0 else 3))
+    for rep, variant in enumerate((2, 3, 4, 5, 4, 3, 0)):
+        # persistent with the tile rows chosen per launch / one workgroup per tile / persistent with 224-row tiles / with 256-row
+        # tiles / the automatic choice of the product
+        got = run(variant)
         for x, y, what in zip(got, ref, ('C', 'resid', 'tap')):
             if x is not None:
                 assert torch.equal(x, y), 'gemm_tc256 != gemm_tc128 (%s, repeat %d): max diff %g' % (
@@ -125,7 +125,7 @@ def test_gemm_ln_fold_producer_epilogue(M, N, K, layerscale):
         check(stats[..., 1].t(), (xs * xs).sum(-1), 1e-5, 'partial sums of squares')
         if tap is not None:
             assert torch.equal(tap, xb.view(M // tpf, tpf, N)[:, 1:].reshape(-1, N))
-    for variant in (1, 2):     # pinned 128x128 / pinned 256x256: residual, xb AND the partial sums bit for bit the automatic run's
+    for variant in (1, 2, 4, 5):     # pinned 128x128 / 256-thread kernel (auto, 224-row, 256-row tiles): residual, xb AND the partial sums bit for bit the automatic run's
         _lib.call('mvf_gemm_tc_select', variant)
         try:
             x2 = x0.clone()
@@ -173,8 +173,9 @@ def test_gemm_ln_fold_consumer_epilogue(M, N, K, epi):
         e_same, e_ln = relerr(C.float(), ref_same), rel_l2(C.float(), ref_ln)
         assert e_same <= 4.5e-3, e_same          # one bf16 ulp of the largest output
         assert e_ln <= 1e-2, e_ln
-    # the 128x128 kernel (which takes the rows of a mostly empty last round) and the 256x256 kernel agree bit for bit
-    for variant in (1, 2):
+    # the 128x128 kernel (which takes the rows of a mostly empty last round) and the 256x256 kernel (tile rows chosen per launch,
+    # 224, 256) agree bit for bit
+    for variant in (1, 2, 4, 5):
         _lib.call('mvf_gemm_tc_select', variant)
         try:
             C2 = torch.full((M, N), 7.0, device=DEV, dtype=torch.bfloat16)
@@ -521,7 +522,7 @@ def test_deferred_residual_layernorm_add_and_second_addend(M, D, K):
     want = x.double() + A.double() @ W.double().t() + b.double() + delta.double()
     Ad, Wd, bb = A.to(DEV), W.to(DEV), b.to(DEV)
     outs = []
-    for variant in (2, 1):       # 256x256 persistent kernel, 128x128 kernel
+    for variant in (2, 1, 4, 5):       # persistent kernel (auto / 224-row / 256-row tiles), 128x128 kernel
         _lib.call('mvf_gemm_tc_select', variant)
         r = x.clone().to(DEV)
         _lib.call('mvf_gemm_tc_resid2', Ad.data_ptr(), K, Wd.data_ptr(), K, bb.data_ptr(), r.data_ptr(), D, dd.data_ptr(), D, None, 0,
@@ -530,7 +531,7 @@ def test_deferred_residual_layernorm_add_and_second_addend(M, D, K):
         outs.append(r)
         check(r, want, 2e-5, 'resid + A W^T + b + delta (variant %d)' % variant)
     _lib.call('mvf_gemm_tc_select', 0)
-    assert torch.equal(outs[0], outs[1])
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
 @pytest.mark.parametrize('F,N,H', [(3, 197, 2), (2, 257, 2), (1, 50, 1), (2, 577, 1), (1, 224, 1), (1, 225, 3)])

@@ -24,7 +24,7 @@ SHAPES = {'qkv': (2304, 768, 0), 'proj': (768, 768, 0), 'fc1': (3072, 768, 1), '
 
 def main():
     p = argparse.ArgumentParser()
-    p.add_argument('--variant', type=int, default=2)
+    p.add_argument('--variant', type=int, default=2)      # 2 tile rows per launch, 4 = 224-row tiles, 5 = 256-row tiles, 1 = 128x128 kernel
     p.add_argument('--shapes', default='qkv,proj,fc1,fc2')
     p.add_argument('--frames', type=int, default=256)
     p.add_argument('--iters', type=int, default=20)

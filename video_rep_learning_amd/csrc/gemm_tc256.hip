@@ -134,9 +134,16 @@ __device__ __forceinline__ void mfma_mx(f32x4_t& acc, const i32x8_t& w, const i3
 // wave, issued with A1 (same distance to its consumer, so the counted vmcnt(6) still leaves exactly three half-tiles in flight).
 // ADD2: EPI_RESID with the second, bf16 addend (a.radd2): an instantiation of its own, one accumulator row per fetch batch,
 // so that the plain read-modify epilogues keep their register budget (the run-time form spilled two registers in both)
-template <int EPI, bool DBG, bool LN, bool FP8, int ABL = 0, bool ADD2 = false>   // ABL: timing ablations (dbg_abl)
+// BMT: rows of a tile, 256 or 224.  224 = the same schedule with three instead of four 16-row fragments in the second m-quadrant
+// of each wave row (wave rows of 112 rows: A1 holds 48 live rows per wave row, its P2 / P3 issue 12 MFMAs instead of 16).  The
+// launch picks it where ceil(tiles / workgroups) x BMT is smaller: the N = 768 GEMMs of 50 432 rows are 591 tiles = 2.31 rounds at
+// 256 rows and 678 tiles = 2.65 rounds at 224 -- three rounds either way, of 12.5 % less work each.
+template <int EPI, bool DBG, bool LN, bool FP8, int ABL = 0, bool ADD2 = false, int BMT = 256>   // ABL: timing ablations (dbg_abl)
 __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(BMT == 256 || BMT == 224, "tile rows");
+  constexpr int WRS = BMT / 2;              // rows of a wave row (128 / 112)
+  constexpr int RT1 = (WRS - 64) / 16;      // 16-row fragments of the second m-quadrant (4 / 3)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
 
   // ---- static tile walk: XCD x (= blockIdx & 7) owns tiles [start, end); its workgroups take them round-robin ----
   const int nbn = (a.N + BN - 1) / BN;
-  const int ntiles = ((a.M + BM - 1) / BM) * nbn;
+  const int ntiles = ((a.M + BMT - 1) / BMT) * nbn;
   const int nwg = gridDim.x;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int bpx = (nwg - xcd + 7) >> 3;            // workgroups on this XCD
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   const unsigned* const sbase = wave < 4 ? a.sa : a.sw;
   const unsigned sstride = wave < 4 ? (unsigned)a.M : (unsigned)a.N;
   auto set_sources = [&](int tile) {
-    const int tm0 = (tile / nbn) * BM, tn0 = (tile % nbn) * BN;
+    const int tm0 = (tile / nbn) * BMT, tn0 = (tile % nbn) * BN;
     if constexpr (FP8)
       ssrc = wave < 4 ? (unsigned)min(tm0 + wave * 64 + lane, a.M - 1) : (unsigned)min(tn0 + (wave - 4) * 64 + lane, a.N - 1);
     // stacked batches (split-K weight gradients): the tile's batch picks its own row block of W
@@ -217,7 +224,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int r = (i * 8 + wave) * 8 + prow;                 // row inside the half-tile, 0..127
-        const int am = (r >> 6) * 128 + h * 64 + (r & 63);       // A: wave row r>>6, m-quadrant h
+        // A: wave row r>>6, m-quadrant h (BMT 224: rows 48 .. 63 of quadrant 1 are not part of the tile; they re-read row 47)
+        const int am = (r >> 6) * WRS + h * 64 + min(r & 63, h ? RT1 * 16 - 1 : 63);
         const int wn = (r >> 5) * 64 + h * 32 + (r & 31);        // W: wave column r>>5, n-quadrant h
         int gm = min(tm0 + am, a.M - 1);
         if constexpr (DBG) gm &= (int)a.dbg_rowmask;
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
         __builtin_amdgcn_global_load_lds(GLB_PTR(a.ln_c + n), LDS_PTR(slnc), 4, 0, 0);
         // rows m0 .. m0+255 as 512 consecutive floats; this wave copies floats [64 w, 64 w + 64) = rows m0 + 32 w ..
         const int fi = wave * 64 + lane;
-        const int row = min((tile / nbn) * BM + (fi >> 1), a.M - 1);
+        const int row = min((tile / nbn) * BMT + (fi >> 1), a.M - 1);
         __builtin_amdgcn_global_load_lds(GLB_PTR(a.ln_mr + (size_t)row * 2 + (fi & 1)),
                                          LDS_PTR(smem + LNMR_OFF + tpar * 2048 + wave * 256), 4, 0, 0);
       }
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   }
 #define LOAD_A(OFF)                                                                                          \
   if constexpr ((ABL & 2) == 0)                                                                              \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \
+  _Pragma("unroll") for (int i = 0; i < ((OFF) == OFF_A1 ? RT1 : 4); ++i) {                                   \
     if constexpr (FP8) {                                                                                     \
       afq[i].lo = *reinterpret_cast<const i32x4_t*>(base + (OFF) + a_rd + i * 16 * ROWB);                    \
       afq[i].hi = *reinterpret_cast<const i32x4_t*>(base + (OFF) + (a_rd ^ KS1) + i * 16 * ROWB);            \
@@ -363,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
       mfma_mx(acc[(MQ) * 4 + i][(NQ) * 2 + j], BQ[j], afq[i], SF[j], sfa[i]);                                \
   } else {                                                                                                   \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+    _Pragma("unroll") for (int i = 0; i < ((MQ) == 1 ? RT1 : 4); ++i)                                         \
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
       acc[(MQ) * 4 + i][(NQ) * 2 + j] =                                                                      \
           __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][ks], af[i][ks], acc[(MQ) * 4 + i][(NQ) * 2 + j], 0, 0, 0); \
@@ -456,7 +464,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   for (;;) {
     int lid_next = dyn ? 0x7fffffff : lid + bpx;   // dyn: known from K tile 1 on (see K_TILE)
     bool have_next = lid_next < end;
-    const int m0 = (lid / nbn) * BM, n0 = (lid % nbn) * BN;   // compute-side tile
+    const int m0 = (lid / nbn) * BMT, n0 = (lid % nbn) * BN;   // compute-side tile
     int kwrap = 0;
     if (wr == 1) WG_BARRIER();  // stagger: wave row 1 runs one barrier behind wave row 0
 
@@ -508,7 +516,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
 #pragma unroll
         for (int ii = 0; ii < EB; ++ii) {
           const int i = b * EB + ii;
-          const int m = m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + frow;
+          if (i >= 4 + RT1) continue;            // (BMT 224: the wave row's eighth 16-row fragment does not exist)
+          const int m = m0 + wr * WRS + (i >> 2) * 64 + (i & 3) * 16 + frow;
           epilogue_prefetch<EPI>(a, m, m < a.M, n0 + wc * 64, fgrp, add[MVF_EPI_PIPE ? (b & 1) : 0][ii]);
           if constexpr (ADD2) epilogue_prefetch2(a, m, m < a.M, n0 + wc * 64, fgrp, add2[ii]);
         }
@@ -519,12 +528,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
       // from this tile's LDS slot, the wave's 64 ln_c values from its own slot), then the plain epilogue with bias = d.
       // Done inside the store loop instead, the extra live values (c, mean/rstd) sat on top of the GELU temporaries and the
       // fc1 epilogue took twice as long.
-      const char* smr = smem + LNMR_OFF + tpar * 2048 + (wr * 128 + frow) * 8;
+      const char* smr = smem + LNMR_OFF + tpar * 2048 + (wr * WRS + frow) * 8;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {     // column tile outermost: 4 ln_c values live at a time, (mean, rstd) re-read per row
         const float4 c = *reinterpret_cast<const float4*>(slnc + (j * 16 + fgrp * 4) * 4);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4 + RT1; ++i) {
           const float2 mr = *reinterpret_cast<const float2*>(smr + ((i >> 2) * 64 + (i & 3) * 16) * 8);
           const float nm = -mr.x;
           acc[i][j][0] = mr.y * fmaf(nm, c.x, acc[i][j][0]);
@@ -545,7 +554,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
 #pragma unroll
       for (int ii = 0; ii < EB; ++ii) {
         const int i = ih * EB + ii;
-        const int m = m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + frow;
+        if (i >= 4 + RT1) continue;
+        const int m = m0 + wr * WRS + (i >> 2) * 64 + (i & 3) * 16 + frow;
         if constexpr (ADD2) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) addb[ii][j] = add_bf16x4(addb[ii][j], add2[ii][j]);
@@ -673,24 +683,46 @@ unsigned* sched_slot() {
   return ring == nullptr ? nullptr : ring + (size_t)(next.fetch_add(1) & 1023u) * 16;
 }
 
-template <int EPI, bool DBG = false, bool LN = false, bool FP8 = false, int ABL = 0, bool ADD2 = false>
-int launch(const GemmTcArgs& a0, bool persistent, hipStream_t st) {
+template <int EPI, bool DBG = false, bool LN = false, bool FP8 = false, int ABL = 0, bool ADD2 = false, int BMT = 256>
+int launch_bm(const GemmTcArgs& a0, bool persistent, hipStream_t st) {
   GemmTcArgs a = a0;
   static const bool force_static = getenv("MVF_GEMM_STATIC") != nullptr;   // A/B measurements only
   a.sched = persistent && !force_static ? sched_slot() : nullptr;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2, BMT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
-  const int ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  const int ntiles = ((a.M + BMT - 1) / BMT) * ((a.N + BN - 1) / BN);
   // persistent: one workgroup per CU (a multiple of 8 so that every XCD gets the same number); otherwise (A/B
   // measurements) one workgroup per tile -- the same kernel, every workgroup then runs the cold prologue
   const int grid = persistent ? std::min(ntiles, std::max(8, num_cus() & ~7)) : ntiles;
-  hipLaunchKernelGGL((gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2>), dim3(grid), dim3(512), LDS_BYTES, st, a);
+  hipLaunchKernelGGL((gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2, BMT>), dim3(grid), dim3(512), LDS_BYTES, st, a);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
+}
+
+// tile rows: MVF_GEMM_BM = 256 | 224 pins them (A/B measurements, tests through mvf_gemm_tc_select 4 / 5), otherwise 224 where
+// ceil(tiles / workgroups) x rows comes out smaller (persistent launches; the fp8, stamped and stacked-batch forms keep 256)
+int g_bm_mode = [] { const char* e = getenv("MVF_GEMM_BM"); return e ? atoi(e) : 0; }();
+
+template <int EPI, bool DBG = false, bool LN = false, bool FP8 = false, int ABL = 0, bool ADD2 = false>
+int launch(const GemmTcArgs& a, bool persistent, hipStream_t st) {
+  if constexpr (!DBG && !FP8) {
+    bool use224 = false;
+    if (a.batch_rows == 0 && g_bm_mode != 256) {
+      if (g_bm_mode == 224) {
+        use224 = true;
+      } else if (persistent) {
+        const long nwg = std::max(8, num_cus() & ~7), nbn = (a.N + BN - 1) / BN;
+        const long r256 = (((a.M + 255) / 256) * nbn + nwg - 1) / nwg, r224 = (((a.M + 223) / 224) * nbn + nwg - 1) / nwg;
+        use224 = r224 * 224 * 27 < r256 * 256 * 25;     // an 8 % margin: a 224-row tile re-uses its W fragments over fewer rows
+      }
+    }
+    if (use224) return launch_bm<EPI, DBG, LN, FP8, ABL, ADD2, 224>(a, persistent, st);
+  }
+  return launch_bm<EPI, DBG, LN, FP8, ABL, ADD2, 256>(a, persistent, st);
 }
 
 }  // namespace
@@ -704,6 +736,7 @@ extern "C" int mvf_gemm_tc_set_cus(int n) {
 }
 
 int mvf_gemm_tc256_num_wgs() { return std::max(8, num_cus() & ~7); }
+void mvf_gemm_tc256_set_bm(int bm) { g_bm_mode = bm; }
 
 int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, bool persistent, hipStream_t st) {
   const bool fp8 = a.sa != nullptr;

@@ -371,4 +371,5 @@ __device__ __forceinline__ unsigned epilogue_pair_gelu_q(const GemmTcArgs& a, in
 
 // gemm_tc256.hip: bf16, K % 128 == 0.  Same contract as the 128x128 kernel's launch.
 int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, bool persistent, hipStream_t st);
+void mvf_gemm_tc256_set_bm(int bm);   // 0 = per launch, 224 / 256 = pinned tile rows
 int mvf_gemm_tc256_num_wgs();   // workgroups of a persistent launch (one per CU of the stream's budget, a multiple of 8)

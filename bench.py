@@ -43,13 +43,22 @@ GEMM_NAMES = {(0, 2304, 768): 'qkv [M,768]x[2304,768]^T', (2, 768, 768): 'proj+r
 PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
 
 
-def rocprof_names(groups, dtype, ln_fold, defer=True):
-    """The same launches under the kernel names rocprofv3 prints, gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2>: one kernel
-    per epilogue flavour.  LN = true for the launches that carry the LN-fold extras: of a shape's 12 launches per forward, 11 in
-    fold mode 2 for qkv (blocks 1..11 consume the folded norm1) and for fc2 (blocks 0..10 produce bf16(x) + the row sums); 12
-    for fc1 / proj in the modes that fold norm2.  ADD2 = true for fc2 when the attention branch's residual add is deferred
-    (then proj is a plain store, <0, ...>, the name it shares with block 0's unfolded qkv).  Averages are per shape group
-    (HIP events cannot tell the two names of one shape apart)."""
+def tile_rows(M, N, nwg=256):
+    """The 256x256-thread kernel's tile rows for an [M, N] output (csrc/gemm_tc256.hip launch<>): 224 where the last round gets at
+    least 8 % shorter, else 256."""
+    nbn = (N + 255) // 256
+    r256 = -(-(-(-M // 256) * nbn) // nwg)
+    r224 = -(-(-(-M // 224) * nbn) // nwg)
+    return 224 if r224 * 224 * 27 < r256 * 256 * 25 else 256
+
+
+def rocprof_names(groups, dtype, ln_fold, defer=True, frames=256, tokens=197):
+    """The same launches under the kernel names rocprofv3 prints, gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2, BMT>: one
+    kernel per epilogue flavour and tile height.  LN = true for the launches that carry the LN-fold extras: of a shape's 12
+    launches per forward, 11 in fold mode 2 for qkv (blocks 1..11 consume the folded norm1) and for fc2 (blocks 0..10 produce
+    bf16(x) + the row sums); 12 for fc1 / proj in the modes that fold norm2.  ADD2 = true for fc2 when the attention branch's
+    residual add is deferred (then proj is a plain store, <0, ...>).  BMT = the tile rows the launch picks for the shape in the
+    one-lane mode these times are taken in.  Averages are per shape group (HIP events cannot tell two names of one shape apart)."""
     by = {}
     for r in groups:
         e = r['epi']
@@ -64,8 +73,9 @@ def rocprof_names(groups, dtype, ln_fold, defer=True):
             if (fc1 or proj) and ln_fold in (1, 3):
                 frac = 1.0
             add2 = 'true' if (fc2 and defer and ln_fold in (0, 2)) else 'false'
-            parts = [('gemm_tc256_kernel<%d, false, true, false, 0, %s>' % (e, add2), frac),
-                     ('gemm_tc256_kernel<%d, false, false, false, 0, %s>' % (e, add2), 1.0 - frac)]
+            bm = tile_rows(frames * (tokens - 1 if e == 3 else tokens), r['n'])
+            parts = [('gemm_tc256_kernel<%d, false, true, false, 0, %s, %d>' % (e, add2, bm), frac),
+                     ('gemm_tc256_kernel<%d, false, false, false, 0, %s, %d>' % (e, add2, bm), 1.0 - frac)]
         for k, f in parts:
             if f > 0:
                 d = by.setdefault(k, {'launches': 0.0, 'ms': 0.0})

@@ -44,12 +44,12 @@ PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
 
 
 def tile_rows(M, N, nwg=256):
-    """The 256x256-thread kernel's tile rows for an [M, N] output (csrc/gemm_tc256.hip launch<>): 224 where the last round gets at
-    least 8 % shorter, else 256."""
+    """The 256x256-thread kernel's tile rows for an [M, N] output (csrc/gemm_tc256.hip launch<>): 224 for launches of three or
+    more rounds on at most three tile columns whose last round gets at least 8 % shorter, else 256."""
     nbn = (N + 255) // 256
     r256 = -(-(-(-M // 256) * nbn) // nwg)
     r224 = -(-(-(-M // 224) * nbn) // nwg)
-    return 224 if r224 * 224 * 27 < r256 * 256 * 25 else 256
+    return 224 if (r256 >= 3 and nbn <= 3 and r224 * 224 * 27 < r256 * 256 * 25) else 256
 
 
 def rocprof_names(groups, dtype, ln_fold, defer=True, frames=256, tokens=197):

@@ -141,7 +141,7 @@ __device__ __forceinline__ void mfma_mx(f32x4_t& acc, const i32x8_t& w, const i3
 template <int EPI, bool DBG, bool LN, bool FP8, int ABL = 0, bool ADD2 = false, int BMT = 256>   // ABL: timing ablations (dbg_abl)
 __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  static_assert(BMT == 256 || BMT == 224, "tile rows");
+  static_assert(BMT == 256 || BMT == 224 || BMT == 192, "tile rows");   // (192 compiles and is correct; measured slower)
   constexpr int WRS = BMT / 2;              // rows of a wave row (128 / 112)
   constexpr int RT1 = (WRS - 64) / 16;      // 16-row fragments of the second m-quadrant (4 / 3)
   const int tid = threadIdx.x;
@@ -717,7 +717,10 @@ int launch(const GemmTcArgs& a, bool persistent, hipStream_t st) {
       } else if (persistent) {
         const long nwg = std::max(8, num_cus() & ~7), nbn = (a.N + BN - 1) / BN;
         const long r256 = (((a.M + 255) / 256) * nbn + nwg - 1) / nwg, r224 = (((a.M + 223) / 224) * nbn + nwg - 1) / nwg;
-        use224 = r224 * 224 * 27 < r256 * 256 * 25;     // an 8 % margin: a 224-row tile re-uses its W fragments over fewer rows
+        // an 8 % margin (a 224-row tile re-uses its W fragments over fewer rows), and only launches of three rounds or more
+        // on one to three tile columns: in the pipelined step (lane-sized launches of two rounds, another lane filling the
+        // tail) 224-row tiles measured 1 % slower, in a full-batch launch on its own 6 % faster (fc2)
+        use224 = r256 >= 3 && nbn <= 3 && r224 * 224 * 27 < r256 * 256 * 25;
       }
     }
     if (use224) return launch_bm<EPI, DBG, LN, FP8, ABL, ADD2, 224>(a, persistent, st);

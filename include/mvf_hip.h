@@ -150,9 +150,14 @@ int mvf_gemm_tc_batched_f32(const void* A, int lda, const void* W, int ldw, floa
 int mvf_gemm_tc_select(int variant);
 /* diagnostic: out[2b] = XCD id, out[2b+1] = HW_ID of workgroup b of a 1-D launch (placement study, never on the path) */
 int mvf_debug_xcc_map(int* out, int nblocks, int threads, int lds_bytes, hipStream_t stream);
-/* CUs available to the stream the GEMMs are launched on (CU-masked streams); 0 = all CUs of the device (default).
- * The persistent 256x256 kernel launches one workgroup per available CU. */
+/* CU budget of the persistent 256x256 kernel, which launches one workgroup per CU it may use and keeps it there for the whole
+ * launch (its 140 KiB of LDS and 2 x 256 VGPRs per SIMD leave no room for another workgroup): 0 = all CUs of the device
+ * (default).  A data-parallel run (utils/distributed.reserve_collective_cus) leaves 8 CUs -- one per XCD -- outside the
+ * budget so that RCCL's all-reduce / all-gather kernels (DDP / SyncBN of CARL_MVF/train.py:283-286) never wait for a GEMM
+ * launch to drain before they get a CU; also the CU count of a CU-masked stream. */
 int mvf_gemm_tc_set_cus(int n);
+/* *out = workgroups a persistent launch uses under the current budget (a multiple of 8, at least 8) */
+int mvf_gemm_tc_get_wgs(int* out);
 /* diagnostic build of the 256x256 kernel: per-block s_memtime stamps into buf[blocks][2][8] (NULL = off, the default) */
 int mvf_gemm_tc_debug_stamps(unsigned long long* buf);
 /* diagnostic, stamped build only: A rows are read as (row & mask), so A's footprint is mask + 1 rows (L2-resident feed rate) */

@@ -46,3 +46,36 @@ def test_bench_two_ranks_do_not_deadlock():
     j = _line(r.stdout)
     assert j['n_gpus'] == 2 and j['config']['parallelism'] == 'dp2' and j['value'] > 0
     assert 'cpu_baseline' not in j or j['cpu_baseline'] is None or True     # N > 1: no CPU leg is required
+
+
+def test_bench_forced_one_rank_rccl_group_reserves_cus_for_the_collectives():
+    """MVF_FORCE_REDUCER=1: a ONE-rank `nccl` (= RCCL) group with every collective of the data-parallel step issued, as the
+    driver's N > 1 runs issue them; the persistent GEMM must then run under the CU budget that leaves 8 CUs to RCCL."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MVF_FORCE_REDUCER='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--profile-steps', '1',
+                        '--no-cpu-baseline'], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r.stdout)
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert j['n_gpus'] == 1 and j['config']['gemm_cu_budget'] == cus - 8 and j['value'] > 0
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()      # does not initialise the GPU in this process
+
+
+@pytest.mark.skipif(_device_count() < 2, reason='needs two GPUs: `python bench.py --gpus 2` over RCCL, one rank per GPU')
+def test_bench_gpus_2_bare_over_rccl():
+    """`python bench.py --gpus 2` exactly as a user (or the driver, through torch.distributed.run) starts it on a multi-GPU
+    node: the script launches its own two ranks, backend nccl (= RCCL over xGMI)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2',
+                        '--profile-steps', '1'], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    j = _line(r.stdout)
+    assert j['n_gpus'] == 2 and j['config']['parallelism'] == 'dp2' and j['value'] > 0
+    assert isinstance(j['config']['gemm_cu_budget'], int)

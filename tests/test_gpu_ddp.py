@@ -145,7 +145,17 @@ def _forced_worker(rank, world, port, ret, gather):
     os.environ['MVF_FORCE_REDUCER'] = '1'
     try:
         from video_rep_learning_amd.utils import distributed as du
+        from video_rep_learning_amd import _lib
+        import ctypes
         assert du.collectives_active()
+        # the persistent GEMM's CU budget: all CUs by default, 8 fewer once the collectives are live
+        wgs = ctypes.c_int(0)
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        _lib.call('mvf_gemm_tc_get_wgs', ctypes.byref(wgs))
+        assert wgs.value == cus & ~7, (wgs.value, cus)
+        assert du.reserve_collective_cus() == cus - 8
+        _lib.call('mvf_gemm_tc_get_wgs', ctypes.byref(wgs))
+        assert wgs.value == (cus - 8) & ~7, (wgs.value, cus)
         launched = []
         real = dist.all_reduce
 

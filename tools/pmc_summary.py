@@ -14,7 +14,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import GEMM_NAMES  # noqa: E402
+from bench import GEMM_NAMES, gemm_source_sha  # noqa: E402
 
 ORDER = [('qkv', (0, 2304, 768)), ('proj', (0, 768, 768)), ('fc1', (1, 3072, 768)), ('fc2', (2, 768, 3072))]
 FRAMES, TOKENS = 256, 197
@@ -45,6 +45,8 @@ def main():
         hbm = (2.0 * fe[key] + wr[key]) * 1024.0
         res[GEMM_NAMES[key]] = {'fetch_size_kb': fe[key], 'write_size_kb': wr[key], 'hbm_bytes_per_launch': hbm,
                                 'algorithmic_bytes_per_launch': algo, 'ratio': round(hbm / algo, 3), 'M': M}
+    # ties the numbers to the kernel source they were measured on: bench.py reports `traffic: null` when the GEMM has changed
+    res['_source_sha'] = gemm_source_sha()
     print(json.dumps(res, indent=1))
 
 

@@ -23,11 +23,8 @@
 namespace {
 using namespace gemm_tc;
 int g_variant = 0;
-// Off by default: alone, the split takes 15 % off the N = 768 GEMMs of a half batch (fc2 156 -> 133 us at M = 25 216), but
-// inside the training step, where two backbone lanes and the head share the chip, it is SLOWER (12.58 vs 11.91 ms/step):
-// the many small 128x128 workgroups of one lane queue behind the other lane's persistent workgroups.  MVF_GEMM_TAIL_SPLIT=1
-// turns it on (tools/gemm_bench.py --variant 0).
-bool g_tail_split = getenv("MVF_GEMM_TAIL_SPLIT") != nullptr;
+// (a "tail split" -- the last, partly empty round of 256x256 tiles on this 128x128 kernel -- was measured in round 2:
+// -15 % on a lone N = 768 launch, +5 % on the training step, where the other backbone lane already fills that tail; removed)
 unsigned long long* g_dbg = nullptr;
 unsigned g_dbg_rowmask = 0x7fffffffu;
 int g_dbg_kt = -1;
@@ -53,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tc_kernel(GemmTcArgs a) {
   const int q8 = nwg >> 3, r8 = nwg & 7;
   const int xcd = blockIdx.x & 7;
   const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-  const int m0 = a.row0 + (lid / nbn) * BM;
+  const int m0 = (lid / nbn) * BM;
   const int n0 = (lid % nbn) * BN;
   const int nk = a.K / KE;
 
@@ -190,7 +187,7 @@ int launch(const GemmTcArgs& a, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
-  const int nbm = (a.M - a.row0 + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+  const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
   hipLaunchKernelGGL((gemm_tc_kernel<T, EPI, LN>), dim3(nbm * nbn), dim3(256), LDS_BYTES, st, a);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
@@ -240,7 +237,6 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
   a.dbg = g_dbg; a.dbg_rowmask = g_dbg_rowmask; a.dbg_kt = g_dbg_kt; a.dbg_abl = g_dbg_abl;
   a.sched = nullptr;   // set by the persistent gemm_tc256 launch
   a.batch_rows = batch_rows; a.w_batch_rows = w_batch_rows;
-  a.row0 = 0;
   a.xb = nullptr; a.ldxb = 0; a.stats = nullptr; a.ln_mr = nullptr; a.ln_c = nullptr;
   a.sa = nullptr; a.sw = nullptr; a.csc = nullptr;
   a.radd = resid;
@@ -269,30 +265,7 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
   }
   // bf16 with K a multiple of 128: the 256x256 8-phase kernel (gemm_tc256.hip); g_variant 1 pins the 128x128 kernel
   if (dtype == MVF_BF16 && g_variant != 1 && K % 128 == 0 && N % 32 == 0) {
-    // Tail split (automatic choice only): the persistent kernel runs one workgroup per CU, so T tiles take ceil(T / G) rounds
-    // and a last round that is mostly empty leaves the chip idle for a whole tile time (N = 768: 591 tiles on 256 CUs = 2.31
-    // rounds).  When the last round would be less than 60 % full, the row panels of the WHOLE rounds go to the 256x256 kernel
-    // and the remaining rows to the 128x128 kernel (4 x the workgroups, two per CU, a quarter of the work each): the two
-    // kernels are bit-identical in every epilogue (tests), so the split changes nothing but the time.
-    int m_split = 0;
-    if (g_variant == 0 && batch_rows == 0 && g_tail_split) {
-      const int G = std::max(8, mvf_gemm_tc256_num_wgs());
-      const int nbm = (M + 255) / 256, nbn = (N + 255) / 256;
-      const long tiles = (long)nbm * nbn;
-      const long full = tiles / G;
-      if (full >= 1 && tiles % G != 0 && (double)(tiles % G) < 0.6 * G) {
-        const int nbm1 = (int)(full * G / nbn);
-        if (nbm1 >= 1 && nbm1 < nbm) m_split = nbm1 * 256;
-      }
-    }
-    GemmTcArgs a1 = a;
-    if (m_split > 0) a1.M = m_split;
-    const int rc = mvf_gemm_tc256_launch(epi, a1, /*persistent=*/g_variant != 3, st);
-    if (rc == MVF_OK && m_split > 0) {
-      GemmTcArgs a2 = a;
-      a2.row0 = m_split;
-      return dispatch<bf16_t>(epi, a2, st);
-    }
+    const int rc = mvf_gemm_tc256_launch(epi, a, /*persistent=*/g_variant != 3, st);
     // operands of 4 GiB or more are beyond the 256x256 kernel's 32-bit offsets: the 128x128 kernel (64-bit addressing)
     // takes over unless the caller pinned the kernel or asked for stacked batches
     if (rc != MVF_ERR_UNSUPPORTED || g_variant >= 2 || batch_rows != 0) return rc;
@@ -318,7 +291,7 @@ int mvf_gemm_fp8_impl(int epi, const void* A, int lda, const unsigned* sa, const
   GemmTcArgs a;
   a.A = (const char*)A; a.W = (const char*)W; a.bias = bias; a.C = (char*)C; a.resid = resid; a.tap = (char*)tap;
   a.pos = nullptr; a.ls = ls; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.ldt = ldt; a.M = M; a.N = N; a.K = K; a.tpf = tpf;
-  a.dbg = nullptr; a.dbg_rowmask = 0x7fffffffu; a.dbg_kt = -1; a.dbg_abl = 0; a.sched = nullptr; a.batch_rows = 0; a.w_batch_rows = 0; a.row0 = 0;
+  a.dbg = nullptr; a.dbg_rowmask = 0x7fffffffu; a.dbg_kt = -1; a.dbg_abl = 0; a.sched = nullptr; a.batch_rows = 0; a.w_batch_rows = 0;
   a.xb = nullptr; a.ldxb = 0; a.stats = nullptr; a.ln_mr = nullptr; a.ln_c = nullptr;
   a.sa = sa; a.sw = sw; a.csc = c_scales; a.radd = resid; a.radd2 = nullptr; a.ldr2 = 0;
   if (addend2 != nullptr) {

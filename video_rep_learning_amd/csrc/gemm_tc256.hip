@@ -56,6 +56,12 @@
 //  * tried and rejected (round 2): every second workgroup of an XCD sleeping 0.15 .. 0.65 of a tile time before its first tile
 //    (fc2, K = 3072) so that the read-modify epilogues of half the chip meet the other half's K loops instead of each other:
 //    306.5 -> 307 .. 313 us.
+//  * tried and rejected (round 3, tools/corun_probe.sh): capping the kernel at 224 VGPRs (amdgpu_num_vgpr(112): the argument counts
+//    half registers on the unified file) with 224-row tiles, so that 64 registers per SIMD lane stay free and a wave of another
+//    stream's small kernel (LayerNorm 40 VGPRs, im2col, the head's row kernels) runs INSIDE the GEMM's CU instead of waiting
+//    for a workgroup to leave.  The kernels do co-execute (LayerNorm overlapped with the other lane's GEMM 49 % of its time
+//    instead of 29 %), but the cap costs 4 - 19 spilled registers: all GEMMs 10.14 -> 10.68 ms one kernel at a time (+5 %),
+//    step 11.75 -> 12.40 ms on the same box.  What co-execution gave back (about 0.25 ms) is less than what the spills cost.
 //  * XCD-aware tile walk: workgroups b, b+8, ... share an XCD (round-robin dispatch, speed only); group x = b & 7 owns a
 //    contiguous chunk of the tile list (tiles of one A row-panel are neighbours).  A workgroup's FIRST tile is static
 //    (chunk start + b/8); every further tile is a ticket from the group's counter (a.sched, agent-scope atomic), so a
@@ -730,8 +736,8 @@ int launch(const GemmTcArgs& a, bool persistent, hipStream_t st) {
 
 }  // namespace
 
-// The persistent launch sizes its grid to one workgroup per CU.  On a CU-masked stream (hipExtStreamCreateWithCUMask) fewer
-// CUs are available than the device reports; the caller states how many (0 = what the device reports).
+// The persistent launch sizes its grid to one workgroup per CU of its budget (0 = what the device reports): a data-parallel
+// run keeps 8 CUs out of it for RCCL's kernels (include/mvf_hip.h), a CU-masked stream (hipExtStreamCreateWithCUMask) has fewer.
 extern "C" int mvf_gemm_tc_set_cus(int n) {
   MVF_CHECK_ARG(n >= 0 && n <= 4096);
   g_cu_budget = n;
@@ -739,6 +745,11 @@ extern "C" int mvf_gemm_tc_set_cus(int n) {
 }
 
 int mvf_gemm_tc256_num_wgs() { return std::max(8, num_cus() & ~7); }
+extern "C" int mvf_gemm_tc_get_wgs(int* out) {
+  MVF_CHECK_ARG(out != nullptr);
+  *out = mvf_gemm_tc256_num_wgs();
+  return MVF_OK;
+}
 void mvf_gemm_tc256_set_bm(int bm) { g_bm_mode = bm; }
 
 int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, bool persistent, hipStream_t st) {

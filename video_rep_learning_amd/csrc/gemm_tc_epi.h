@@ -29,9 +29,6 @@ struct GemmTcArgs {
   // gemm_tc256 only: A / C rows are `batch_rows`-row batches stacked along M (a multiple of 256), batch b multiplying rows
   // [b * w_batch_rows, b * w_batch_rows + N) of W (split-K weight gradients); batch_rows == 0: one plain GEMM
   int batch_rows, w_batch_rows;
-  // gemm_tc (128x128) only: the launch covers rows [row0, M) -- the tail of a GEMM whose whole rounds of 256x256 tiles went to
-  // gemm_tc256 (mvf_gemm_tc_impl); every index below stays a GLOBAL row
-  int row0;
   // ---- LayerNorm folded into the GEMMs (gemm_tc256 only; DESIGN.md "LayerNorm folded into the GEMMs") ----
   // producer side, EPI_RESID: besides the fp32 residual stream also store xb = bf16(x_new) [M, ldxb] (the next GEMM's A
   // operand) and, per row and per 64-column wave slice, the partial (sum, sum of squares) of x_new: stats[N/64][M][2]

@@ -73,6 +73,7 @@ class VisionTransformer(nn.Module):
         self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
         self._packed = {}
         self._plist = None
+        self._pack_epoch = 0
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -98,7 +99,15 @@ class VisionTransformer(nn.Module):
         themselves instead of on an overridden method."""
         if getattr(self, '_plist', None) is None:       # re-homing goes through _apply, which drops this list (15 us per call)
             self._plist = list(self.parameters())
-        return tuple(p._version for p in self._plist)
+        # data_ptr too: `p.data = ...` and a flat-buffer adoption move the storage without touching _version.  What neither
+        # sees is a raw-pointer write into the SAME storage (a ctypes kernel, FusedAdam's flat-buffer step): whoever does that
+        # to a packed parameter calls invalidate_packed().
+        return tuple((p._version, p.data_ptr()) for p in self._plist) + (self._pack_epoch,)
+
+    def invalidate_packed(self):
+        """Forces the packed device copy to be rebuilt at the next forward (explicit hook for writers that bypass torch's
+        version counters)."""
+        self._pack_epoch += 1
 
     def _packed_for(self, key, depth, taps, dtype):
         ver = self._weights_version()

@@ -180,6 +180,8 @@ def main(argv=None):
     model = build_model(cfg, args.local_rank).to(device)
     if du.collectives_active():            # world > 1 (train.py:283), or a forced one-rank group
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        if device == 'cuda':
+            du.reserve_collective_cus()    # RCCL's kernels get CUs of their own beside the persistent GEMM
     model = DataParallelModel(model)
     optimizer = construct_optimizer(model, cfg)
     algo = get_algo(cfg)

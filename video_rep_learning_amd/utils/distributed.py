@@ -27,6 +27,26 @@ def collectives_active():
     return is_dist() and (dist.get_world_size() > 1 or os.environ.get('MVF_FORCE_REDUCER', '0') == '1')
 
 
+def reserve_collective_cus(device=None):
+    """Data-parallel runs: keep `MVF_RCCL_CUS` (default 8 = one per XCD) CUs out of the persistent backbone GEMM's budget.
+
+    That kernel holds one workgroup on EVERY CU it may use for a whole launch (180-300 us at BASELINE configs[1]) and, with
+    two backbone lanes, the next launch is already queued when one ends -- so without a reserve RCCL's kernels (gradient
+    bucket all-reduce, SyncBN statistics, embedding all-gather: train.py:283-286 of the reference) start only when some
+    GEMM workgroup happens to run out of tiles.  With the reserve they start at once; the GEMMs run on 248 of 256 CUs
+    (-3 % of their throughput, measured in DESIGN.md section 5).  No-op without collectives.  Returns the GEMM's CU budget."""
+    from .. import _lib
+    if not collectives_active():
+        _lib.call('mvf_gemm_tc_set_cus', 0)
+        return 0
+    reserve = int(os.environ.get('MVF_RCCL_CUS', '8'))
+    dev = torch.cuda.current_device() if device is None else device
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    budget = max(8, cus - max(reserve, 0)) if reserve > 0 else 0
+    _lib.call('mvf_gemm_tc_set_cus', budget)
+    return budget
+
+
 def get_world_size():
     return dist.get_world_size() if is_dist() else 1
 

@@ -82,6 +82,13 @@ int mvf_vit_fwd(const MvfVitWeights* w, int dtype, const float* frames, int F, v
 int mvf_vit_fwd_x(const MvfVitWeights* w, int dtype, const float* frames, int F, void* const* taps_out, float* cls_out,
                   float* x_out, void* workspace, size_t ws_bytes, int frames_per_chunk, int attn_variant,
                   hipStream_t stream);
+/* Blocks [first_block, first_block + n_blocks) on a residual stream the caller supplies: x [F*tokens, dim] fp32 (CLS row
+ * included), updated in place -- timm Block.forward x n_blocks (x += attn(norm1(x)); x += mlp(norm2(x)), LayerScale where the
+ * model has it), the loop body of VisionTransformer.forward_features reached from models/transformer.py:188.  For the
+ * per-block ("teacher-forced") parity checks, which feed every block the oracle's input.  No taps, no final norm.  bf16:
+ * first_block must not be a folded-LayerNorm consumer (pack with the fold off).  workspace: mvf_vit_workspace_bytes(dtype, F, ..). */
+int mvf_vit_blocks_fwd(const MvfVitWeights* w, int dtype, float* x, int F, int first_block, int n_blocks, void* workspace,
+                       size_t ws_bytes, int attn_variant, hipStream_t stream);
 
 /* measurement hooks (bench.py roofline): when enabled, every GEMM launch of mvf_vit_fwd is bracketed by HIP events
  * on the launch stream; collect() waits for them and returns, per GEMM shape (epilogue kind, N, K) -- group g <

@@ -148,33 +148,29 @@ def test_full_size_fp32_and_bf16_vs_oracle(tag):
     loss.backward()
     e_emb, e_loss = T.relerr(emb, remb), T.relerr(loss, rloss)
     gscale = max(g.abs().max().item() for g in rgrads.values() if g is not None)
-    worst, worst_raw = (0.0, ''), (0.0, '')
-    for n, prm in model.named_parameters():
-        if n in rgrads and rgrads[n] is not None and prm.grad is not None:
-            d = (prm.grad.double().cpu() - rgrads[n].double()).abs().flatten()
-            scale = max(rgrads[n].abs().max().item(), 1e-2 * gscale)
-            worst_raw = max(worst_raw, (d.max().item() / scale, n))
-            # ReLU flips (test_gpu_model.bf16_mode_report): a unit whose pre-activation is within fp32 rounding of 0 is on in one
-            # implementation and off in the other and moves single elements of the bias / BatchNorm-affine gradients in front of
-            # it by one row's share (the fg99 head has 1536 such channels x 1536 rows): the 0.4 % worst elements are set aside
-            # here and bounded on their own below
-            k = max(1, d.numel() // 250)
-            d = d.topk(d.numel() - k, largest=False)[0] if d.numel() > k else d[:0]
-            worst = max(worst, ((d.max().item() if d.numel() else 0.0) / scale, n))
-    record_parity('%s HIP fp32 vs fp32 oracle: embeddings max-rel %.3e, SCL loss %.6f vs %.6f rel %.3e, worst head-gradient rel '
-                  '%.3e (%s); %.3e (%s) with the 0.4 %% worst elements of each tensor (ReLU flips) counted' % (
-                      tag, e_emb, loss.item(), rloss.item(), e_loss, worst[0], worst[1], worst_raw[0], worst_raw[1]))
+    # ReLU flips (test_gpu_model.flip_census): a unit whose pre-activation is within fp32 rounding of 0 is on in one implementation
+    # and off in the other and moves single elements of the bias / BatchNorm-affine gradients in front of it by one row's share
+    # (the fg99 head has 1536 such channels x 1536 rows).  Elements above the 1e-2 gate are COUNTED and bounded, not trimmed.
+    census = {n: T.flip_census(prm.grad.cpu(), rgrads[n], max(rgrads[n].abs().max().item(), 1e-2 * gscale), 1e-2)
+              for n, prm in model.named_parameters() if n in rgrads and rgrads[n] is not None and prm.grad is not None}
+    flips, nelem = sum(c[0] for c in census.values()), sum(rgrads[n].numel() for n in census)
+    worst_raw = max((c[1], n) for n, c in census.items())
+    worst = max((c[2], n) for n, c in census.items())
+    record_parity('%s HIP fp32 vs fp32 oracle: embeddings max-rel %.3e, SCL loss %.6f vs %.6f rel %.3e; head gradients: %d of %d '
+                  'elements above the 1e-2 gate (ReLU flips), the largest %.3e (%s), every other element <= %.3e (%s)' % (
+                      tag, e_emb, loss.item(), rloss.item(), e_loss, flips, nelem, worst_raw[0], worst_raw[1], worst[0], worst[1]))
     assert e_emb <= 1e-3 and e_loss <= 1e-3, (e_emb, e_loss)          # the north-star gate
-    # 1e-2: the flipped units also perturb every gradient upstream of them a little (measured up to 5.0e-3 on the pooling queries
-    # of the 1536-wide fg99 head; 6e-4 .. 4.5e-3 on the other two configs)
-    assert worst[0] <= 1e-2 and worst_raw[0] <= 5e-2, (worst, worst_raw)
+    # the flipped units also perturb every gradient upstream of them a little (measured up to 5.0e-3 on the pooling queries of
+    # the 1536-wide fg99 head; 6e-4 .. 4.5e-3 on the other two configs): those stay under the 1e-2 gate
+    assert flips <= 4 * T.FLIP_MAX and worst_raw[0] <= 5e-2, (flips, worst_raw, worst)
     # ---- bf16 mode (the benchmarked dtype)
     r = T.bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, ref_emb_fp32=remb)
     record_parity('%s HIP bf16: %s' % (tag, r['text']))
-    # bounds: measured on MI355X (profiles/r02/parity.txt) with ~2-3x margin.  The two sides differ by fp32 summation order and
-    # by bf16 roundings that flip where a value sits on a rounding boundary (one bf16 ulp of a tap's largest element is 3.9e-3)
-    assert r['emb'] <= 5e-2 and r['loss'] <= 5e-3 and r['emb_fp32'] <= 1e-1, r
-    assert r['loss_head'] <= 1e-3 and r['head_grad'] <= 2e-2 and r['head_grad_raw'] <= 0.1, r
+    # bounds: at most 3x what was measured on MI355X (profiles/r02/parity.txt: embeddings 5.3e-4 .. 6.3e-4, loss 9e-5 .. 6e-4,
+    # 1.6e-2 .. 1.8e-2 against the fp32 oracle).  The two sides differ by fp32 summation order and by bf16 roundings that flip
+    # where a value sits on a rounding boundary (one bf16 ulp of a tap's largest element is 3.9e-3)
+    assert r['emb'] <= 2e-3 and r['loss'] <= 2e-3 and r['emb_fp32'] <= 5e-2, r
+    assert r['loss_head'] <= 1e-3 and r['flips'] <= 4 * T.FLIP_MAX and r['head_grad_raw'] <= 0.1, r
     assert r['grad_cos'] >= 0.98, r
 
 
@@ -219,3 +215,50 @@ def test_config4_dinov2_vitl14_336_backbone_vs_oracle():
             e32 = [T.relerr(got[j].float(), feats[:, 1:, j * dim:(j + 1) * dim].reshape(-1, dim)) for j in range(len(taps))]
             record_parity('configs[4] HIP bf16 vs the fp32 oracle: taps max-rel %s' % ' '.join('%.3e' % e for e in e32))
             assert max(e32) <= 5e-2, e32
+
+
+def test_config4_per_block_teacher_forced_fp8_and_bf16():
+    """Every block of the configs[4] backbone on its own: block l is fed the ORACLE's input x_l (the emulating oracle's own
+    residual stream) and its output is compared with the oracle's block output.  What is compared is the block's UPDATE
+    x_{l+1} - x_l (the residual stream itself is the same on both sides and would hide the error).  A scale byte landing on the
+    wrong MX block, a wrong k-permutation in one epilogue or a mis-staged scale tile shows here as an O(1) error of that block's
+    update, where the 24-block end-to-end distance (test above, gate 0.10) could not tell it from rounding divergence."""
+    dim, depth, heads, patch, img, F = 1024, 24, 16, 14, 336, 2
+    w = OV.init_vit_weights(dim, depth, patch, img, seed=41, layerscale=True)
+    x = torch.randn(F, 3, img, img, generator=torch.Generator().manual_seed(42))
+    sd = {k: v.to(DEV) for k, v in w.items()}
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    for mode, gate in (('fp8', 3e-2), ('bf16', 1.5e-2)):
+        pk = ops.PackedViT(sd, depth, dim, heads, patch, img, (), mode, ln_fold=0)
+        emul = 'fp8' if mode == 'fp8' else 'bf16_nofold'      # a block on its own cannot consume a folded LayerNorm
+        worst = (0.0, -1)
+        errs = []
+        with torch.no_grad():
+            xl = OV.vit_embed(x, w, patch, mode)
+            for l in range(depth):
+                ref = OV.vit_block(xl, w, 'blocks.%d.' % l, heads, 1e-6, emul)
+                got = ops.vit_blocks(xl.to(DEV), pk, l, 1).cpu()
+                e = rel_l2(got - xl, ref - xl)
+                errs.append(e)
+                worst = max(worst, (e, l))
+                xl = ref
+        record_parity('configs[4] DINOv2 ViT-L/14 @ 336 px, per block, teacher-forced with the %s-emulating oracle\'s input: rel-L2 of '
+                      'the block update, blocks 0..23: %s (worst %.3e at block %d)' % (mode, ' '.join('%.2e' % e for e in errs), *worst))
+        assert worst[0] <= gate, (mode, worst, errs)
+        del pk
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'fp8'])
+def test_config4_full_step(mode):
+    """BASELINE configs[4] as ONE training step on the device -- DINOv2 ViT-L/14 at 336 px (577 tokens), 32-frame clips,
+    C_in = 3 x 1024 tapped channels, 576 pooled tokens per frame -- for one video (2 clips = 64 frames; the per-GPU batch of the
+    config is a multiple of this).  The backbone's own parity is the two tests above; here the oracle HEAD and loss run on the
+    device's taps, and the device loss / every head gradient must match them at the fp32 gates: the pooling, the temporal
+    encoder over S = 96 and the SCL kernels at this config's widths."""
+    cfg, model = T.make(23, network='TIMM-vit_large_patch14_dinov2.lvd142m', num_frames=32, batch_size=1, image_size=336,
+                        dropout=0.0, compute_dtype=mode, SMART_FEATS='7,15,23')
+    videos, seq_lens, steps, masks = T.batch(cfg, 24, pad=3)
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    r = T.bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, mode=mode, end_to_end=False)
+    record_parity('configs[4] full step (ViT-L/14 @ 336, T=32, 2 clips) HIP %s: %s' % (mode, r['text']))
+    assert r['loss_head'] <= 1e-3 and r['flips'] <= 4 * T.FLIP_MAX and r['head_grad_raw'] <= 0.1, r

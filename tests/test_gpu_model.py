@@ -290,25 +290,43 @@ def test_full_size_vitb16_fp32_and_bf16():
     record_parity('ViT-B/16 T=4 B=1 HIP bf16: ' + r['text'])
     # loss gate 2e-2: 8 frames (T = 4, B = 1) -- a single clip pair's loss moves by 0.9 .. 1.3 % under bf16 features (the
     # full-size configs[1] test gates 5e-3 on 256 frames)
-    assert r['emb'] <= 5e-2 and r['loss'] <= 2e-2 and r['head_grad'] <= 2e-2 and r['head_grad_raw'] <= 0.1 and r['emb_fp32'] < 0.1, r
+    assert r['emb'] <= 5e-3 and r['loss'] <= 2e-2 and r['emb_fp32'] < 0.1, r
+    assert r['loss_head'] <= 1e-3 and r['flips'] <= FLIP_MAX and r['head_grad_raw'] <= 0.1, r
 
 
-def bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, ref_emb_fp32=None):
-    """bf16 mode of `model` on one batch (dropout 0) against
-      (1) the bf16-EMULATING oracle end to end: eval embeddings (max-rel), training loss (rel), and the cosine between the two
-          head-gradient vectors -- the gradients themselves are ill-conditioned in the taps (softmax at temperature 0.1: a 0.4 %
-          change of the features moves single gradient tensors by tens of percent on BOTH sides), so they are not gated here;
-      (2) the oracle HEAD fed with the device's own bf16 taps: loss and every head gradient at the fp32 gates -- this is the
-          check that the head (pooling kernels reading bf16 taps, everything behind them) is right in bf16 mode."""
+# gradient elements a head of 4.8 M parameters may have above the kernels' gate through ReLU flips (measured: 0 .. 3)
+FLIP_MAX = 16
+
+
+def flip_census(got, ref, scale, gate):
+    """Gradient elements above `gate` x scale: (count, largest error / scale, largest error / scale among the rest).  The head
+    has ReLUs: a unit whose pre-activation is within fp32 rounding of 0 for one token is switched on in one implementation and
+    off in the other, which moves ONE bias-gradient element (and one row of the weight gradient in front of it) by that token's
+    whole share.  The tests bound how MANY elements sit above the kernels' gate and how far, instead of trimming a fixed
+    fraction."""
+    d = (got.double() - ref.double()).abs().flatten() / scale
+    over = d > gate
+    n = int(over.sum())
+    rest = d[~over]
+    return n, (d.max().item() if d.numel() else 0.0), (rest.max().item() if rest.numel() else 0.0)
+
+
+def bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, ref_emb_fp32=None, mode='bf16', end_to_end=True, gate=2e-2):
+    """Reduced-precision mode (`mode` = 'bf16' or 'fp8': the backbone's GEMM operand dtype) of `model` on one batch (dropout 0)
+    against
+      (1) end_to_end: the EMULATING oracle (oracle/vit.py emulate=mode): eval embeddings (max-rel), training loss (rel), and the
+          cosine between the two head-gradient vectors -- the gradients themselves are ill-conditioned in the taps (softmax at
+          temperature 0.1: a 0.4 % change of the features moves single gradient tensors by tens of percent on BOTH sides), so
+          they are not gated here;
+      (2) the oracle HEAD fed with the device's own taps: loss and every head gradient at the fp32 gates -- this is the check
+          that the head (pooling kernels reading bf16 taps, everything behind them) is right in this mode.  Elements above
+          `gate` are counted (flip_census), not trimmed."""
     vit_cfg, head_cfg, scl_cfg = oracle_cfgs(cfg)
-    vc16 = dict(vit_cfg, emulate='bf16')
+    vc16 = dict(vit_cfg, emulate=mode)
     b, t = cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.NUM_FRAMES
     x = videos.view(b * 2, t, *videos.shape[3:])
     m2 = masks.view(b * 2, 1, t)
     params = cpu_params(model)
-    with torch.no_grad():
-        feat16, cls16 = OM.backbone_features(x.reshape(b * 2 * t, *x.shape[2:]), params, vc16)
-        ref16 = OM.forward_from_backbone(feat16, cls16, b * 2, t, params, vc16, head_cfg, m2, project=False, training=False)
 
     def oracle_loss_grads(feat, cls):
         leaves = {k: params[k].clone().requires_grad_(True) for k in OM.trainable_names(params)}
@@ -317,8 +335,12 @@ def bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, ref_emb_fp32=No
         loss = OM.loss_from_backbone(feat, cls, seq_lens, steps, masks, p, vc16, head_cfg, scl_cfg, training=True)
         loss.backward()
         return loss.detach(), {k: v.grad for k, v in leaves.items() if v.grad is not None}
-    lref16, g16 = oracle_loss_grads(feat16, cls16)
-    model.compute_dtype = 'bf16'
+    if end_to_end:
+        with torch.no_grad():
+            feat16, cls16 = OM.backbone_features(x.reshape(b * 2 * t, *x.shape[2:]), params, vc16)
+            ref16 = OM.forward_from_backbone(feat16, cls16, b * 2, t, params, vc16, head_cfg, m2, project=False, training=False)
+        lref16, g16 = oracle_loss_grads(feat16, cls16)
+    model.compute_dtype = mode
     model.eval()
     with torch.no_grad():
         emb = model(x.to(DEV), t, video_masks=m2.to(DEV))
@@ -332,37 +354,29 @@ def bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, ref_emb_fp32=No
     loss.backward()
     got = {n: p.grad.detach().double().cpu() for n, p in model.named_parameters() if p.grad is not None}
     gscale = max(g.abs().max().item() for g in g_dev.values())
-
-    def perr(n, trim):
-        """max error of parameter n's gradient relative to its largest entry; trim: without its numel/1000 (>= 1) worst
-        elements.  The head has ReLUs: a unit whose pre-activation is within fp32 rounding of 0 for one token is switched on
-        in one implementation and off in the other, which moves ONE bias-gradient element (and one row of the weight
-        gradient) by that token's whole share -- measured: 1 of 1024 elements of fc1.bias off by 2.6e-2, everything else
-        <= 3e-3.  The trimmed error gates the kernels, the raw one bounds the flips."""
-        d = (got[n] - g_dev[n].double()).abs().flatten()
-        if trim:
-            k = max(1, d.numel() // 1000)
-            d = d.topk(d.numel() - k, largest=False)[0] if d.numel() > k else d[:0]
-        return (d.max().item() if d.numel() else 0.0) / max(g_dev[n].abs().max().item(), 1e-2 * gscale)
-    worst = max((perr(n, True), n) for n in g_dev if n in got)
-    worst_raw = max((perr(n, False), n) for n in g_dev if n in got)
-    # per-parameter detail for the log: error and how many elements carry it (a ReLU unit whose pre-activation is within
-    # rounding of 0 flips between the two implementations and moves ONE element of a bias gradient by one token's share)
-    det = sorted(((got[n] - g_dev[n].double()).abs().max().item() / max(g_dev[n].abs().max().item(), 1e-2 * gscale),
-                  int(((got[n] - g_dev[n].double()).abs() > 1e-3 * max(g_dev[n].abs().max().item(), 1e-2 * gscale)).sum()),
-                  got[n].numel(), n) for n in g_dev if n in got)[-3:]
-    names = sorted(n for n in g16 if n in got)
-    va = torch.cat([got[n].flatten() for n in names])
-    vb = torch.cat([g16[n].double().flatten() for n in names])
-    cos = torch.nn.functional.cosine_similarity(va, vb, dim=0).item()
-    out = dict(emb=relerr(emb, ref16), loss=relerr(loss, lref16), loss_head=relerr(loss, lref_dev), head_grad=worst[0], head_grad_raw=worst_raw[0],
-               head_grad_name=worst[1], grad_cos=cos, emb_fp32=relerr(emb, ref_emb_fp32) if ref_emb_fp32 is not None else float('nan'))
-    out['text'] = ('embeddings max-rel %.3e vs bf16-emulating oracle (%.3e vs fp32 oracle); SCL loss %.6f vs %.6f rel %.3e; '
-                   'head-gradient cosine vs emulating oracle %.5f; oracle head on the DEVICE taps: loss rel %.3e, worst '
-                   'head-gradient rel %.3e (%s; %.3e (%s) with the 0.1 %% worst elements of each tensor, ReLU flips, counted)' % (
-                       out['emb'], out['emb_fp32'], loss.item(), lref16.item(), out['loss'], cos, out['loss_head'], worst[0],
-                       worst[1], worst_raw[0], worst_raw[1]))
-    out['text'] += '; top-3 ' + ', '.join('%s %.2e (%d of %d elements off)' % (n, e, k, tot) for e, k, tot, n in det)
+    census = {n: flip_census(got[n], g_dev[n], max(g_dev[n].abs().max().item(), 1e-2 * gscale), gate) for n in g_dev if n in got}
+    flips = sum(c[0] for c in census.values())
+    nelem = sum(got[n].numel() for n in census)
+    worst_raw = max((c[1], n) for n, c in census.items())
+    worst = max((c[2], n) for n, c in census.items())
+    det = sorted((c[1], c[0], got[n].numel(), n) for n, c in census.items())[-3:]
+    out = dict(loss_head=relerr(loss, lref_dev), head_grad=worst[0], head_grad_raw=worst_raw[0], head_grad_name=worst[1],
+               flips=flips, flip_frac=flips / max(nelem, 1),
+               emb_fp32=relerr(emb, ref_emb_fp32) if ref_emb_fp32 is not None else float('nan'))
+    txt = ''
+    if end_to_end:
+        names = sorted(n for n in g16 if n in got)
+        va = torch.cat([got[n].flatten() for n in names])
+        vb = torch.cat([g16[n].double().flatten() for n in names])
+        cos = torch.nn.functional.cosine_similarity(va, vb, dim=0).item()
+        out.update(emb=relerr(emb, ref16), loss=relerr(loss, lref16), grad_cos=cos)
+        txt = ('embeddings max-rel %.3e vs %s-emulating oracle (%.3e vs fp32 oracle); SCL loss %.6f vs %.6f rel %.3e; '
+               'head-gradient cosine vs emulating oracle %.5f; ' % (out['emb'], mode, out['emb_fp32'], loss.item(), lref16.item(),
+                                                                  out['loss'], cos))
+    out['text'] = txt + ('oracle head on the DEVICE taps: loss %.6f rel %.3e, head gradients: %d of %d elements above the %.0e gate '
+                         '(ReLU flips), the largest %.3e (%s), every other element <= %.3e (%s)' % (
+                             loss.item(), out['loss_head'], flips, nelem, gate, worst_raw[0], worst_raw[1], worst[0], worst[1]))
+    out['text'] += '; top-3 ' + ', '.join('%s %.2e (%d of %d elements above the gate)' % (n, e, k, tot) for e, k, tot, n in det)
     return out
 
 

@@ -19,6 +19,7 @@ SIGNATURES = {
     'mvf_vit_workspace_bytes': 'iiiii',
     'mvf_vit_fwd': 'pipipppziip',
     'mvf_vit_fwd_x': 'pipippppziip',
+    'mvf_vit_blocks_fwd': 'pipiiipzip',
     'mvf_prof_enable': 'i',
     'mvf_prof_collect': 'ppppppip',
     'mvf_gemm_tc': 'iipipippipipippiiiip',

@@ -127,6 +127,114 @@ extern "C" size_t mvf_vit_workspace_bytes(int dtype, int frames_per_chunk, int t
   return carve(dtype, frames_per_chunk, tokens, dim, patch, nullptr, nullptr);
 }
 
+namespace {
+#define RUN(call)               \
+  do {                          \
+    rc = (call);                \
+    if (rc != MVF_OK) return rc; \
+  } while (0)
+
+// Blocks [l0, l1) on the `fc` frames whose fp32 residual stream is ws.x (updated in place); `dtype` is the activation dtype
+// (fp8 mode: bf16), taps_out slices start at frame f0.  Layer l0 must not be a folded-LayerNorm consumer unless the previous
+// residual epilogue of THIS call produced its statistics (l0 == first layer of the model: never folded).
+int run_blocks(const MvfVitWeights* w, int dtype, bool fp8, const Ws& ws, int fc, int N, int l0, int l1, void* const* taps_out,
+               int f0, int attn_variant, hipStream_t st) {
+  const int D = w->dim, H = w->heads, np = N - 1;
+  const int Mc = fc * N;
+  const size_t esz = dtype == MVF_BF16 ? 2 : 4;
+  int rc;
+  // LN fold (bf16): where a layer's table entry qkv_c[l] / fc1_c[l] is set, qkv_w / fc1_w hold gamma (.) W, the bias table
+  // holds b + W beta, and the GEMM consumes xb = bf16(x) with the row statistics applied in its epilogue -- no LayerNorm
+  // kernel.  xb and the statistics' partial sums come out of the PREVIOUS residual epilogue (proj for LN2, the previous
+  // layer's fc2 for LN1); layer 0's LN1 follows the patch embedding and keeps the LayerNorm kernel.
+  const bool can_fold = !fp8 && dtype == MVF_BF16 && ws.xb != nullptr && D % 128 == 0;
+  auto folded = [&](const float* const* tab, int l) { return can_fold && tab != nullptr && l < w->depth && tab[l] != nullptr; };
+  const int ns = D / 64;
+  for (int l = l0; l < l1; ++l) {
+    int tap = -1;
+    for (int j = 0; j < w->n_taps; ++j)
+      if (w->taps[j] == l) tap = j;
+    if (fp8) {
+      // MX-fp8 block: every GEMM operand is quantised by its producer (LayerNorm and the fc1+GELU epilogue write fp8
+      // directly; the attention output is bf16 and goes through mvf_quant_mxfp8)
+      void* tap_ptr = nullptr;
+      if (tap >= 0 && taps_out && taps_out[tap]) tap_ptr = (char*)taps_out[tap] + (size_t)f0 * np * D * 2;
+      // deferred residual as in the bf16 path below (LayerScale models: the packer folds gamma_1 into proj's weights and bias
+      // and leaves ls1 NULL)
+      const bool defer8 = g_proj_defer && ws.delta != nullptr && w->ls1 == nullptr;
+      const Fp8Scales sq = {ws.hs, w->qkv_s[l], nullptr, nullptr, 0}, sp = {ws.hs, w->proj_s[l], nullptr, nullptr, 0},
+                      s1 = {ws.hs, w->fc1_s[l], ws.hids, nullptr, 0},
+                      s2 = {ws.hids, w->fc2_s[l], nullptr, defer8 ? ws.delta : nullptr, D};
+      RUN(mvf_layernorm_mxfp8_impl(ws.x, D, w->ln1_w[l], w->ln1_b[l], ws.hq, D, ws.hs, Mc, D, w->ln_eps, st));
+      RUN(timed_gemm(dtype, EPI_STORE, ws.hq, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0, nullptr,
+                     nullptr, N, Mc, 3 * D, D, st, nullptr, &sq));
+      RUN(mvf_vit_attn_impl(dtype, ws.qkv, ws.h, fc, N, H, D, attn_variant, st));
+      RUN(mvf_quant_mxfp8_impl(MVF_BF16, ws.h, D, ws.hq, D, ws.hs, Mc, D, st));
+      if (defer8)
+        RUN(timed_gemm(dtype, EPI_STORE, ws.hq, D, w->proj_w[l], D, w->proj_b[l], ws.delta, D, nullptr, 0, nullptr, 0, nullptr,
+                       nullptr, N, Mc, D, D, st, nullptr, &sp));
+      else
+        RUN(timed_gemm(dtype, EPI_RESID, ws.hq, D, w->proj_w[l], D, w->proj_b[l], nullptr, 0, ws.x, D, nullptr, 0, nullptr,
+                       w->ls1 ? w->ls1[l] : nullptr, N, Mc, D, D, st, nullptr, &sp));
+      RUN(mvf_layernorm_mxfp8_impl(ws.x, D, w->ln2_w[l], w->ln2_b[l], ws.hq, D, ws.hs, Mc, D, w->ln_eps, st,
+                                   defer8 ? ws.delta : nullptr, D));
+      // fc1 + GELU with the MX-fp8 quantisation in its epilogue: hidq / hids straight out of the GEMM (no bf16 hid)
+      RUN(timed_gemm(dtype, EPI_GELU, ws.hq, D, w->fc1_w[l], D, w->fc1_b[l], ws.hidq, 4 * D, nullptr, 0, nullptr, 0, nullptr,
+                     nullptr, N, Mc, 4 * D, D, st, nullptr, &s1));
+      RUN(timed_gemm(dtype, EPI_RESID, ws.hidq, 4 * D, w->fc2_w[l], 4 * D, w->fc2_b[l], nullptr, 0, ws.x, D, tap_ptr, D,
+                     nullptr, w->ls2 ? w->ls2[l] : nullptr, N, Mc, D, 4 * D, st, nullptr, &s2));
+      continue;
+    }
+    if (folded(w->qkv_c, l)) {
+      if (l == l0) return MVF_ERR_ARG;   // nothing in this call produced the layer's statistics
+      RUN(mvf_ln_stats_finalize_impl(ws.stats, ns, ws.mr, Mc, D, w->ln_eps, st));
+      const MvfGemmLn ln = {nullptr, 0, nullptr, ws.mr, w->qkv_c[l], 0, nullptr};
+      RUN(timed_gemm(dtype, EPI_STORE, ws.xb, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0,
+                     nullptr, nullptr, N, Mc, 3 * D, D, st, &ln));
+    } else {
+      RUN(mvf_layernorm_impl(dtype, ws.x, D, w->ln1_w[l], w->ln1_b[l], ws.h, D, Mc, D, w->ln_eps, st));
+      RUN(timed_gemm(dtype, EPI_STORE, ws.h, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0,
+                     nullptr, nullptr, N, Mc, 3 * D, D, st));
+    }
+    RUN(mvf_vit_attn_impl(dtype, ws.qkv, ws.h, fc, N, H, D, attn_variant, st));
+    const bool fold2 = folded(w->fc1_c, l);
+    // Deferred residual (bf16, no LayerScale, norm2 not folded): proj stores its result (+ bias) as bf16 with the plain
+    // epilogue instead of read-modifying the fp32 residual (310 MB per launch with the matrix cores idle); LayerNorm 2
+    // normalises x + delta and the fc2 epilogue adds delta with its own residual update.  The branch output is rounded to
+    // bf16 before the add -- what the reference's autocast does to it (fp16 there; transformer.py:188).
+    const bool defer = g_proj_defer && dtype == MVF_BF16 && ws.delta != nullptr && !fold2 && w->ls1 == nullptr && D % 128 == 0;
+    if (defer) {
+      RUN(timed_gemm(dtype, EPI_STORE, ws.h, D, w->proj_w[l], D, w->proj_b[l], ws.delta, D, nullptr, 0, nullptr, 0, nullptr,
+                     nullptr, N, Mc, D, D, st));
+    } else {
+      const MvfGemmLn ln = {fold2 ? ws.xb : nullptr, D, fold2 ? ws.stats : nullptr, nullptr, nullptr, 0, nullptr};
+      RUN(timed_gemm(dtype, EPI_RESID, ws.h, D, w->proj_w[l], D, w->proj_b[l], nullptr, 0, ws.x, D, nullptr, 0,
+                     nullptr, w->ls1 ? w->ls1[l] : nullptr, N, Mc, D, D, st, fold2 ? &ln : nullptr));
+    }
+    if (fold2) {
+      RUN(mvf_ln_stats_finalize_impl(ws.stats, ns, ws.mr, Mc, D, w->ln_eps, st));
+      const MvfGemmLn ln = {nullptr, 0, nullptr, ws.mr, w->fc1_c[l], 0, nullptr};
+      RUN(timed_gemm(dtype, EPI_GELU, ws.xb, D, w->fc1_w[l], D, w->fc1_b[l], ws.hid, 4 * D, nullptr, 0, nullptr, 0,
+                     nullptr, nullptr, N, Mc, 4 * D, D, st, &ln));
+    } else {
+      RUN(mvf_layernorm_impl(dtype, ws.x, D, w->ln2_w[l], w->ln2_b[l], ws.h, D, Mc, D, w->ln_eps, st, defer ? ws.delta : nullptr, D));
+      RUN(timed_gemm(dtype, EPI_GELU, ws.h, D, w->fc1_w[l], D, w->fc1_b[l], ws.hid, 4 * D, nullptr, 0, nullptr, 0,
+                     nullptr, nullptr, N, Mc, 4 * D, D, st));
+    }
+    void* tap_ptr = nullptr;
+    if (tap >= 0 && taps_out && taps_out[tap]) tap_ptr = (char*)taps_out[tap] + (size_t)f0 * np * D * esz;
+    const bool fold_next = l + 1 < l1 && folded(w->qkv_c, l + 1);
+    {
+      const MvfGemmLn ln = {fold_next ? ws.xb : nullptr, D, fold_next ? ws.stats : nullptr, nullptr, nullptr, 0, nullptr,
+                            defer ? ws.delta : nullptr, D};
+      RUN(timed_gemm(dtype, EPI_RESID, ws.hid, 4 * D, w->fc2_w[l], 4 * D, w->fc2_b[l], nullptr, 0, ws.x, D, tap_ptr,
+                     D, nullptr, w->ls2 ? w->ls2[l] : nullptr, N, Mc, D, 4 * D, st, (fold_next || defer) ? &ln : nullptr));
+    }
+  }
+  return MVF_OK;
+}
+}  // namespace
+
 extern "C" int mvf_vit_fwd(const MvfVitWeights* w, int dtype, const float* frames, int F, void* const* taps_out,
                            float* cls_out, void* workspace, size_t ws_bytes, int frames_per_chunk, int attn_variant,
                            hipStream_t st) {
@@ -153,15 +261,8 @@ extern "C" int mvf_vit_fwd_x(const MvfVitWeights* w, int dtype, const float* fra
   const int fc_max = frames_per_chunk > 0 ? std::min(frames_per_chunk, F) : F;
   Ws ws;
   MVF_CHECK_ARG(carve(fp8 ? MVF_FP8 : dtype, fc_max, N, D, P, &ws, (char*)workspace) <= ws_bytes);
-  const size_t esz = dtype == MVF_BF16 ? 2 : 4;
   const int kp = mvf_patch_k(P);   // patch_w is [dim, kp] (zero-padded beyond 3*P*P)
   int rc;
-#define RUN(call)               \
-  do {                          \
-    rc = (call);                \
-    if (rc != MVF_OK) return rc; \
-  } while (0)
-
   for (int f0 = 0; f0 < F; f0 += fc_max) {
     const int fc = std::min(fc_max, F - f0);
     const int Mc = fc * N;
@@ -170,103 +271,39 @@ extern "C" int mvf_vit_fwd_x(const MvfVitWeights* w, int dtype, const float* fra
     RUN(timed_gemm(dtype, EPI_PATCH, ws.hid, kp, w->patch_w, kp, w->patch_b, nullptr, 0, ws.x, D, nullptr, 0,
                          w->pos_embed, nullptr, N, fc * np, D, kp, st));
     RUN(mvf_cls_row_impl(ws.x, w->cls_token, w->pos_embed, fc, N, D, st));
-    // LN fold (bf16): where a layer's table entry qkv_c[l] / fc1_c[l] is set, qkv_w / fc1_w hold gamma (.) W, the bias table
-    // holds b + W beta, and the GEMM consumes xb = bf16(x) with the row statistics applied in its epilogue -- no LayerNorm
-    // kernel.  xb and the statistics' partial sums come out of the PREVIOUS residual epilogue (proj for LN2, the previous
-    // layer's fc2 for LN1); layer 0's LN1 follows the patch embedding and keeps the LayerNorm kernel.
-    const bool can_fold = !fp8 && dtype == MVF_BF16 && ws.xb != nullptr && D % 128 == 0;
-    auto folded = [&](const float* const* tab, int l) { return can_fold && tab != nullptr && l < w->depth && tab[l] != nullptr; };
-    const int ns = D / 64;
-    for (int l = 0; l < w->depth; ++l) {
-      int tap = -1;
-      for (int j = 0; j < w->n_taps; ++j)
-        if (w->taps[j] == l) tap = j;
-      if (fp8) {
-        // MX-fp8 block: every GEMM operand is quantised by its producer (LayerNorm and the fc1+GELU epilogue write fp8
-        // directly; the attention output is bf16 and goes through mvf_quant_mxfp8)
-        void* tap_ptr = nullptr;
-        if (tap >= 0 && taps_out && taps_out[tap]) tap_ptr = (char*)taps_out[tap] + (size_t)f0 * np * D * 2;
-        // deferred residual as in the bf16 path below (LayerScale models: the packer folds gamma_1 into proj's weights and bias
-        // and leaves ls1 NULL)
-        const bool defer8 = g_proj_defer && ws.delta != nullptr && w->ls1 == nullptr;
-        const Fp8Scales sq = {ws.hs, w->qkv_s[l], nullptr, nullptr, 0}, sp = {ws.hs, w->proj_s[l], nullptr, nullptr, 0},
-                        s1 = {ws.hs, w->fc1_s[l], ws.hids, nullptr, 0},
-                        s2 = {ws.hids, w->fc2_s[l], nullptr, defer8 ? ws.delta : nullptr, D};
-        RUN(mvf_layernorm_mxfp8_impl(ws.x, D, w->ln1_w[l], w->ln1_b[l], ws.hq, D, ws.hs, Mc, D, w->ln_eps, st));
-        RUN(timed_gemm(dtype, EPI_STORE, ws.hq, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0, nullptr,
-                       nullptr, N, Mc, 3 * D, D, st, nullptr, &sq));
-        RUN(mvf_vit_attn_impl(dtype, ws.qkv, ws.h, fc, N, H, D, attn_variant, st));
-        RUN(mvf_quant_mxfp8_impl(MVF_BF16, ws.h, D, ws.hq, D, ws.hs, Mc, D, st));
-        if (defer8)
-          RUN(timed_gemm(dtype, EPI_STORE, ws.hq, D, w->proj_w[l], D, w->proj_b[l], ws.delta, D, nullptr, 0, nullptr, 0, nullptr,
-                         nullptr, N, Mc, D, D, st, nullptr, &sp));
-        else
-          RUN(timed_gemm(dtype, EPI_RESID, ws.hq, D, w->proj_w[l], D, w->proj_b[l], nullptr, 0, ws.x, D, nullptr, 0, nullptr,
-                         w->ls1 ? w->ls1[l] : nullptr, N, Mc, D, D, st, nullptr, &sp));
-        RUN(mvf_layernorm_mxfp8_impl(ws.x, D, w->ln2_w[l], w->ln2_b[l], ws.hq, D, ws.hs, Mc, D, w->ln_eps, st,
-                                     defer8 ? ws.delta : nullptr, D));
-        // fc1 + GELU with the MX-fp8 quantisation in its epilogue: hidq / hids straight out of the GEMM (no bf16 hid)
-        RUN(timed_gemm(dtype, EPI_GELU, ws.hq, D, w->fc1_w[l], D, w->fc1_b[l], ws.hidq, 4 * D, nullptr, 0, nullptr, 0, nullptr,
-                       nullptr, N, Mc, 4 * D, D, st, nullptr, &s1));
-        RUN(timed_gemm(dtype, EPI_RESID, ws.hidq, 4 * D, w->fc2_w[l], 4 * D, w->fc2_b[l], nullptr, 0, ws.x, D, tap_ptr, D,
-                       nullptr, w->ls2 ? w->ls2[l] : nullptr, N, Mc, D, 4 * D, st, nullptr, &s2));
-        continue;
-      }
-      if (folded(w->qkv_c, l)) {
-        if (l == 0) return MVF_ERR_ARG;   // nothing produces layer 0's statistics
-        RUN(mvf_ln_stats_finalize_impl(ws.stats, ns, ws.mr, Mc, D, w->ln_eps, st));
-        const MvfGemmLn ln = {nullptr, 0, nullptr, ws.mr, w->qkv_c[l], 0, nullptr};
-        RUN(timed_gemm(dtype, EPI_STORE, ws.xb, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0,
-                       nullptr, nullptr, N, Mc, 3 * D, D, st, &ln));
-      } else {
-        RUN(mvf_layernorm_impl(dtype, ws.x, D, w->ln1_w[l], w->ln1_b[l], ws.h, D, Mc, D, w->ln_eps, st));
-        RUN(timed_gemm(dtype, EPI_STORE, ws.h, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0,
-                       nullptr, nullptr, N, Mc, 3 * D, D, st));
-      }
-      RUN(mvf_vit_attn_impl(dtype, ws.qkv, ws.h, fc, N, H, D, attn_variant, st));
-      const bool fold2 = folded(w->fc1_c, l);
-      // Deferred residual (bf16, no LayerScale, norm2 not folded): proj stores its result (+ bias) as bf16 with the plain
-      // epilogue instead of read-modifying the fp32 residual (310 MB per launch with the matrix cores idle); LayerNorm 2
-      // normalises x + delta and the fc2 epilogue adds delta with its own residual update.  The branch output is rounded to
-      // bf16 before the add -- what the reference's autocast does to it (fp16 there; transformer.py:188).
-      const bool defer = g_proj_defer && dtype == MVF_BF16 && ws.delta != nullptr && !fold2 && w->ls1 == nullptr && D % 128 == 0;
-      if (defer) {
-        RUN(timed_gemm(dtype, EPI_STORE, ws.h, D, w->proj_w[l], D, w->proj_b[l], ws.delta, D, nullptr, 0, nullptr, 0, nullptr,
-                       nullptr, N, Mc, D, D, st));
-      } else {
-        const MvfGemmLn ln = {fold2 ? ws.xb : nullptr, D, fold2 ? ws.stats : nullptr, nullptr, nullptr, 0, nullptr};
-        RUN(timed_gemm(dtype, EPI_RESID, ws.h, D, w->proj_w[l], D, w->proj_b[l], nullptr, 0, ws.x, D, nullptr, 0,
-                       nullptr, w->ls1 ? w->ls1[l] : nullptr, N, Mc, D, D, st, fold2 ? &ln : nullptr));
-      }
-      if (fold2) {
-        RUN(mvf_ln_stats_finalize_impl(ws.stats, ns, ws.mr, Mc, D, w->ln_eps, st));
-        const MvfGemmLn ln = {nullptr, 0, nullptr, ws.mr, w->fc1_c[l], 0, nullptr};
-        RUN(timed_gemm(dtype, EPI_GELU, ws.xb, D, w->fc1_w[l], D, w->fc1_b[l], ws.hid, 4 * D, nullptr, 0, nullptr, 0,
-                       nullptr, nullptr, N, Mc, 4 * D, D, st, &ln));
-      } else {
-        RUN(mvf_layernorm_impl(dtype, ws.x, D, w->ln2_w[l], w->ln2_b[l], ws.h, D, Mc, D, w->ln_eps, st, defer ? ws.delta : nullptr, D));
-        RUN(timed_gemm(dtype, EPI_GELU, ws.h, D, w->fc1_w[l], D, w->fc1_b[l], ws.hid, 4 * D, nullptr, 0, nullptr, 0,
-                       nullptr, nullptr, N, Mc, 4 * D, D, st));
-      }
-      void* tap_ptr = nullptr;
-      if (tap >= 0 && taps_out && taps_out[tap]) tap_ptr = (char*)taps_out[tap] + (size_t)f0 * np * D * esz;
-      const bool fold_next = folded(w->qkv_c, l + 1);
-      {
-        const MvfGemmLn ln = {fold_next ? ws.xb : nullptr, D, fold_next ? ws.stats : nullptr, nullptr, nullptr, 0, nullptr,
-                              defer ? ws.delta : nullptr, D};
-        RUN(timed_gemm(dtype, EPI_RESID, ws.hid, 4 * D, w->fc2_w[l], 4 * D, w->fc2_b[l], nullptr, 0, ws.x, D, tap_ptr,
-                       D, nullptr, w->ls2 ? w->ls2[l] : nullptr, N, Mc, D, 4 * D, st, (fold_next || defer) ? &ln : nullptr));
-      }
-    }
+    RUN(run_blocks(w, dtype, fp8, ws, fc, N, 0, w->depth, taps_out, f0, attn_variant, st));
     if (x_out && hipMemcpyAsync(x_out + (size_t)f0 * N * D, ws.x, (size_t)Mc * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
       return MVF_ERR_ARG;
     if (cls_out)  // final LN on the CLS rows only (timm forward_head, global_pool='token')
       RUN(mvf_layernorm_impl(MVF_F32, ws.x, (size_t)N * D, w->norm_w, w->norm_b, cls_out + (size_t)f0 * D, D, fc, D,
                              w->ln_eps, st));
   }
-#undef RUN
   return MVF_OK;
 }
+
+// Blocks [first_block, first_block + n_blocks) of the backbone on a residual stream the CALLER supplies: x [F*N, dim] fp32,
+// updated in place (timm Block.forward, reached from models/transformer.py:188 through VisionTransformer.forward_features).
+// The per-block ("teacher-forced") parity checks feed every block the oracle's input, so that one block's error is seen on
+// its own instead of through the 12 / 24 blocks behind it.  bf16 with the LayerNorm fold: first_block must be a layer whose
+// norm1 is NOT folded (its statistics would have come from the previous block's epilogue) -- pack with the fold off.
+extern "C" int mvf_vit_blocks_fwd(const MvfVitWeights* w, int dtype, float* x, int F, int first_block, int n_blocks,
+                                  void* workspace, size_t ws_bytes, int attn_variant, hipStream_t st) {
+  MVF_CHECK_ARG(w && x && workspace && F > 0 && first_block >= 0 && n_blocks > 0 && first_block + n_blocks <= w->depth);
+  MVF_CHECK_ARG(dtype == MVF_F32 || dtype == MVF_BF16 || dtype == MVF_FP8);
+  const bool fp8 = dtype == MVF_FP8;
+  if (fp8) {
+    MVF_CHECK_ARG(w->dim % 256 == 0 && w->qkv_s && w->proj_s && w->fc1_s && w->fc2_s && !w->qkv_c && !w->fc1_c);
+    dtype = MVF_BF16;
+  }
+  const int D = w->dim, P = w->patch, img = w->img;
+  MVF_CHECK_ARG(D == w->heads * 64 && img % P == 0 && ((uintptr_t)x % 16) == 0);
+  const int N = (img / P) * (img / P) + 1;
+  Ws ws;
+  MVF_CHECK_ARG(carve(fp8 ? MVF_FP8 : dtype, F, N, D, P, &ws, (char*)workspace) <= ws_bytes);
+  ws.x = x;
+  return run_blocks(w, dtype, fp8, ws, F, N, first_block, first_block + n_blocks, nullptr, 0, attn_variant, st);
+}
+#undef RUN
 
 // ---- profiling hooks (NOT graph-capturable: mvf_prof_collect synchronises the recorded events) ----
 extern "C" int mvf_prof_enable(int on) {

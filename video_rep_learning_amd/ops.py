@@ -1357,6 +1357,19 @@ def vit_front(frames, packed, frames_per_chunk=0):
     return x
 
 
+def vit_blocks(x, packed, first_block, n_blocks=1):
+    """x [F, N, dim] fp32 residual stream -> the stream after blocks [first_block, first_block + n_blocks) (a new tensor):
+    mvf_vit_blocks_fwd, for the per-block parity checks (every block fed the oracle's input)."""
+    if not x.is_cuda:
+        raise _lib.MvfError('vit_blocks received a %s tensor (no CPU fallback)' % x.device)
+    x = x.float().contiguous().clone()
+    F = x.shape[0]
+    ws = packed.workspace(F, x.device)
+    call('mvf_vit_blocks_fwd', ctypes.byref(packed.struct), packed.code, ptr(x), F, first_block, n_blocks, ptr(ws), ws.numel(),
+         0, stream())
+    return x
+
+
 # ------------------------------------------------------------------------------------------------
 # optimiser
 # ------------------------------------------------------------------------------------------------

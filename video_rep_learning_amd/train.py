@@ -161,6 +161,60 @@ def setup_distributed(args):
     return device, world, rank
 
 
+def plumbing_run(cfg, args, model, optimizer, scheduler, algo, train_loader, data_preprocess, device, start_epoch):
+    """`--plumbing` (BASELINE configs[0], "runs without a GPU"): everything of train.py:230-307 AROUND the kernels has already
+    run when this is called -- parser, config merge, LOGDIR/config.yml, process group (gloo), build_model, SyncBN conversion,
+    construct_optimizer (flat buffers, gradient buckets), loaders, load_checkpoint, scheduler.  What is left: one loader batch,
+    a checkpoint round trip, the collectives of an iteration on the flat gradient buffer -- and the first model call, which
+    must FAIL on a device without HIP: the product has no CPU compute path and does not grow one here."""
+    from ._lib import MvfError
+    it = iter(train_loader)
+    videos, _labels, seq_lens, chosen_steps, video_masks, names = next(it)
+    videos = synthetic.preproc_views(videos[0], videos[1], data_preprocess, device)
+    b, t = cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.NUM_FRAMES
+    assert videos.shape[:3] == (b, 2, t) and tuple(seq_lens.shape) == (b, 2) and tuple(chosen_steps.shape) == (b, 2, t)
+    # checkpoint round trip in the reference's format (models/__init__.py:17-60): parameters, BN buffers, Adam state
+    before = {k: v.detach().clone() for k, v in model.module.state_dict().items()}
+    if du.is_root_proc():
+        save_checkpoint(cfg, model, optimizer, start_epoch)
+    du.synchronize()
+    with torch.no_grad():
+        for p in model.module.parameters():
+            if p.requires_grad:
+                p.add_(1.0)
+    restored = load_checkpoint(cfg, model, optimizer)
+    after = model.module.state_dict()
+    assert restored == start_epoch + 1 and all(torch.equal(before[k], after[k]) for k in before), 'checkpoint round trip'
+    # the iteration's collectives on host tensors (gloo): gradient buckets of the flat buffer, loss all-reduce
+    optimizer.zero_grad()
+    if hasattr(optimizer, 'reducer'):
+        optimizer.flat.flat_g.fill_(float(du.get_rank() + 1))
+        active = optimizer.reducer.active
+        gscale = optimizer.reducer.finish()          # launches every bucket's all-reduce (SUM) and waits
+        want = float(sum(range(1, du.get_world_size() + 1))) if active else float(du.get_rank() + 1)
+        assert gscale == 1.0 / du.get_world_size()
+        assert torch.equal(optimizer.flat.flat_g, torch.full_like(optimizer.flat.flat_g, want)), 'gradient all-reduce'
+        optimizer.zero_grad()
+    loss_log = du.all_reduce([torch.tensor([float(du.get_rank())])])[0].item()
+    assert abs(loss_log - (du.get_world_size() - 1) / 2.0) < 1e-6
+    assert get_lr(optimizer)[0] == cfg.OPTIMIZER.LR.INITIAL_LR or cfg.OPTIMIZER.LR.DECAY_TYPE == 'cosinewarmup'
+    reached = None
+    try:
+        algo.compute_loss(model, videos, seq_lens, chosen_steps, video_masks)
+    except MvfError as e:
+        reached = str(e)
+    if reached is None:
+        raise RuntimeError('--plumbing expects a device without HIP: the model call succeeded, so this is a real run -- drop the flag')
+    logger.info('plumbing run complete on %s/%s: config, process group, model (%d parameters), optimizer (%d trainable), loader, '
+                'checkpoint round trip, collectives; stopped at the first kernel call: %s' % (
+                    device, args.backend or 'gloo', sum(p.numel() for p in model.parameters()),
+                    optimizer.flat.numel if hasattr(optimizer, 'flat') else -1, reached))
+    du.synchronize()
+    if du.is_dist():
+        torch.distributed.destroy_process_group()
+    return {'plumbing': True, 'stopped_at': reached}
+
+
 def main(argv=None):
     args = parse_args(argv)
     cfg = load_config(args)
@@ -199,6 +253,8 @@ def main(argv=None):
     start_epoch = load_checkpoint(cfg, model, optimizer)
     cfg.TRAIN.MAX_ITERS = cfg.TRAIN.MAX_EPOCHS * len(train_loader)
     scheduler = construct_scheduler(optimizer, cfg)
+    if args.plumbing:
+        return plumbing_run(cfg, args, model, optimizer, scheduler, algo, train_loader, train_preproc, device, start_epoch)
     for cur_epoch in range(start_epoch, cfg.TRAIN.MAX_EPOCHS):
         logger.info(f'Traning epoch {cur_epoch}/{cfg.TRAIN.MAX_EPOCHS}, {len(train_loader)} iters each epoch')
         t0 = time.time()

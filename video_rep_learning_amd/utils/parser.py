@@ -3,7 +3,7 @@
 SHALLOWLY over the defaults (a top-level key of the file replaces the default block), `--opts` values typed after the
 value they replace, EVAL batch size / frame count tied to TRAIN's, and LOGDIR/config.yml written on first use and re-read
 on later runs.  Added for this build: `--local-rank` / LOCAL_RANK (torchrun), `--device`, `--backend`, `--synthetic`,
-`--synthetic_raw H W`, `--max_iters`, and creation of the optional MI355X.* / MODEL.EMBEDDER_MODEL.* keys from `--opts`."""
+`--synthetic_raw H W`, `--max_iters`, `--plumbing`, and creation of the optional MI355X.* / MODEL.EMBEDDER_MODEL.* keys from `--opts`."""
 import argparse
 import os
 
@@ -31,6 +31,10 @@ _OPTIONS = (
                                 help='synthetic clips as RAW [0,1] frames of this size: the GPU-side augmentation runs '
                                      'in the loop')),
     (('--max_iters',), dict(type=int, default=0, help='stop each epoch after this many iterations (0 = full)')),
+    (('--plumbing',), dict(action='store_true', default=False,
+                           help='BASELINE configs[0] without a GPU (--device cpu --backend gloo): run everything around the '
+                                'kernels -- config, process group, model and optimizer construction, loader, checkpoint save and '
+                                'restore -- and stop at the first HIP call, which raises (there is NO CPU compute path)')),
     (('--opts',), dict(default=None, nargs=argparse.REMAINDER, help='KEY VALUE pairs overriding the config')),
 )
 # sections whose keys are probed with `in` by the model code and may therefore be introduced from the command line

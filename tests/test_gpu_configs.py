@@ -162,7 +162,7 @@ def test_full_size_fp32_and_bf16_vs_oracle(tag):
     assert e_emb <= 1e-3 and e_loss <= 1e-3, (e_emb, e_loss)          # the north-star gate
     # the flipped units also perturb every gradient upstream of them a little (measured up to 5.0e-3 on the pooling queries of
     # the 1536-wide fg99 head; 6e-4 .. 4.5e-3 on the other two configs): those stay under the 1e-2 gate
-    assert flips <= 4 * T.FLIP_MAX and worst_raw[0] <= 5e-2, (flips, worst_raw, worst)
+    assert flips <= T.flip_bound(nelem) and worst_raw[0] <= 5e-2, (flips, worst_raw, worst)
     # ---- bf16 mode (the benchmarked dtype)
     r = T.bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, ref_emb_fp32=remb)
     record_parity('%s HIP bf16: %s' % (tag, r['text']))
@@ -170,7 +170,7 @@ def test_full_size_fp32_and_bf16_vs_oracle(tag):
     # 1.6e-2 .. 1.8e-2 against the fp32 oracle).  The two sides differ by fp32 summation order and by bf16 roundings that flip
     # where a value sits on a rounding boundary (one bf16 ulp of a tap's largest element is 3.9e-3)
     assert r['emb'] <= 2e-3 and r['loss'] <= 2e-3 and r['emb_fp32'] <= 5e-2, r
-    assert r['loss_head'] <= 1e-3 and r['flips'] <= 4 * T.FLIP_MAX and r['head_grad_raw'] <= 0.1, r
+    assert r['loss_head'] <= 1e-3 and r['flips'] <= T.flip_bound(r['nelem']) and r['head_grad_raw'] <= 0.1, r
     assert r['grad_cos'] >= 0.98, r
 
 
@@ -228,7 +228,7 @@ def test_config4_per_block_teacher_forced_fp8_and_bf16():
     x = torch.randn(F, 3, img, img, generator=torch.Generator().manual_seed(42))
     sd = {k: v.to(DEV) for k, v in w.items()}
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
-    for mode, gate in (('fp8', 3e-2), ('bf16', 1.5e-2)):
+    for mode, gate in (('fp8', 3e-2), ('bf16', 5e-3)):      # measured 1.1e-2 .. 1.8e-2 / 1.4e-3 .. 1.7e-3
         pk = ops.PackedViT(sd, depth, dim, heads, patch, img, (), mode, ln_fold=0)
         emul = 'fp8' if mode == 'fp8' else 'bf16_nofold'      # a block on its own cannot consume a folded LayerNorm
         worst = (0.0, -1)
@@ -255,10 +255,10 @@ def test_config4_full_step(mode):
     config is a multiple of this).  The backbone's own parity is the two tests above; here the oracle HEAD and loss run on the
     device's taps, and the device loss / every head gradient must match them at the fp32 gates: the pooling, the temporal
     encoder over S = 96 and the SCL kernels at this config's widths."""
-    cfg, model = T.make(23, network='TIMM-vit_large_patch14_dinov2.lvd142m', num_frames=32, batch_size=1, image_size=336,
-                        dropout=0.0, compute_dtype=mode, SMART_FEATS='7,15,23')
+    cfg, model = T.make(23, layer=24, network='TIMM-vit_large_patch14_dinov2.lvd142m', num_frames=32, batch_size=1, image_size=336,
+                        dropout=0.0, compute_dtype=mode, SMART_FEATS='7,15,23')      # LAYER = depth: fully frozen backbone
     videos, seq_lens, steps, masks = T.batch(cfg, 24, pad=3)
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     r = T.bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, mode=mode, end_to_end=False)
     record_parity('configs[4] full step (ViT-L/14 @ 336, T=32, 2 clips) HIP %s: %s' % (mode, r['text']))
-    assert r['loss_head'] <= 1e-3 and r['flips'] <= 4 * T.FLIP_MAX and r['head_grad_raw'] <= 0.1, r
+    assert r['loss_head'] <= 1e-3 and r['flips'] <= T.flip_bound(r['nelem']) and r['head_grad_raw'] <= 0.1, r

@@ -4,7 +4,7 @@ persistent GEMM.  Usage: python3 tools/trace_overlap.py <dir>"""
 import csv
 import glob
 import sys
-from collections import defaultdict
+from collections import Counter, defaultdict
 
 files = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)
 rows = []
@@ -23,7 +23,10 @@ gemm = [(s, e, q) for s, e, n, q in rows if 'gemm_tc256' in n]
 
 
 def group(n):
-    for k in ('gemm_tc256', 'layernorm_kernel', 'vit_attn', 'im2col', 'ln_stats_finalize', 'lstp', 'hgemm', 'hlinear_bwd', 'tattn', 'adam', 'scl_'):
+    n_l = n.lower()
+    if 'nccl' in n_l:
+        return 'nccl'
+    for k in ('nccl', 'gemm_tc256', 'layernorm_kernel', 'vit_attn', 'im2col', 'ln_stats_finalize', 'lstp', 'hgemm', 'hlinear_bwd', 'tattn', 'adam', 'scl_'):
         if k in n:
             return k
     return 'other'
@@ -42,6 +45,16 @@ for s, e, n, q in rows:
         if gq == q: continue
         o += max(0, min(e, ge) - max(s, gs))
     ov[g] += min(o, e - s)
+# every RCCL kernel: when did it run relative to the kernels of the other queues?
+nccl = [(s, e, n, q) for s, e, n, q in rows if 'nccl' in n.lower()]
+if nccl:
+    print('RCCL kernels in the steady-state window: %d' % len(nccl))
+    for s, e, n, q in nccl[:40]:
+        conc = Counter()
+        for s2, e2, n2, q2 in rows:
+            if q2 != q and s2 < e and e2 > s:
+                conc[group(n2)] += 1
+        print('  %-44s %7.1f us  concurrent kernels of other queues: %s' % (n[:44], (e - s) / 1e3, dict(conc) or 'none'))
 span = rows[-1][1] - rows[0][0]
 print('trace', sys.argv[1], 'steady-state span %.2f ms' % (span / 1e6))
 for g in sorted(busy, key=lambda k: -busy[k]):

@@ -78,19 +78,43 @@ __device__ __forceinline__ float row_quad_sum(float v) {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-// GELU for bf16 outputs: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below bf16's 2^-9 rounding) on the
-// hardware exp2/rcp: ~14 VALU per element instead of erff's ~45 -- the exact-erf epilogue cost a third of the fc1 GEMM.
+// GELU for bf16 outputs on ONE transcendental: x Phi(x) = max(x, 0) - |x|/2 * erfc(|x| / sqrt 2) with
+// erfc(z) = (1 + a1 z + .. + a6 z^6)^-16 (Abramowitz-Stegun 7.1.28, |abs err| <= 3e-7; in fp32 arithmetic the GELU is
+// within 7e-7 absolute and 2.8e-4 relative wherever |gelu| > 1e-3 -- bf16 rounds at 2^-9).  6 fma + 4 squarings + rcp:
+// ~10 VALU issue slots per element where erff takes ~45 and the 7.1.26 form used before (rcp AND exp2, 14 slots; the fc1
+// epilogue is VALU-bound: 1750 VALU instructions per wave and tile) took a quarter more.  The max / fma form has no
+// cancellation on either side of 0 (0.5 x (1 + erf) loses the negative tail to the rounding of 1 + erf).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// two elements at a time, written on 2-vectors: the polynomial, the squarings and the last fma are v_pk_fma_f32 / v_pk_mul_f32
+// (left to the SLP vectoriser, the literal constants of the scalar form end up in v_fmaak_f32 and nothing is packed)
+__device__ __forceinline__ f32x2_t gelu_erf_fast2(f32x2_t x) {
+  const f32x2_t z = {fabsf(x.x) * 0.70710678118654752440f, fabsf(x.y) * 0.70710678118654752440f};   // |.| is a source modifier
+  const f32x2_t a6 = {0.0000430638f, 0.0000430638f}, a5 = {0.0002765672f, 0.0002765672f}, a4 = {0.0001520143f, 0.0001520143f},
+                a3 = {0.0092705272f, 0.0092705272f}, a2 = {0.0422820123f, 0.0422820123f}, a1 = {0.0705230784f, 0.0705230784f},
+                one = {1.0f, 1.0f};
+  f32x2_t p = __builtin_elementwise_fma(a6, z, a5);
+  p = __builtin_elementwise_fma(p, z, a4);
+  p = __builtin_elementwise_fma(p, z, a3);
+  p = __builtin_elementwise_fma(p, z, a2);
+  p = __builtin_elementwise_fma(p, z, a1);
+  f32x2_t d = __builtin_elementwise_fma(p, z, one);
+  d *= d;
+  d *= d;
+  d *= d;
+  d *= d;                                                  // overflows to +inf beyond |x| ~ 13: rcp -> 0, gelu -> max(x, 0)
+  const f32x2_t r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};   // erfc(|x| / sqrt 2)
+  const f32x2_t nh = {-0.5f * fabsf(x.x), -0.5f * fabsf(x.y)};
+  const f32x2_t pos = {fmaxf(x.x, 0.0f), fmaxf(x.y, 0.0f)};
+  return __builtin_elementwise_fma(nh, r, pos);
+}
 __device__ __forceinline__ float gelu_erf_fast(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  p *= t;
-  const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
-  const float erf_abs = fmaf(-p, e, 1.0f);                 // erf(|x|/sqrt2)
-  return 0.5f * x + 0.5f * fabsf(x) * erf_abs;             // 0.5 x (1 + sign(x) erf_abs)
+  const f32x2_t v = {x, x};
+  return gelu_erf_fast2(v).x;
+}
+// in place on the four values of a lane's accumulator-tile row
+__device__ __forceinline__ void gelu_erf_fast4(float (&v)[4]) {
+  const f32x2_t a = gelu_erf_fast2((f32x2_t){v[0], v[1]}), b = gelu_erf_fast2((f32x2_t){v[2], v[3]});
+  v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
 }
 
 __device__ __forceinline__ float4 add_bf16x4(float4 v, uint2 u);
@@ -236,8 +260,8 @@ __device__ __forceinline__ void epilogue_pair_bf16(const GemmTcArgs& a, int m, b
   if constexpr (EPI == EPI_STORE) {
     swap_store_bf16x8(a.C, (size_t)m * a.ldc, nb, fgrp, ok, v0, v1);
   } else if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { v0[r] = gelu_erf_fast(v0[r]); v1[r] = gelu_erf_fast(v1[r]); }
+    gelu_erf_fast4(v0);
+    gelu_erf_fast4(v1);
     swap_store_bf16x8(a.C, (size_t)m * a.ldc, nb, fgrp, ok, v0, v1);
   } else if constexpr (EPI == EPI_RESID) {
     bool tap_ok = false;
@@ -294,8 +318,8 @@ __device__ __forceinline__ void epilogue_pair_bf16_ln(const GemmTcArgs& a, int m
   if constexpr (EPI == EPI_STORE) {
     swap_store_bf16x8(a.C, (size_t)m * a.ldc, nb, fgrp, ok, v0, v1);
   } else if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { v0[r] = gelu_erf_fast(v0[r]); v1[r] = gelu_erf_fast(v1[r]); }
+    gelu_erf_fast4(v0);
+    gelu_erf_fast4(v1);
     swap_store_bf16x8(a.C, (size_t)m * a.ldc, nb, fgrp, ok, v0, v1);
   } else if constexpr (EPI == EPI_RESID) {
     bool tap_ok = false;
@@ -348,12 +372,10 @@ __device__ __forceinline__ unsigned epilogue_pair_gelu_q(const GemmTcArgs& a, in
   float v0[4] = {acc0[0] + b0.x, acc0[1] + b0.y, acc0[2] + b0.z, acc0[3] + b0.w};
   float v1[4] = {acc1[0] + b1.x, acc1[1] + b1.y, acc1[2] + b1.z, acc1[3] + b1.w};
   float amax = 0.f;
+  gelu_erf_fast4(v0);
+  gelu_erf_fast4(v1);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    v0[r] = gelu_erf_fast(v0[r]);
-    v1[r] = gelu_erf_fast(v1[r]);
-    amax = fmaxf(amax, fmaxf(fabsf(v0[r]), fabsf(v1[r])));
-  }
+  for (int r = 0; r < 4; ++r) amax = fmaxf(amax, fmaxf(fabsf(v0[r]), fabsf(v1[r])));
   amax = row_quad_max(amax);
   const unsigned sb = mx_scale_byte(amax);
   const float inv = mx_inv_scale(sb);

@@ -282,9 +282,9 @@ def main():
     from video_rep_learning_amd.train import DataParallelModel
     from video_rep_learning_amd.datasets import synthetic
 
+    from video_rep_learning_amd import ops
     if a.serial:
-        from video_rep_learning_amd import ops as _ops
-        _ops.VIT_LANE_MIN_ROWS = 1 << 62
+        ops.VIT_LANE_MIN_ROWS = 1 << 62
     cfg = presets.baseline_config_2(compute_dtype=a.dtype)     # penn_mvf.yml + ViT-B/16, T=32, B=4 (dropout 0.1 kept)
     torch.manual_seed(cfg.RNG_SEED)
     model = build_model(cfg, local).to(dev)
@@ -313,7 +313,7 @@ def main():
             wrapped.prefetch(videos)
         opt.zero_grad()
         loss = algo.compute_loss(wrapped, videos, seq_lens, steps, masks)['loss']
-        loss.backward()
+        ops.backward(loss)                 # as train.train does: loss.backward() with a cached seed gradient
         opt.step(max_norm=clip)
         return loss
 
@@ -345,7 +345,6 @@ def main():
     # flight together (a launch's event-to-event time would then include the other streams' kernels), so these extra
     # steps run the backbone as one lane, without lookahead -- the same serial order rocprofv3 records.  EVERY rank runs
     # them (a step contains the gradient all-reduce and the SyncBN exchanges); only rank 0 records and reports.
-    from video_rep_learning_amd import ops
     lane_rows, ops.VIT_LANE_MIN_ROWS = ops.VIT_LANE_MIN_ROWS, 1 << 62
     step(lookahead=False)                  # drains the primed forward
     torch.cuda.synchronize()

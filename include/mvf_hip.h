@@ -257,6 +257,10 @@ int mvf_ln_fwd(const float* x, const float* g, const float* b, float* y, float* 
                float eps, hipStream_t stream);
 int mvf_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, float* dx, float* dg,
                float* db, int rows, int D, int accumulate_dx, int accumulate_params, hipStream_t stream);
+/* dx = dres + d LN / dx (dy): x of a pre-LN residual connection x + sub(LN(x)) (ResidualConnection, models/utils.py:147-159)
+ * receives two gradients, the residual path's (dres) and the LayerNorm's; summed in the LayerNorm backward's pass */
+int mvf_ln_bwd_res(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, const float* dres,
+                   float* dx, float* dg, float* db, int rows, int D, int accumulate_params, hipStream_t stream);
 
 /* BatchNorm1d (+fused ReLU)  (models/mvformer.py:78-79, resnet_c2d.py:118-119); SyncBN = caller merges the
  * (mean, var) / (s1, s2) vectors across ranks between the two halves (train.py:283) */
@@ -281,13 +285,15 @@ int mvf_l2norm_fwd(const float* x, float* y, float* nrm, int rows, int D, float 
 int mvf_l2norm_bwd(const float* dy, const float* y, const float* nrm, float* dx, int rows, int D, float eps,
                    hipStream_t stream);
 
-/* temporal multi-head self-attention (models/utils.py:11-44,88-104); qkv [B*S, 3*Dm], mask [B,S] or NULL */
+/* temporal multi-head self-attention (models/utils.py:11-44,88-104); qkv [B*S, 3*Dm]; mask [B, mask_len] or NULL (1 = keep,
+ * 0 = masked key), key s reading column s % mask_len: mask_len = S is a plain key mask, mask_len = T the frame mask of the joint
+ * (entity, frame) sequence S = ntok * T, which mvformer.py:171-172 tiles to [B, 1, S] first */
 /* 1 = scalar-FMA kernels only (cross-check, A/B), 0 = fp32 matrix-core kernels when dk is 16, 32 or 64 (default) */
 int mvf_tattn_select(int scalar_only);
-int mvf_tattn_fwd(const float* qkv, const float* mask, float* o, float* lse, int B, int S, int H, int Dm,
+int mvf_tattn_fwd(const float* qkv, const float* mask, int mask_len, float* o, float* lse, int B, int S, int H, int Dm,
                   hipStream_t stream);
-int mvf_tattn_bwd(const float* qkv, const float* mask, const float* o, const float* lse, const float* d_o, float* dqkv,
-                  int B, int S, int H, int Dm, hipStream_t stream);
+int mvf_tattn_bwd(const float* qkv, const float* mask, int mask_len, const float* o, const float* lse, const float* d_o,
+                  float* dqkv, int B, int S, int H, int Dm, hipStream_t stream);
 
 /* LSTP learned-query pooling passes over the tap tensors (models/mvformer.py:243-266,352-414) */
 int mvf_lstp_scores(const void* const* taps_host, int n_taps, int dtype, int D, int F, int N, int T, int nq,
@@ -313,6 +319,11 @@ int mvf_lstp_dx(float* const* dx_host, int n_taps, int D, int F, int N, int T, i
  * Sequence-contrastive loss (algos/scl.py:52-105), fused forward / backward
  *   negative_flags: bit0 'single' in NEGATIVE_TYPE, bit1 'noself' in NEGATIVE_TYPE
  * ---------------------------------------------------------------------------------------------- */
+/* rows[3][M], M = clips * T: chosen_steps [clips, T] int64, seq_lens [clips] int64 (repeated over the clip's frames) and
+ * video_masks [clips, T] fp32 (NULL = ones) as per-row floats -- the reshape / expand / float() prologue of
+ * compute_sequence_loss (algos/scl.py:52-64) in one launch */
+int mvf_scl_rows(const long long* steps, const long long* seq_lens, const float* masks, float* rows, int clips, int T,
+                 hipStream_t stream);
 int mvf_scl_fwd(const float* emb, const float* step, const float* len, const float* mask, float* S, float* R, float* c,
                 float* lossrow, float* loss, int M, int E, int T, int negative_flags, float temperature,
                 float label_variance, hipStream_t stream);
@@ -327,8 +338,11 @@ int mvf_scl_bwd(const float* emb, const float* step, const float* len, const flo
  * mvf_adam_step given that pair skips the update on a non-finite norm and leaves skipped steps out of its bias correction --
  * the GradScaler.step behaviour of the reference's fp16 path (train.py:127-133). */
 int mvf_grad_norm(const float* g, size_t n, const float* extra_sq, float* scratch, float* norm_out, hipStream_t stream);
-int mvf_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, int step, float clip, const float* norm, float gscale, hipStream_t stream);
+/* zero_grad != 0: g is zeroed as it is consumed (and when the step is skipped): the next iteration's optimizer.zero_grad()
+ * (train.py:113) costs no pass of its own */
+int mvf_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, float clip, const float* norm, float gscale, int zero_grad,
+                  hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GPU-side view augmentation: one clip [T,3,H,W] of floats in [0,1] -> [T,3,S,S], normalised

@@ -306,11 +306,14 @@ def flip_census(got, ref, scale, gate):
     off in the other, which moves ONE bias-gradient element (and one row of the weight gradient in front of it) by that token's
     whole share.  The tests bound how MANY elements sit above the kernels' gate and how far, instead of trimming a fixed
     fraction."""
-    d = (got.double() - ref.double()).abs().flatten() / scale
+    d = (got.double() - ref.double()).abs() / scale
     over = d > gate
     n = int(over.sum())
     rest = d[~over]
-    return n, (d.max().item() if d.numel() else 0.0), (rest.max().item() if rest.numel() else 0.0)
+    # output units (rows of a weight, elements of a bias) that hold the elements above the gate: a flipped ReLU unit shows as ONE
+    # row of the weight gradient of its layer and one element of its bias gradient
+    rows = int(over.reshape(over.shape[0], -1).any(dim=1).sum()) if over.dim() >= 1 and n else 0
+    return n, (d.max().item() if d.numel() else 0.0), (rest.max().item() if rest.numel() else 0.0), rows
 
 
 def bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, ref_emb_fp32=None, mode='bf16', end_to_end=True, gate=2e-2):
@@ -358,12 +361,13 @@ def bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, ref_emb_fp32=No
     gscale = max(g.abs().max().item() for g in g_dev.values())
     census = {n: flip_census(got[n], g_dev[n], max(g_dev[n].abs().max().item(), 1e-2 * gscale), gate) for n in g_dev if n in got}
     flips = sum(c[0] for c in census.values())
+    flip_rows = sum(c[3] for c in census.values())
     nelem = sum(got[n].numel() for n in census)
     worst_raw = max((c[1], n) for n, c in census.items())
     worst = max((c[2], n) for n, c in census.items())
     det = sorted((c[1], c[0], got[n].numel(), n) for n, c in census.items())[-3:]
     out = dict(loss_head=relerr(loss, lref_dev), head_grad=worst[0], head_grad_raw=worst_raw[0], head_grad_name=worst[1],
-               flips=flips, nelem=nelem,
+               flips=flips, flip_rows=flip_rows, nelem=nelem,
                emb_fp32=relerr(emb, ref_emb_fp32) if ref_emb_fp32 is not None else float('nan'))
     txt = ''
     if end_to_end:
@@ -375,9 +379,9 @@ def bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, ref_emb_fp32=No
         txt = ('embeddings max-rel %.3e vs %s-emulating oracle (%.3e vs fp32 oracle); SCL loss %.6f vs %.6f rel %.3e; '
                'head-gradient cosine vs emulating oracle %.5f; ' % (out['emb'], mode, out['emb_fp32'], loss.item(), lref16.item(),
                                                                   out['loss'], cos))
-    out['text'] = txt + ('oracle head on the DEVICE taps: loss %.6f rel %.3e, head gradients: %d of %d elements above the %.0e gate '
+    out['text'] = txt + ('oracle head on the DEVICE taps: loss %.6f rel %.3e, head gradients: %d of %d elements in %d rows above the %.0e gate '
                          '(ReLU flips), the largest %.3e (%s), every other element <= %.3e (%s)' % (
-                             loss.item(), out['loss_head'], flips, nelem, gate, worst_raw[0], worst_raw[1], worst[0], worst[1]))
+                             loss.item(), out['loss_head'], flips, nelem, flip_rows, gate, worst_raw[0], worst_raw[1], worst[0], worst[1]))
     out['text'] += '; top-3 ' + ', '.join('%s %.2e (%d of %d elements above the gate)' % (n, e, k, tot) for e, k, tot, n in det)
     return out
 

@@ -16,6 +16,7 @@ from video_rep_learning_amd.models import build_model  # noqa: E402
 from video_rep_learning_amd.algos import get_algo  # noqa: E402
 from video_rep_learning_amd.train import DataParallelModel  # noqa: E402
 from video_rep_learning_amd.datasets import synthetic  # noqa: E402
+from video_rep_learning_amd import ops  # noqa: E402
 
 
 def main():
@@ -37,14 +38,14 @@ def main():
         wrapped.prefetch(videos)
         opt.zero_grad()
         loss = algo.compute_loss(wrapped, videos, seq_lens, stp, masks)['loss']
-        loss.backward()
+        ops.backward(loss)
         opt.step(max_norm=cfg.OPTIMIZER.GRAD_CLIP)
 
     wrapped.prefetch(videos)
     for _ in range(5):
         step()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
@@ -63,6 +64,12 @@ def main():
                 continue
             frames = [f for f in (ev.stack or []) if 'video_rep_learning_amd' in f or 'bench.py' in f or 'aten_hunt' in f]
             site = ' <- '.join(fr.split('video_rep_learning_amd/')[-1] for fr in frames[:3]) or '(no repo frame: autograd engine / runtime)'
+            chain, par = [], getattr(ev, 'cpu_parent', None)
+            while par is not None and len(chain) < 4:
+                chain.append(par.name[:40])
+                par = getattr(par, 'cpu_parent', None)
+            site = 'inside ' + ' < '.join(chain) if chain else site
+            site += '   shapes ' + str(getattr(ev, 'input_shapes', None))[:100] + ('  thread %s' % ev.thread)
             by_site[(ev.name, kn[:70])][site] += 1
     print('non-library device kernels over %d steps (op, kernel): count per call site' % steps)
     for (op, kn), sites in sorted(by_site.items(), key=lambda kv: -sum(kv[1].values())):

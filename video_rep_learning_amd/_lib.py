@@ -66,6 +66,7 @@ SIGNATURES = {
     'mvf_dropout_add': 'pppzfuup',
     'mvf_ln_fwd': 'ppppppiifp',
     'mvf_ln_bwd': 'ppppppppiiiip',
+    'mvf_ln_bwd_res': 'pppppppppiiip',
     'mvf_bn_workspace_floats': 'ii',
     'mvf_bn_stats': 'piippppfpzp',
     'mvf_bn_fwd': 'ppppppiifip',
@@ -77,8 +78,8 @@ SIGNATURES = {
     'mvf_l2norm_fwd': 'pppiifp',
     'mvf_l2norm_bwd': 'ppppiifp',
     'mvf_tattn_select': 'i',
-    'mvf_tattn_fwd': 'ppppiiiip',
-    'mvf_tattn_bwd': 'ppppppiiiip',
+    'mvf_tattn_fwd': 'ppippiiiip',
+    'mvf_tattn_bwd': 'ppippppiiiip',
     'mvf_lstp_scores': 'piiiiiiipipp',
     'mvf_lstp_wsum': 'piiiiiiippp',
     'mvf_lstp_softmax_fwd': 'ppppiiifip',
@@ -86,10 +87,11 @@ SIGNATURES = {
     'mvf_lstp_reduce_frames': 'ppiiiip',
     'mvf_token_pool': 'piiiiiipp',
     'mvf_lstp_dx': 'piiiiiippppip',
+    'mvf_scl_rows': 'ppppiip',
     'mvf_scl_fwd': 'pppppppppiiiiffp',
     'mvf_scl_bwd': 'pppppppppiiiiiiffp',
     'mvf_grad_norm': 'pzpppp',
-    'mvf_adam_step': 'ppppzfffffifpfp',
+    'mvf_adam_step': 'ppppzfffffifpfip',
     'mvf_augment_workspace_bytes': 'iii',
     'mvf_augment_clips': 'ppiiiiippzp',
 }

@@ -46,9 +46,13 @@ class SCL(object):
         assert num_views == 2
         m_local = batch_size * num_views * num_frames
         e = embs.reshape(m_local, channels)
-        st = steps.reshape(m_local).float()
-        ln = seq_lens.reshape(batch_size, num_views, 1).expand(batch_size, num_views, num_frames).reshape(m_local).float()
-        mk = masks.reshape(m_local).float()
+        per_row = ops.scl_rows(steps, seq_lens, masks) if masks is not None else None     # one launch for the three vectors
+        if per_row is not None:
+            st, ln, mk = per_row[0], per_row[1], per_row[2]
+        else:
+            st = steps.reshape(m_local).float()
+            ln = seq_lens.reshape(batch_size, num_views, 1).expand(batch_size, num_views, num_frames).reshape(m_local).float()
+            mk = masks.reshape(m_local).float()
         row0, rows, scale = 0, None, 1.0
         if self.gather and 'single' not in self.negative_type and du.collectives_active():
             ws, rk = du.get_world_size(), du.get_rank()

@@ -20,7 +20,8 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 struct TAttnArgs {
   const float* qkv;    // [B*S, 3*Dm]
-  const float* mask;   // [B, S] (1 keep / 0 masked) or null
+  const float* mask;   // [B, Sm] (1 keep / 0 masked) or null; key s reads column s % Sm (Sm = S: a plain key mask;
+  int Sm;              // Sm = T for the joint entity x frame sequence, whose keys (j, t) share the frame mask [B, T])
   float* o;            // [B*S, Dm]
   float* lse;          // [B, H, S]  log2-domain log-sum-exp of scaled scores
   const float* d_o;    // [B*S, Dm]
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(TQ) void tattn_fwd_kernel(TAttnArgs a) {
     }
     if (threadIdx.x < TK) {
       const int key = k0 + threadIdx.x;
-      sm[threadIdx.x] = (key < a.S && (a.mask == nullptr || a.mask[(size_t)b * a.S + key] != 0.f)) ? 1.f : 0.f;
+      sm[threadIdx.x] = (key < a.S && (a.mask == nullptr || a.mask[(size_t)b * a.Sm + key % a.Sm] != 0.f)) ? 1.f : 0.f;
     }
     __syncthreads();
     for (int c0 = 0; c0 < TK; c0 += 8) {
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(TQ) void tattn_bwd_dq_kernel(TAttnArgs a) {
     }
     if (threadIdx.x < TK) {
       const int key = k0 + threadIdx.x;
-      sm[threadIdx.x] = (key < a.S && (a.mask == nullptr || a.mask[(size_t)b * a.S + key] != 0.f)) ? 1.f : 0.f;
+      sm[threadIdx.x] = (key < a.S && (a.mask == nullptr || a.mask[(size_t)b * a.Sm + key % a.Sm] != 0.f)) ? 1.f : 0.f;
     }
     __syncthreads();
     for (int j = 0; j < TK; ++j) {
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(TQ) void tattn_bwd_dkv_kernel(TAttnArgs a) {
 #pragma unroll
     for (int d = 0; d < DK; ++d) { k[d] = kp[d] * a.scale_log2; v[d] = vp[d]; dk[d] = 0.f; dv[d] = 0.f; }
   }
-  const bool keep = kvalid && (a.mask == nullptr || a.mask[(size_t)b * a.S + kc] != 0.f);
+  const bool keep = kvalid && (a.mask == nullptr || a.mask[(size_t)b * a.Sm + kc % a.Sm] != 0.f);
   for (int q0 = 0; q0 < a.S; q0 += TK) {
     __syncthreads();
     for (int i = threadIdx.x; i < TK * (DK / 4); i += TQ) {
@@ -271,33 +272,35 @@ extern "C" int mvf_tattn_select(int scalar_only) {
   return MVF_OK;
 }
 
-extern "C" int mvf_tattn_fwd(const float* qkv, const float* mask, float* o, float* lse, int B, int S, int H, int Dm,
-                             hipStream_t st) {
+extern "C" int mvf_tattn_fwd(const float* qkv, const float* mask, int mask_len, float* o, float* lse, int B, int S, int H,
+                             int Dm, hipStream_t st) {
   MVF_CHECK_ARG(qkv && o && lse && B > 0 && S > 0 && H > 0 && Dm % H == 0 && Dm % 4 == 0);
+  MVF_CHECK_ARG(mask == nullptr || (mask_len > 0 && S % mask_len == 0));
   MVF_CHECK_ARG(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 15) == 0);
   if ((Dm / H) % 16 == 0 && g_tattn_scalar == 0) {   // matrix-core path (head_attn_mfma.hip)
-    const int rc = mvf_tattn_mfma(0, qkv, mask, o, lse, nullptr, nullptr, B, S, H, Dm, st);
+    const int rc = mvf_tattn_mfma(0, qkv, mask, mask_len, o, lse, nullptr, nullptr, B, S, H, Dm, st);
     if (rc != MVF_ERR_UNSUPPORTED) return rc;
   }
   TAttnArgs a{};
-  a.qkv = qkv; a.mask = mask; a.o = o; a.lse = lse; a.B = B; a.S = S; a.H = H; a.Dm = Dm;
+  a.qkv = qkv; a.mask = mask; a.Sm = mask != nullptr ? mask_len : S; a.o = o; a.lse = lse; a.B = B; a.S = S; a.H = H; a.Dm = Dm;
   const int dk = Dm / H;
   a.scale = 1.0f / sqrtf((float)dk);
   a.scale_log2 = a.scale * LOG2E;
   return dispatch(0, dk, a, st);
 }
 
-extern "C" int mvf_tattn_bwd(const float* qkv, const float* mask, const float* o, const float* lse, const float* d_o,
-                             float* dqkv, int B, int S, int H, int Dm, hipStream_t st) {
+extern "C" int mvf_tattn_bwd(const float* qkv, const float* mask, int mask_len, const float* o, const float* lse,
+                             const float* d_o, float* dqkv, int B, int S, int H, int Dm, hipStream_t st) {
   MVF_CHECK_ARG(qkv && o && lse && d_o && dqkv && B > 0 && S > 0 && H > 0 && Dm % H == 0 && Dm % 4 == 0);
+  MVF_CHECK_ARG(mask == nullptr || (mask_len > 0 && S % mask_len == 0));
   MVF_CHECK_ARG(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)dqkv & 15) == 0 && ((uintptr_t)d_o & 15) == 0);
   if ((Dm / H) % 16 == 0 && g_tattn_scalar == 0) {
-    const int rc = mvf_tattn_mfma(1, qkv, mask, const_cast<float*>(o), const_cast<float*>(lse), d_o, dqkv, B, S, H, Dm, st);
+    const int rc = mvf_tattn_mfma(1, qkv, mask, mask_len, const_cast<float*>(o), const_cast<float*>(lse), d_o, dqkv, B, S, H, Dm, st);
     if (rc != MVF_ERR_UNSUPPORTED) return rc;
   }
   TAttnArgs a{};
-  a.qkv = qkv; a.mask = mask; a.o = const_cast<float*>(o); a.lse = const_cast<float*>(lse); a.d_o = d_o; a.dqkv = dqkv;
-  a.B = B; a.S = S; a.H = H; a.Dm = Dm;
+  a.qkv = qkv; a.mask = mask; a.Sm = mask != nullptr ? mask_len : S; a.o = const_cast<float*>(o); a.lse = const_cast<float*>(lse);
+  a.d_o = d_o; a.dqkv = dqkv; a.B = B; a.S = S; a.H = H; a.Dm = Dm;
   const int dk = Dm / H;
   a.scale = 1.0f / sqrtf((float)dk);
   a.scale_log2 = a.scale * LOG2E;

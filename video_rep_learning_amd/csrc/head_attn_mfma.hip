@@ -33,7 +33,8 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 struct TAttnArgs {
   const float* qkv;    // [B*S, 3*Dm]
-  const float* mask;   // [B, S] (1 keep / 0 masked) or null
+  const float* mask;   // [B, Sm] (1 keep / 0 masked) or null; key s reads column s % Sm (Sm = S: a plain key mask;
+  int Sm;              // Sm = T for the joint entity x frame sequence, whose keys (j, t) share the frame mask [B, T])
   float* o;            // [B*S, Dm]
   float* lse;          // [B, H, S]  log2-domain log-sum-exp of scaled scores
   const float* d_o;    // [B*S, Dm]
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(TAttnArgs a) {
     }
     if (threadIdx.x < BLK) {
       const int key = k0 + threadIdx.x;
-      sm[threadIdx.x] = (key < a.S && (a.mask == nullptr || a.mask[(size_t)b * a.S + key] != 0.f)) ? 1.f : 0.f;
+      sm[threadIdx.x] = (key < a.S && (a.mask == nullptr || a.mask[(size_t)b * a.Sm + key % a.Sm] != 0.f)) ? 1.f : 0.f;
     }
     __syncthreads();
     f32x4_t s[4];
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void tattn_mfma_dq_kernel(TAttnArgs a) {
     }
     if (threadIdx.x < BLK) {
       const int key = k0 + threadIdx.x;
-      sm[threadIdx.x] = (key < a.S && (a.mask == nullptr || a.mask[(size_t)b * a.S + key] != 0.f)) ? 1.f : 0.f;
+      sm[threadIdx.x] = (key < a.S && (a.mask == nullptr || a.mask[(size_t)b * a.Sm + key % a.Sm] != 0.f)) ? 1.f : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void tattn_mfma_dkv_kernel(TAttnArgs a) {
   f32x4_t kfr[DK / 16], vfr[DK / 16];
   load_rowfrag<DK>(base + a.Dm, ld, kc, g, kfr);
   load_rowfrag<DK>(base + 2 * a.Dm, ld, kc, g, vfr);
-  const bool keep = key < a.S && (a.mask == nullptr || a.mask[(size_t)b * a.S + kc] != 0.f);
+  const bool keep = key < a.S && (a.mask == nullptr || a.mask[(size_t)b * a.Sm + kc % a.Sm] != 0.f);
   f32x4_t dk[DK / 16], dv[DK / 16];
 #pragma unroll
   for (int dt = 0; dt < DK / 16; ++dt) { dk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
@@ -354,10 +355,10 @@ int run(int which, const TAttnArgs& a, hipStream_t st) {
 }  // namespace
 
 // which: 0 forward, 1 backward; returns MVF_ERR_UNSUPPORTED when dk is not 16, 32 or 64 (scalar kernels take over)
-int mvf_tattn_mfma(int which, const float* qkv, const float* mask, float* o, float* lse, const float* d_o, float* dqkv,
-                   int B, int S, int H, int Dm, hipStream_t st) {
+int mvf_tattn_mfma(int which, const float* qkv, const float* mask, int mask_len, float* o, float* lse, const float* d_o,
+                   float* dqkv, int B, int S, int H, int Dm, hipStream_t st) {
   TAttnArgs a{};
-  a.qkv = qkv; a.mask = mask; a.o = o; a.lse = lse; a.d_o = d_o; a.dqkv = dqkv; a.B = B; a.S = S; a.H = H; a.Dm = Dm;
+  a.qkv = qkv; a.mask = mask; a.Sm = mask != nullptr ? mask_len : S; a.o = o; a.lse = lse; a.d_o = d_o; a.dqkv = dqkv; a.B = B; a.S = S; a.H = H; a.Dm = Dm;
   const int dk = Dm / H;
   a.scale = 1.0f / sqrtf((float)dk);
   a.scale_log2 = a.scale * LOG2E;

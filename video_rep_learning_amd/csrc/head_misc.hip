@@ -37,9 +37,10 @@ constexpr int LN_ROWS_PER_WAVE = 4;
 template <int NCMAX>   // columns per lane: D <= 64 * NCMAX (8: the head's widths, 24: ViT widths up to 1536)
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ g, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, float* __restrict__ dx,
-                                                     float* __restrict__ dg, float* __restrict__ db, int rows, int D,
-                                                     int accumulate) {
+                                                     const float* __restrict__ rstd, const float* dres, float* dx,
+                                                     float* __restrict__ dg, float* __restrict__ db, int rows, int D) {
+  // dres (may be NULL, may alias dx): a gradient that reaches x on a second path -- the residual connection around the
+  // LayerNorm -- added here instead of by an elementwise kernel of the autograd engine
   extern __shared__ float red[];  // [4 waves][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nc = (D + 63) / 64;   // columns per lane (<= NCMAX)
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       const int c = lane + q * 64;
       if (q < nc && c < D) {
         const float v = rs * (dy[o + c] * g[c] - c1 - (x[o + c] - mu) * rs * c2);
-        dx[o + c] = accumulate ? dx[o + c] + v : v;
+        dx[o + c] = dres != nullptr ? dres[o + c] + v : v;
       }
     }
   }
@@ -356,9 +357,8 @@ extern "C" int mvf_ln_fwd(const float* x, const float* g, const float* b, float*
 }
 
 // dg/db: accumulate_params != 0 adds into them (flat gradient buffer), else they are overwritten (zeroed here first)
-extern "C" int mvf_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, float* dx,
-                          float* dg, float* db, int rows, int D, int accumulate_dx, int accumulate_params,
-                          hipStream_t st) {
+static int ln_bwd_launch(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, const float* dres,
+                         float* dx, float* dg, float* db, int rows, int D, int accumulate_params, hipStream_t st) {
   MVF_CHECK_ARG(dy && x && g && mean && rstd && dx && rows > 0 && D > 0 && D <= 1536 && ((dg == nullptr) == (db == nullptr)));
   if (dg && !accumulate_params) {
     if (hipMemsetAsync(dg, 0, (size_t)D * 4, st) != hipSuccess || hipMemsetAsync(db, 0, (size_t)D * 4, st) != hipSuccess)
@@ -366,13 +366,26 @@ extern "C" int mvf_ln_bwd(const float* dy, const float* x, const float* g, const
   }
   const dim3 grid(ceil_div(rows, 4 * LN_ROWS_PER_WAVE));
   if (D <= 512)
-    hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, dim3(256), (size_t)8 * D * 4, st, dy, x, g, mean, rstd, dx, dg, db, rows, D,
-                       accumulate_dx);
+    hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, dim3(256), (size_t)8 * D * 4, st, dy, x, g, mean, rstd, dres, dx, dg, db, rows, D);
   else   // ViT widths (trainable backbone blocks): 768 .. 1536
-    hipLaunchKernelGGL(ln_bwd_kernel<24>, grid, dim3(256), (size_t)8 * D * 4, st, dy, x, g, mean, rstd, dx, dg, db, rows, D,
-                       accumulate_dx);
+    hipLaunchKernelGGL(ln_bwd_kernel<24>, grid, dim3(256), (size_t)8 * D * 4, st, dy, x, g, mean, rstd, dres, dx, dg, db, rows, D);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
+}
+
+extern "C" int mvf_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, float* dx,
+                          float* dg, float* db, int rows, int D, int accumulate_dx, int accumulate_params,
+                          hipStream_t st) {
+  return ln_bwd_launch(dy, x, g, mean, rstd, accumulate_dx ? dx : nullptr, dx, dg, db, rows, D, accumulate_params, st);
+}
+
+// dx = dres + d LN / dx (dy): the pre-LN residual connection x + sub(LN(x)) (models/utils.py:147-159) hands x two gradients --
+// the residual path's (dres) and the LayerNorm's -- summed here in the LayerNorm backward's own pass over the rows
+extern "C" int mvf_ln_bwd_res(const float* dy, const float* x, const float* g, const float* mean, const float* rstd,
+                              const float* dres, float* dx, float* dg, float* db, int rows, int D, int accumulate_params,
+                              hipStream_t st) {
+  MVF_CHECK_ARG(dres != nullptr);
+  return ln_bwd_launch(dy, x, g, mean, rstd, dres, dx, dg, db, rows, D, accumulate_params, st);
 }
 
 extern "C" size_t mvf_bn_workspace_floats(int rows, int C) { return (size_t)bn_splits(rows) * 2 * C; }

@@ -44,5 +44,5 @@ int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H
 
 // ---- head ----
 // MFMA temporal attention (head_attn_mfma.hip); which: 0 forward, 1 backward; MVF_ERR_UNSUPPORTED unless dk in {16,32,64}
-int mvf_tattn_mfma(int which, const float* qkv, const float* mask, float* o, float* lse, const float* d_o, float* dqkv,
+int mvf_tattn_mfma(int which, const float* qkv, const float* mask, int mask_len, float* o, float* lse, const float* d_o, float* dqkv,
                    int B, int S, int H, int Dm, hipStream_t st);

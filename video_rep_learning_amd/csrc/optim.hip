@@ -43,15 +43,19 @@ __global__ void sqnorm_final_kernel(const float* __restrict__ part, int nparts, 
   }
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
                                                    float wd, float bc1, float bc2_sqrt, float clip,
-                                                   const float* __restrict__ norm, float gscale, int step_no) {
+                                                   const float* __restrict__ norm, float gscale, int step_no, int zero_grad) {
   float coef = gscale;
   if (norm != nullptr) {
     // a NaN / Inf gradient norm poisons parameters and both moments for good (fminf(1, clip / NaN) = 1): skip the step,
     // and leave it out of the bias-correction step count like a GradScaler-skipped step
-    if (!isfinite(norm[0])) return;
+    if (!isfinite(norm[0])) {
+      if (zero_grad)      // the rejected gradient is dropped all the same
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) g[i] = 0.f;
+      return;
+    }
     const float skipped = norm[1];
     if (skipped > 0.f) {
       const double eff = fmax((double)step_no - (double)skipped, 1.0);
@@ -69,6 +73,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     m[i] = mi;
     v[i] = vi;
     p[i] = pi - step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    if (zero_grad) g[i] = 0.f;      // the next step's zero_grad() in the pass that has the gradient in registers anyway
   }
 }
 
@@ -89,16 +94,17 @@ extern "C" int mvf_grad_norm(const float* g, size_t n, const float* extra_sq, fl
 // One Adam step on flat buffers. step >= 1 (1-based, like torch). clip <= 0 disables clipping.
 // gscale multiplies every gradient first (e.g. 1/world_size when the all-reduce summed instead of averaged).
 // norm (optional) = the two floats of mvf_grad_norm: a non-finite norm[0] turns the call into a no-op, and norm[1] steps
-// skipped that way so far are taken off `step` in the bias correction.
-extern "C" int mvf_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+// skipped that way so far are taken off `step` in the bias correction.  zero_grad != 0: g is zeroed as it is consumed (also
+// when the step is skipped) -- optimizer.zero_grad() of the next iteration (train.py:113) without its own pass over g.
+extern "C" int mvf_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                              float eps, float weight_decay, int step, float clip, const float* norm, float gscale,
-                             hipStream_t st) {
+                             int zero_grad, hipStream_t st) {
   MVF_CHECK_ARG(p && g && m && v && n > 0 && step >= 1);
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   const int nblk = (int)std::min<size_t>(2048, (n + 255) / 256);
   hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1,
-                     bc2s, clip, norm, gscale, step);
+                     bc2s, clip, norm, gscale, step, zero_grad);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

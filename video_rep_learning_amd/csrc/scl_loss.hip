@@ -255,7 +255,29 @@ void set_lds(K kern, size_t bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// the loader's bookkeeping tensors -> the three per-row float vectors the loss kernels read (rows ordered (video, view, frame))
+__global__ void scl_rows_kernel(const long long* __restrict__ steps, const long long* __restrict__ lens,
+                                const float* __restrict__ masks, float* __restrict__ out, int M, int T) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= M) return;
+  out[r] = (float)steps[r];
+  out[M + r] = (float)lens[r / T];
+  out[2 * M + r] = masks != nullptr ? masks[r] : 1.0f;
+}
+
 }  // namespace
+
+// rows[0 | 1 | 2][M]: chosen_steps [clips, T] int64, seq_lens [clips] int64 (one per clip, repeated over its T frames) and
+// video_masks [clips, T] fp32 (NULL: all ones) as floats per embedding row -- what SCL.compute_sequence_loss derives with
+// reshape / expand / .float() before the loss proper (algos/scl.py:52-64)
+extern "C" int mvf_scl_rows(const long long* steps, const long long* seq_lens, const float* masks, float* rows, int clips,
+                            int T, hipStream_t st) {
+  MVF_CHECK_ARG(steps && seq_lens && rows && clips > 0 && T > 0);
+  const int M = clips * T;
+  hipLaunchKernelGGL(scl_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, st, steps, seq_lens, masks, rows, M, T);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
 
 // negative_flags: bit0 = 'single' in NEGATIVE_TYPE, bit1 = 'noself' in NEGATIVE_TYPE
 extern "C" int mvf_scl_fwd(const float* emb, const float* step, const float* len, const float* mask, float* S, float* R,

@@ -76,6 +76,8 @@ class LSTPCrossAtt(nn.Module):
         """wq = q W_K: [nq, C] for static-only queries, else [Bc, nq, T, C] (one query set per frame); project=False: the
         queries themselves ([nq, d] / [Bc, nq, T, d])."""
         wk = self.linear_K2d.weight
+        if not self.dyn and project and torch.is_grad_enabled():
+            return ops.static_query(self.Q_s, self.Q_s_b, wk)                 # (Q_s + Q_s_b) W_K, gradients written in place
         qs = (self.Q_s + self.Q_s_b)[0] if self.stat else None            # [nst, d]
         if not self.dyn:
             return ops.matmul(qs, wk) if project else qs
@@ -262,9 +264,9 @@ class MultiEntityTransformerEmbModel(nn.Module):
             x = ops.concat_onehot(x, ntok, T)
         x = x.view(Bc, ntok * T, -1)
         if self.cfg.MODEL.EMBEDDER_MODEL.NUM_LAYERS > 0:
-            vm = None
-            if video_masks is not None:
-                vm = video_masks.reshape(Bc, 1, T).expand(Bc, ntok, T).reshape(Bc, 1, ntok * T)
+            # mvformer.py:171-172 tiles the frame mask to the joint sequence ([Bc, 1, ntok * T]); the attention kernels read the
+            # [Bc, T] mask periodically instead (key (j, t) -> column t), so nothing is copied
+            vm = video_masks.reshape(Bc, 1, T) if video_masks is not None else None
             x = self.video_encoder(x, src_mask=vm, drop_state=self.drop_state)
         x = x.view(Bc, ntok, T, -1)
         if self.smart_final == 'lin':

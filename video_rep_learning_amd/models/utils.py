@@ -80,12 +80,13 @@ class MultiheadedAttention(nn.Module):
         return w, b, None
 
     def forward(self, x, mask=None, resid=None, drop=None):
-        """Self-attention only (Q = K = V = x), x [B, S, D], mask [B, 1, S]; `resid`/`drop`: the residual connection
+        """Self-attention only (Q = K = V = x), x [B, S, D], mask [B, 1, S] (or [B, 1, S / k], read periodically: the frame mask
+        of a joint entity x frame sequence); `resid`/`drop`: the residual connection
         and its dropout, fused into the output projection's epilogue."""
         B, S, _ = x.shape
         w, b, fused = self._qkv_operands()
         qkv = ops.linear(x.reshape(B * S, -1), w, b, fused=fused)
-        o = ops.temporal_attention(qkv, None if mask is None else mask.reshape(B, S), B, S, self.H)
+        o = ops.temporal_attention(qkv, None if mask is None else mask.reshape(B, -1), B, S, self.H)     # [B, S] or periodic
         return ops.linear(o, self.linear_d2Q.weight, self.linear_d2Q.bias,
                           resid=None if resid is None else resid.reshape(B * S, -1), drop=drop).view(B, S, -1)
 
@@ -123,10 +124,11 @@ class EncoderLayer(nn.Module):
 
     def forward(self, x, src_mask=None, drop_state=None):
         r0, r1 = self.res_layer0, self.res_layer1
-        # x + drop(sub(LN(x))) twice; the add and the dropout live in the epilogue of each sub-layer's last GEMM
-        h = ops.layer_norm(x, r0.norm.weight, r0.norm.bias, r0.norm.eps)
+        # x + drop(sub(LN(x))) twice; the add and the dropout live in the epilogue of each sub-layer's last GEMM, and the two
+        # gradients of x (residual path + LayerNorm) are summed inside the LayerNorm backward kernel (ops.layer_norm_fork)
+        x, h = ops.layer_norm_fork(x, r0.norm.weight, r0.norm.bias, r0.norm.eps)
         x = self.self_att(h, src_mask, resid=x, drop=ops.drop_args(r0.dout_p, self.training, drop_state, x.numel()))
-        h = ops.layer_norm(x, r1.norm.weight, r1.norm.bias, r1.norm.eps)
+        x, h = ops.layer_norm_fork(x, r1.norm.weight, r1.norm.bias, r1.norm.eps)
         return self.feed_forward(h, resid=x, drop=ops.drop_args(r1.dout_p, self.training, drop_state, x.numel()))
 
 

@@ -48,7 +48,12 @@ def grad_slot(p):
     """The parameter's slice of the flat gradient buffer (utils.distributed.FlatBuffers sets `p._mvf_grad`), or None.
     Backward kernels ACCUMULATE parameter gradients straight into it (the buffer is zeroed once per step) and the op
     returns None for that input: no per-parameter `grad.add_()` kernels, no temporaries."""
-    return getattr(p, '_mvf_grad', None) if p is not None else None
+    if p is None:
+        return None
+    flat = getattr(p, '_mvf_flat', None)
+    if flat is not None:
+        flat.dirty = True         # a backward kernel is going to write here: the next zero_grad() has work to do
+    return getattr(p, '_mvf_grad', None)
 
 
 def grad_ready(*params):
@@ -96,8 +101,9 @@ class _Linear(torch.autograd.Function):
         relu, (p, seed, off), has_resid, has_bias, slots, owners = ctx.cfg
         M, K = x.shape
         N = w.shape[0]
-        if dy.stride(1) != 1 or dy.stride(0) != N:
-            dy = dy.contiguous()      # the pre-op masks are indexed like the dense forward output
+        if dy.stride(1) != 1 or (dy.stride(0) != N and (relu or p > 0.0)) or dy.stride(0) < N:
+            dy = dy.contiguous()      # the pre-op masks are indexed like the dense forward output; plain layers take dy with
+        ldy = dy.stride(0) if M > 1 else N      # its row stride (a column slice of a wider gradient: concat_onehot's backward)
         dev = dy.device
         dx = torch.empty(M, K, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         if slots is not None:
@@ -111,12 +117,12 @@ class _Linear(torch.autograd.Function):
         if relu:                      # g = dy * [y > 0]
             gm = torch.empty_like(dy)
             call('mvf_relu_bwd', dy.data_ptr(), y.data_ptr(), gm.data_ptr(), M * N, stream())
-            dy = gm
+            dy, ldy = gm, N
         elif p > 0.0:                 # g = dy * keep / (1 - p): the forward's counter-based mask
             gm = torch.empty_like(dy)
             call('mvf_dropout_add', dy.data_ptr(), None, gm.data_ptr(), M * N, p, seed, off, stream())
-            dy = gm
-        call('mvf_hlinear_bwd', dy.data_ptr(), N, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), ptr(dx), K,
+            dy, ldy = gm, N
+        call('mvf_hlinear_bwd', dy.data_ptr(), ldy, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), ptr(dx), K,
              gw.data_ptr(), gw.stride(0) if gw.dim() == 2 else K, ptr(gb) if has_bias else None, M, N, K, acc, stream())
         if slots is not None:
             grad_ready(*owners)
@@ -219,6 +225,8 @@ def linear(x, w, b=None, relu=False, table=None, tab_div=1, tab_mod=1, resid=Non
     slots, owners = None, ()
     if fused is not None:
         slots, owners = (fused[0], fused[1]), tuple(fused[2])
+        for o in owners:
+            grad_slot(o)                    # marks the flat gradient buffer as written
     elif x2.requires_grad and grad_slot(w) is not None and (b is None or grad_slot(b) is not None):
         slots, owners = (grad_slot(w), grad_slot(b)), (w, b)
     if slots is not None and not x2.requires_grad:
@@ -262,6 +270,55 @@ def matmul(a, b):
     return _MatmulNN.apply(a, b)
 
 
+class _StaticQuery(torch.autograd.Function):
+    """wq = (Q_s + Q_s_b) W_K  [nq, C]: the query side of the pooling rewrite for static queries (LSTPCrossAtt,
+    mvformer.py:383 `Q = self.Q_s + self.Q_s_b`, folded through linear_K2d as csrc/lstp_pool.hip describes).  By linearity
+    (Q_s + 1 b^T) W = Q_s W + 1 (b^T W): two small GEMM launches forward, the second one's result entering the first as its
+    bias; the backward accumulates all three parameter gradients straight into their flat-gradient slots -- no broadcast add,
+    no select / sum / AccumulateGrad kernels of the autograd engine."""
+
+    @staticmethod
+    def forward(ctx, qs, qb, wk, slots):
+        ctx.owners = (qs, qb, wk)
+        nq, d = qs.shape[-2], qs.shape[-1]
+        C = wk.shape[1]
+        dev = wk.device
+        bw = torch.empty(1, C, device=dev, dtype=torch.float32)
+        _hgemm(qb.data_ptr(), d, 1, wk.data_ptr(), wk.stride(0), 1, bw.data_ptr(), C, 1, C, d)               # b^T W_K
+        out = torch.empty(nq, C, device=dev, dtype=torch.float32)
+        _hgemm(qs.data_ptr(), d, 1, wk.data_ptr(), wk.stride(0), 1, out.data_ptr(), C, nq, C, d, bias=bw)    # Q_s W_K + 1 (b^T W_K)
+        ctx.save_for_backward(qs, qb, wk)
+        ctx.slots = slots
+        return out
+
+    @staticmethod
+    def backward(ctx, dv):
+        qs, qb, wk = ctx.saved_tensors
+        gqs, gqb, gwk = ctx.slots
+        nq, d = qs.shape[-2], qs.shape[-1]
+        C = wk.shape[1]
+        dv, dvp, ldv = _mat(dv)
+        cs = torch.empty(C, device=dv.device, dtype=torch.float32)
+        call('mvf_colsum', dvp, ldv, nq, C, ptr(cs), 0, stream())                                           # 1^T dv
+        _hgemm(dvp, ldv, 1, wk.data_ptr(), 1, wk.stride(0), gqs.data_ptr(), d, nq, d, C, accumulate=True)    # dQ_s += dv W_K^T
+        _hgemm(cs.data_ptr(), C, 1, wk.data_ptr(), 1, wk.stride(0), gqb.data_ptr(), d, 1, d, C, accumulate=True)   # dQ_s_b += (1^T dv) W_K^T
+        _hgemm(qs.data_ptr(), 1, d, dvp, ldv, 1, gwk.data_ptr(), gwk.stride(0), d, C, nq, accumulate=True)   # dW_K += Q_s^T dv
+        _hgemm(qb.data_ptr(), 1, d, cs.data_ptr(), C, 1, gwk.data_ptr(), gwk.stride(0), d, C, 1, accumulate=True)  # dW_K += b (1^T dv)
+        grad_ready(*ctx.owners)
+        return None, None, None, None
+
+
+def static_query(q_s, q_s_b, w_k):
+    """(Q_s + Q_s_b)[0] @ W_K for Q_s [1, nq, d], Q_s_b [d], W_K [d, C]: fused form with in-slot gradients when all three
+    parameters live in the flat buffers (training under FusedAdam), the plain composition otherwise."""
+    slots = (grad_slot(q_s), grad_slot(q_s_b), grad_slot(w_k))
+    if any(s is None for s in slots) or not (q_s.requires_grad and q_s_b.requires_grad and w_k.requires_grad) or \
+            not (q_s.is_contiguous() and q_s_b.is_contiguous() and w_k.stride(1) == 1):
+        return matmul((q_s + q_s_b)[0], w_k)
+    out = _StaticQuery.apply(q_s, q_s_b, w_k, slots)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # LayerNorm
 # ------------------------------------------------------------------------------------------------
@@ -301,6 +358,59 @@ class _LayerNorm(torch.autograd.Function):
 def layer_norm(x, g, b, eps=1e-5):
     shp = x.shape
     return _LayerNorm.apply(x.reshape(-1, shp[-1]), g, b, eps).view(shp)
+
+
+class _LayerNormFork(torch.autograd.Function):
+    """(x, LN(x)) for a pre-LN residual connection out = x + sub(LN(x)) (ResidualConnection, models/utils.py:147-159).
+    x has two consumers there -- the LayerNorm and the residual add -- and the autograd engine would sum their two gradients
+    with an elementwise ATen kernel.  Here x leaves through this node as well, so BOTH gradients come back to it and the
+    LayerNorm backward kernel adds the residual one in its own pass (mvf_ln_bwd_res)."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        x = x.contiguous()
+        R, D = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(R, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        call('mvf_ln_fwd', ptr(x), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), R, D, eps, stream())
+        ctx.save_for_backward(x, g, mean, rstd)
+        use = x.requires_grad and grad_slot(g) is not None and grad_slot(b) is not None
+        ctx.slots = (grad_slot(g), grad_slot(b)) if use else (None, None)
+        ctx.owners = (g, b) if use else ()
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        x, g, mean, rstd = ctx.saved_tensors
+        if dy is None:                     # the LayerNorm branch was not used
+            return dres, None, None, None
+        dy = dy.contiguous()
+        R, D = x.shape
+        dx = torch.empty_like(x)
+        gw, gb = ctx.slots
+        acc = 1 if gw is not None else 0
+        dg = gw if gw is not None else torch.empty_like(g)
+        db = gb if gb is not None else torch.empty_like(g)
+        if dres is not None:
+            dres = dres.contiguous()
+            call('mvf_ln_bwd_res', ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), dg.data_ptr(), db.data_ptr(),
+                 R, D, acc, stream())
+        else:
+            call('mvf_ln_bwd', ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dx), dg.data_ptr(), db.data_ptr(), R, D, 0, acc,
+                 stream())
+        if gw is not None:
+            grad_ready(*ctx.owners)
+            return dx, None, None, None
+        return dx, dg, db, None
+
+
+def layer_norm_fork(x, g, b, eps=1e-5):
+    """-> (x, LN(x)): use the returned x for the residual add (see _LayerNormFork)."""
+    shp = x.shape
+    xr, y = _LayerNormFork.apply(x.reshape(-1, shp[-1]), g, b, eps)
+    return xr.view(shp), y.view(shp)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -497,20 +607,27 @@ class _TemporalAttention(torch.autograd.Function):
         Dm = qkv.shape[1] // 3
         o = torch.empty(B * S, Dm, device=qkv.device, dtype=torch.float32)
         lse = torch.empty(B, H, S, device=qkv.device, dtype=torch.float32)
+        mlen = S
         if mask is not None:
-            mask = mask.reshape(B, S).contiguous().float()
-        call('mvf_tattn_fwd', ptr(qkv), ptr(mask), ptr(o), ptr(lse), B, S, H, Dm, stream())
+            # [B, S] key mask, or [B, S / k]: the frame mask of a joint (entity, frame) sequence, read periodically by the kernels
+            # (no tiled copy).  No kernel runs here when the mask already is contiguous fp32.
+            mask = mask.reshape(B, -1)
+            mlen = mask.shape[1]
+            assert S % mlen == 0, (S, mlen)
+            if mask.dtype != torch.float32 or not mask.is_contiguous():
+                mask = mask.contiguous().float()
+        call('mvf_tattn_fwd', ptr(qkv), ptr(mask), mlen, ptr(o), ptr(lse), B, S, H, Dm, stream())
         ctx.save_for_backward(qkv, mask, o, lse)
-        ctx.dims = (B, S, H, Dm)
+        ctx.dims = (B, S, H, Dm, mlen)
         return o
 
     @staticmethod
     def backward(ctx, d_o):
         qkv, mask, o, lse = ctx.saved_tensors
-        B, S, H, Dm = ctx.dims
+        B, S, H, Dm, mlen = ctx.dims
         d_o = d_o.contiguous()
         dqkv = torch.empty_like(qkv)
-        call('mvf_tattn_bwd', ptr(qkv), ptr(mask), ptr(o), ptr(lse), ptr(d_o), ptr(dqkv), B, S, H, Dm, stream())
+        call('mvf_tattn_bwd', ptr(qkv), ptr(mask), mlen, ptr(o), ptr(lse), ptr(d_o), ptr(dqkv), B, S, H, Dm, stream())
         return dqkv, None, None, None, None
 
 
@@ -719,7 +836,8 @@ def vit_block_tc(x, heads, eps1, eps2, params):
 
 
 def temporal_attention(qkv, mask, B, S, H):
-    """qkv [B*S, 3*Dm] (q | k | v column blocks, heads contiguous inside) -> [B*S, Dm]; mask [B,S] (0 = masked key)."""
+    """qkv [B*S, 3*Dm] (q | k | v column blocks, heads contiguous inside) -> [B*S, Dm]; mask [B, S] (0 = masked key) or
+    [B, S / k] (then key s is masked by column s % (S / k): the frame mask of k entities' joint sequence)."""
     return _TemporalAttention.apply(qkv, mask, B, S, H)
 
 
@@ -861,6 +979,18 @@ def dropout_add(x, resid, p, training, state):
 # ------------------------------------------------------------------------------------------------
 # LSTP pooling core over the backbone taps
 # ------------------------------------------------------------------------------------------------
+_CONST = {}
+
+
+def _ones(shape, device):
+    """A cached all-ones fp32 tensor (read-only by convention: returned to callers as a non-differentiable output)."""
+    key = (tuple(shape), str(device))
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.ones(tuple(shape), device=device, dtype=torch.float32)
+    return t
+
+
 def _tap_table(taps):
     arr = (ctypes.c_void_p * len(taps))(*[ptr(t) for t in taps])
     return arr
@@ -897,16 +1027,19 @@ class _LSTPPool(torch.autograd.Function):
         ctx.cfg = (F, N, T, nq, inv_sqrt_d, per_frame, dt, D, C)
         if holder is not None:
             holder['attn'] = Pm if disjoint else P      # [F, nq, N], like LSTPCrossAtt.attn_matrix
+        ctx.set_materialize_grads(False)       # no zero-filled gradient for the (constant) row sums
         if disjoint:
             rs = rowsum.view(F // T, T, nq).transpose(1, 2).contiguous()     # (b, j, t) like pooled
         else:
-            rs = torch.ones(F // T, nq, T, device=dev, dtype=torch.float32)
+            rs = _ones((F // T, nq, T), dev).view(F // T, nq, T)
             ctx.mark_non_differentiable(rs)
         return pooled, rs
 
     @staticmethod
     def backward(ctx, dpooled, drs):
         P, Pm, vec = ctx.saved_tensors
+        if dpooled is None:
+            dpooled = torch.zeros(ctx.cfg[0] // ctx.cfg[2], ctx.cfg[3], ctx.cfg[2], ctx.cfg[8], device=P.device, dtype=torch.float32)
         F, N, T, nq, inv_sqrt_d, per_frame, dt, D, C = ctx.cfg
         taps = ctx.taps
         tab = _tap_table(taps)
@@ -961,16 +1094,19 @@ class _LSTPPoolScores(torch.autograd.Function):
         ctx.cfg = (F, N, T, nq, inv_sqrt_d, dt, D, C)
         if holder is not None:
             holder['attn'] = Pm if disjoint else P
+        ctx.set_materialize_grads(False)
         if disjoint:
             rs = rowsum.view(F // T, T, nq).transpose(1, 2).contiguous()
         else:
-            rs = torch.ones(F // T, nq, T, device=dev, dtype=torch.float32)
+            rs = _ones((F // T, nq, T), dev).view(F // T, nq, T)
             ctx.mark_non_differentiable(rs)
         return pooled, rs
 
     @staticmethod
     def backward(ctx, dpooled, drs):
         P, Pm = ctx.saved_tensors
+        if dpooled is None:
+            dpooled = torch.zeros(ctx.cfg[0] // ctx.cfg[2], ctx.cfg[3], ctx.cfg[2], ctx.cfg[7], device=P.device, dtype=torch.float32)
         F, N, T, nq, inv_sqrt_d, dt, D, C = ctx.cfg
         taps = ctx.taps
         tab = _tap_table(taps)
@@ -1076,12 +1212,36 @@ class _SCLLoss(torch.autograd.Function):
         emb, step, length, mask, st = ctx.saved_tensors
         T, flags, tau, var, row0, rows, grad_scale = ctx.cfg
         M, E = emb.shape
-        g = (gout * grad_scale).reshape(1).contiguous().float()
+        g = gout.reshape(1) if (grad_scale == 1.0 and gout.dtype == torch.float32) else (gout * grad_scale).reshape(1).contiguous().float()
         dE = torch.zeros(M, E, device=emb.device, dtype=torch.float32) if rows != M else \
             torch.empty(M, E, device=emb.device, dtype=torch.float32)
         call('mvf_scl_bwd', ptr(emb), ptr(step), ptr(length), ptr(mask), st[0].data_ptr(), st[1].data_ptr(),
              st[2].data_ptr(), ptr(g), dE[row0:row0 + rows].data_ptr(), M, E, T, row0, rows, flags, tau, var, stream())
         return dE, None, None, None, None, None, None, None, None, None, None
+
+
+def scl_rows(steps, seq_lens, masks):
+    """chosen_steps [B, V, T] int64, seq_lens [B, V] int64, video_masks [B*V, 1, T] / [B, V, T] fp32 (or None) on the device ->
+    the three per-row float vectors of the loss as ONE [3, M] tensor (mvf_scl_rows), or None when the inputs are not of that
+    form (the caller then converts them with tensor ops)."""
+    if not (steps.is_cuda and seq_lens.is_cuda and steps.dtype == torch.int64 and seq_lens.dtype == torch.int64 and
+            steps.is_contiguous() and seq_lens.is_contiguous()):
+        return None
+    if masks is not None and not (masks.is_cuda and masks.dtype == torch.float32 and masks.is_contiguous() and
+                                  masks.numel() == steps.numel()):
+        return None
+    T = steps.shape[-1]
+    clips = steps.numel() // T
+    if seq_lens.numel() != clips:
+        return None
+    out = torch.empty(3, clips * T, device=steps.device, dtype=torch.float32)
+    call('mvf_scl_rows', ptr(steps), ptr(seq_lens), ptr(masks), ptr(out), clips, T, stream())
+    return out
+
+
+def backward(loss):
+    """loss.backward() with a cached seed gradient (autograd otherwise fills a fresh ones_like(loss) every step)."""
+    loss.backward(_ones((), loss.device).view(()) if loss.dim() == 0 and loss.dtype == torch.float32 else None)
 
 
 def scl_loss(emb, steps, seq_lens, masks, num_frames, negative_type, temperature, label_variance, row0=0, rows=None,
@@ -1378,6 +1538,7 @@ def grad_norm(flat_grad, scratch, out, extra_sq=None):
     return out
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, clip=0.0, norm=None, gscale=1.0):
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, clip=0.0, norm=None, gscale=1.0, zero_grad=False):
+    """zero_grad: the kernel zeroes g as it consumes it (utils.optimizer.FusedAdam: the next zero_grad() becomes free)."""
     call('mvf_adam_step', ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step, clip,
-         ptr(norm), gscale, stream())
+         ptr(norm), gscale, int(zero_grad), stream())

@@ -26,6 +26,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import ops
 from .utils import distributed as du
 from .utils import logging
 from .utils.parser import parse_args, load_config, setup_train_dir
@@ -97,7 +98,7 @@ def train(cfg, train_loader, model, optimizer, scheduler, algo, cur_epoch, summa
         optimizer.zero_grad()
         loss_dict = algo.compute_loss(model, videos, seq_lens, chosen_steps, video_masks)
         loss = loss_dict['loss']
-        loss.backward()
+        ops.backward(loss)                 # loss.backward() with a cached seed gradient
         clip = cfg.OPTIMIZER.GRAD_CLIP
         if hasattr(optimizer, 'reducer'):
             optimizer.step(max_norm=clip if clip > 0 else 0.0)
@@ -189,6 +190,7 @@ def plumbing_run(cfg, args, model, optimizer, scheduler, algo, train_loader, dat
     optimizer.zero_grad()
     if hasattr(optimizer, 'reducer'):
         optimizer.flat.flat_g.fill_(float(du.get_rank() + 1))
+        optimizer.flat.dirty = True                  # written behind the optimizer's back: the next zero_grad() must fill
         active = optimizer.reducer.active
         gscale = optimizer.reducer.finish()          # launches every bucket's all-reduce (SUM) and waits
         want = float(sum(range(1, du.get_world_size() + 1))) if active else float(du.get_rank() + 1)

@@ -153,6 +153,12 @@ class FlatBuffers:
             p.data = v
             p.grad = self.flat_g[o:o + p.numel()].view_as(p)
             p._mvf_grad = p.grad
+            p._mvf_flat = self                      # ops.grad_slot marks the buffer dirty through this
+            if p.requires_grad:
+                p.register_hook(self._mark_dirty)   # gradients that arrive through autograd's AccumulateGrad
+        # True while the gradient buffer may hold anything but zeros.  The fused Adam kernel zeroes the gradients it consumes,
+        # so the zero_grad() that follows a step has nothing to do unless something wrote gradients in between.
+        self.dirty = True
         self.fused = []
         for g in groups:
             o0, tot = off[id(g[0])], sum(q.numel() for q in g)
@@ -160,8 +166,13 @@ class FlatBuffers:
             shape = (sum(q.shape[0] for q in g),) + tuple(g[0].shape[1:])
             self.fused.append((self.flat_p[o0:o0 + tot].view(shape), self.flat_g[o0:o0 + tot].view(shape)) if contiguous else None)
 
-    def zero_grad(self):
-        self.flat_g.zero_()
+    def _mark_dirty(self, _grad):
+        self.dirty = True
+
+    def zero_grad(self, force=False):
+        if self.dirty or force:
+            self.flat_g.zero_()
+            self.dirty = False
         for p, o in zip(self.params, self.offsets):   # re-attach in case something set .grad to None
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
                 p.grad = self.flat_g[o:o + p.numel()].view_as(p)

@@ -90,8 +90,12 @@ class FusedAdam(torch.optim.Optimizer):
                 assert e0 - s0 == sum(m for _, m in offs), 'a fuse group straddles two optimizer param groups'
                 self._ranges.append((s0, e0))
             k += n
+        # the Adam kernel doubles as zero_grad(): it must see every element of the gradient buffer
+        assert sum(e - s_ for s_, e in self._ranges) == self.flat.numel, 'optimizer param groups do not cover the flat buffers'
 
     def zero_grad(self, set_to_none=False):
+        """Free right after a step (the Adam kernel zeroed the buffer while reading it); a real fill only when gradients
+        were written since (FlatBuffers.dirty: a backward without a step, manual writes through ops.grad_slot)."""
         self.flat.zero_grad()
 
     @torch.no_grad()
@@ -107,7 +111,8 @@ class FusedAdam(torch.optim.Optimizer):
                 continue
             ops.adam_step(self.flat.flat_p[s:e], self.flat.flat_g[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e],
                           float(g['lr']), g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], self.step_count,
-                          clip=float(max_norm or 0.0), norm=norm, gscale=gscale)
+                          clip=float(max_norm or 0.0), norm=norm, gscale=gscale, zero_grad=True)
+        self.flat.dirty = False           # every element of the gradient buffer lies in one of the ranges (asserted above)
         for m in self.packed_owners:
             m.invalidate_packed()
         return norm[:1] if (max_norm and max_norm > 0) else None

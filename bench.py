@@ -41,7 +41,7 @@ GEMM_NAMES = {(0, 2304, 768): 'qkv [M,768]x[2304,768]^T', (2, 768, 768): 'proj+r
               (1, 3072, 768): 'fc1+gelu [M,768]x[3072,768]^T', (2, 768, 3072): 'fc2+resid [M,3072]x[768,3072]^T',
               (3, 768, 768): 'patch-embed+pos [M,768]x[768,768]^T'}
 # bf16 mode against the bf16-emulating oracle, (loss, embeddings): about 3x what the driver-style runs measure
-BF16_GATES = (2e-3, 2e-3)
+BF16_GATES = (2e-3, 3e-3)      # measured over driver-style runs: loss 1.5e-4 .. 7.5e-4, embeddings 5.7e-4 .. 1.1e-3
 PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
 
 

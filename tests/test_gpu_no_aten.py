@@ -121,11 +121,10 @@ def test_static_query_gradients_land_in_the_flat_buffers():
     get_algo(cfg2).compute_loss(ref, videos, seq_lens, steps, masks)['loss'].backward()
     torch.cuda.synchronize()
     ca, cb = model.embed.pooling.cross_att, ref.embed.pooling.cross_att
-    for name in ('Q_s', 'Q_s_b'):
-        a_, b_ = getattr(ca, name).grad, getattr(cb, name).grad
-        assert torch.allclose(a_, b_, rtol=2e-4, atol=1e-6 * b_.abs().max().item() + 1e-9), (name, (a_ - b_).abs().max(), b_.abs().max())
-    a_, b_ = ca.linear_K2d.weight.grad, cb.linear_K2d.weight.grad
-    assert torch.allclose(a_, b_, rtol=2e-4, atol=1e-5 * b_.abs().max().item() + 1e-9), ((a_ - b_).abs().max(), b_.abs().max())
+    for name, a_, b_ in (('Q_s', ca.Q_s.grad, cb.Q_s.grad), ('Q_s_b', ca.Q_s_b.grad, cb.Q_s_b.grad),
+                         ('linear_K2d.weight', ca.linear_K2d.weight.grad, cb.linear_K2d.weight.grad)):
+        e = ((a_ - b_).abs().max() / b_.abs().max()).item()        # fp32 summation order only
+        assert e <= 5e-5, (name, e)
 
 
 def test_zero_grad_after_step_is_free_and_still_correct_in_odd_orders():

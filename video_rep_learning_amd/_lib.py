@@ -80,6 +80,8 @@ SIGNATURES = {
     'mvf_tattn_select': 'i',
     'mvf_tattn_fwd': 'ppippiiiip',
     'mvf_tattn_bwd': 'ppippppiiiip',
+    'mvf_lstp_fused_fwd': 'piiiiiiipifppp',
+    'mvf_lstp_fused_bwd': 'piiiiiiipppfpp',
     'mvf_lstp_scores': 'piiiiiiipipp',
     'mvf_lstp_wsum': 'piiiiiiippp',
     'mvf_lstp_softmax_fwd': 'ppppiiifip',
@@ -147,6 +149,17 @@ def call(name, *args):
     rc = getattr(load(), name)(*args)
     if rc != 0:
         raise MvfError('%s failed with code %d%s' % (name, rc, ' (bad argument)' if rc == 10001 else ''))
+
+
+def try_call(name, *args):
+    """call() for entry points that may decline a shape: returns False on MVF_ERR_UNSUPPORTED (10002), True on success,
+    raises on any other code."""
+    rc = getattr(load(), name)(*args)
+    if rc == 10002:
+        return False
+    if rc != 0:
+        raise MvfError('%s failed with code %d%s' % (name, rc, ' (bad argument)' if rc == 10001 else ''))
+    return True
 
 
 def stream():

@@ -251,6 +251,292 @@ __global__ __launch_bounds__(256) void lstp_reduce_frames_kernel(const float* __
   if (rl == 0 && c < C) out[(size_t)j * C + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// One-pass forms (static or per-frame queries, no SMART_DISJOINT, frozen taps): the tap tensors are read ONCE forward and
+// ONCE backward instead of twice each.
+//   forward : online softmax over a frame's tokens.  A wave owns tokens n = w, w + 8, ..; per token it has the whole
+//             channel vector x_n in registers, takes the NQ scores s_j = x_n . vec_j (vec in LDS), updates its running
+//             (m_j, l_j) and accumulates p_j x_n; the eight waves' partial results are merged in a fixed order through LDS.
+//             Writes pooled [Bc, nq, T, C] and P [F, nq, N] (the normalised weights: LSTPCrossAtt.attn_matrix and the
+//             backward's input).
+//   backward: with g_jn = dpooled_j . x_n and gbar_j = sum_n P_jn g_jn, the raw-score gradient is dS_jn = c P_jn (g_jn - gbar_j)
+//             (c = 1 / sqrt(d)), so the query-vector gradient  sum_n dS_jn x_n = c (sum_n P_jn g_jn x_n - gbar_j pooled_j)
+//             needs ONE pass that accumulates A_j = sum_n P_jn g_jn x_n and gbar_j (pooled_j is the forward's output).
+// Lane layout: 16-byte (bf16: 8 values, f32: 4 values x 2) channel chunks; chunk q of tap t belongs to lane q % 64, slot q / 64.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int FQ = 3;            // queries the one-pass kernels hold accumulators for
+constexpr int FSLOT = 2;         // chunk slots per lane and tap: D <= 8 * 64 * FSLOT = 1024
+constexpr int FTAPS = 3;
+constexpr int FWAVES = 8;
+
+struct FusedArgs {
+  const void* taps[FTAPS];
+  int n_taps, D, N, T, nq, per_frame;
+  const float* vec;       // fwd: query-side vectors; bwd: dpooled [Bc, nq, T, C]
+  float* P;               // [F, nq, N]  (fwd: out, bwd: in)
+  float* pooled;          // [Bc, nq, T, C]  (fwd: out, bwd: in)
+  float* G;               // bwd: [Bc, nq, T, C]
+  float inv_sqrt_d;
+};
+
+template <typename T>
+__device__ __forceinline__ void load_chunk(const T* p, float (&v)[8]);
+template <>
+__device__ __forceinline__ void load_chunk<bf16_t>(const bf16_t* p, float (&v)[8]) { Ld16<bf16_t>::ld(p, v); }
+template <>
+__device__ __forceinline__ void load_chunk<float>(const float* p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// dot products of one token's channel vector with the NQ vectors in LDS: d[j] = sum over this lane's chunks; the caller reduces
+template <typename T>
+__device__ __forceinline__ void token_dots(const FusedArgs& a, const float* svec, int C, size_t row, int lane, float (&d)[FQ]) {
+#pragma unroll
+  for (int j = 0; j < FQ; ++j) d[j] = 0.f;
+  const int nch = a.D >> 3;
+#pragma unroll
+  for (int tp = 0; tp < FTAPS; ++tp) {
+    if (tp >= a.n_taps) break;
+    const T* x = reinterpret_cast<const T*>(a.taps[tp]) + row * a.D;
+#pragma unroll
+    for (int sl = 0; sl < FSLOT; ++sl) {
+      const int q = lane + 64 * sl;
+      if (q < nch) {
+        float v[8];
+        load_chunk<T>(x + q * 8, v);
+#pragma unroll
+        for (int j = 0; j < FQ; ++j) {
+          if (j < a.nq) {
+            const float4 w0 = *reinterpret_cast<const float4*>(svec + j * C + tp * a.D + q * 8);
+            const float4 w1 = *reinterpret_cast<const float4*>(svec + j * C + tp * a.D + q * 8 + 4);
+            d[j] += v[0] * w0.x + v[1] * w0.y + v[2] * w0.z + v[3] * w0.w + v[4] * w1.x + v[5] * w1.y + v[6] * w1.z + v[7] * w1.w;
+          }
+        }
+      }
+    }
+  }
+}
+
+// acc[j][tp][sl][:] = acc * scale[j] + wgt[j] * x  for this lane's chunks of one token
+template <typename T>
+__device__ __forceinline__ void token_axpy(const FusedArgs& a, size_t row, int lane, const float (&wgt)[FQ],
+                                           float (&acc)[FQ][FTAPS][FSLOT][8]) {
+  const int nch = a.D >> 3;
+#pragma unroll
+  for (int tp = 0; tp < FTAPS; ++tp) {
+    if (tp >= a.n_taps) break;
+    const T* x = reinterpret_cast<const T*>(a.taps[tp]) + row * a.D;
+#pragma unroll
+    for (int sl = 0; sl < FSLOT; ++sl) {
+      const int q = lane + 64 * sl;
+      if (q < nch) {
+        float v[8];
+        load_chunk<T>(x + q * 8, v);        // second read of the token: served by L1 / L2 (4.6 KB read microseconds earlier)
+#pragma unroll
+        for (int j = 0; j < FQ; ++j)
+          if (j < a.nq)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[j][tp][sl][e] = fmaf(wgt[j], v[e], acc[j][tp][sl][e]);
+      }
+    }
+  }
+}
+
+// the eight waves' accumulators -> red[nq][C] in LDS, each scaled by its wave's factor, added in wave order (deterministic)
+__device__ __forceinline__ void merge_waves(const FusedArgs& a, float* red, int C, int lane, int wave, const float (&f)[FQ],
+                                            const float (&acc)[FQ][FTAPS][FSLOT][8]) {
+  const int nch = a.D >> 3;
+  for (int w = 0; w < FWAVES; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int j = 0; j < FQ; ++j) {
+        if (j >= a.nq) break;
+#pragma unroll
+        for (int tp = 0; tp < FTAPS; ++tp) {
+          if (tp >= a.n_taps) break;
+#pragma unroll
+          for (int sl = 0; sl < FSLOT; ++sl) {
+            const int q = lane + 64 * sl;
+            if (q < nch) {
+              float* r = red + j * C + tp * a.D + q * 8;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) r[e] = (w == 0 ? 0.f : r[e]) + f[j] * acc[j][tp][sl][e];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void lstp_fused_fwd_kernel(FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int C = a.n_taps * a.D;
+  float* svec = sm;                         // [nq][C]; reused as the merge buffer
+  float* ssc = sm + a.nq * C;               // [nq][N] raw scores (scaled by 1 / sqrt(d))
+  float* sst = ssc + a.nq * a.N;            // [FWAVES][nq][2] (m, l) per wave
+  const int f = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = f / a.T, t = f % a.T;
+  for (int i = threadIdx.x; i < a.nq * C; i += 512) {
+    const int j = i / C, c = i % C;
+    svec[i] = a.per_frame ? a.vec[(((size_t)b * a.nq + j) * a.T + t) * C + c] : a.vec[(size_t)j * C + c];
+  }
+  __syncthreads();
+  float acc[FQ][FTAPS][FSLOT][8];
+#pragma unroll
+  for (int j = 0; j < FQ; ++j)
+#pragma unroll
+    for (int tp = 0; tp < FTAPS; ++tp)
+#pragma unroll
+      for (int sl = 0; sl < FSLOT; ++sl)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][tp][sl][e] = 0.f;
+  float m[FQ], l[FQ];
+#pragma unroll
+  for (int j = 0; j < FQ; ++j) { m[j] = -1e30f; l[j] = 0.f; }
+  for (int n = wave; n < a.N; n += FWAVES) {
+    const size_t row = (size_t)f * a.N + n;
+    float d[FQ], wgt[FQ];
+    token_dots<T>(a, svec, C, row, lane, d);
+    bool grow = false;
+    float al[FQ];
+#pragma unroll
+    for (int j = 0; j < FQ; ++j) {
+      al[j] = 1.f;
+      wgt[j] = 0.f;
+      if (j < a.nq) {
+        const float s = wave_sum(d[j]) * a.inv_sqrt_d;
+        if (lane == 0) ssc[j * a.N + n] = s;
+        const float mn = fmaxf(m[j], s);
+        al[j] = __expf(m[j] - mn);
+        grow = grow || (mn > m[j]);
+        wgt[j] = __expf(s - mn);
+        l[j] = l[j] * al[j] + wgt[j];
+        m[j] = mn;
+      }
+    }
+    if (grow) {       // wave-uniform: a running maximum moved (rare after the first few tokens)
+#pragma unroll
+      for (int j = 0; j < FQ; ++j)
+#pragma unroll
+        for (int tp = 0; tp < FTAPS; ++tp)
+#pragma unroll
+          for (int sl = 0; sl < FSLOT; ++sl)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[j][tp][sl][e] *= al[j];
+    }
+    token_axpy<T>(a, row, lane, wgt, acc);
+  }
+  if (lane == 0)
+    for (int j = 0; j < a.nq; ++j) { sst[(wave * a.nq + j) * 2] = m[j]; sst[(wave * a.nq + j) * 2 + 1] = l[j]; }
+  __syncthreads();        // every wave is done with svec; (m, l) of all waves and all raw scores are visible
+  float fac[FQ], M[FQ], L[FQ];
+#pragma unroll
+  for (int j = 0; j < FQ; ++j) {
+    fac[j] = 0.f; M[j] = 0.f; L[j] = 1.f;
+    if (j < a.nq) {
+      float mm = -1e30f;
+      for (int w = 0; w < FWAVES; ++w) mm = fmaxf(mm, sst[(w * a.nq + j) * 2]);
+      float ll = 0.f;
+      for (int w = 0; w < FWAVES; ++w) ll += sst[(w * a.nq + j) * 2 + 1] * __expf(sst[(w * a.nq + j) * 2] - mm);
+      M[j] = mm; L[j] = ll;
+      fac[j] = __expf(m[j] - mm) / ll;
+    }
+  }
+  merge_waves(a, svec, C, lane, wave, fac, acc);
+  for (int i = threadIdx.x; i < a.nq * C; i += 512) {
+    const int j = i / C, c = i % C;
+    a.pooled[(((size_t)b * a.nq + j) * a.T + t) * C + c] = svec[i];
+  }
+  for (int i = threadIdx.x; i < a.nq * a.N; i += 512) {
+    const int j = i / a.N;
+    float Mj = M[0], Lj = L[0];
+#pragma unroll
+    for (int q = 1; q < FQ; ++q) if (j == q) { Mj = M[q]; Lj = L[q]; }
+    a.P[(size_t)f * a.nq * a.N + i] = __expf(ssc[i] - Mj) / Lj;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void lstp_fused_bwd_kernel(FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int C = a.n_taps * a.D;
+  float* sdp = sm;                          // [nq][C] dpooled of this frame; reused as the merge buffer
+  float* sP = sm + a.nq * C;                // [nq][N]
+  float* sgb = sP + a.nq * a.N;             // [FWAVES][nq] partial gbar
+  const int f = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = f / a.T, t = f % a.T;
+  for (int i = threadIdx.x; i < a.nq * C; i += 512) {
+    const int j = i / C, c = i % C;
+    sdp[i] = a.vec[(((size_t)b * a.nq + j) * a.T + t) * C + c];
+  }
+  for (int i = threadIdx.x; i < a.nq * a.N; i += 512) sP[i] = a.P[(size_t)f * a.nq * a.N + i];
+  __syncthreads();
+  float acc[FQ][FTAPS][FSLOT][8];
+#pragma unroll
+  for (int j = 0; j < FQ; ++j)
+#pragma unroll
+    for (int tp = 0; tp < FTAPS; ++tp)
+#pragma unroll
+      for (int sl = 0; sl < FSLOT; ++sl)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][tp][sl][e] = 0.f;
+  float gb[FQ] = {0.f, 0.f, 0.f};
+  for (int n = wave; n < a.N; n += FWAVES) {
+    const size_t row = (size_t)f * a.N + n;
+    float d[FQ], wgt[FQ];
+    token_dots<T>(a, sdp, C, row, lane, d);
+#pragma unroll
+    for (int j = 0; j < FQ; ++j) {
+      wgt[j] = 0.f;
+      if (j < a.nq) {
+        wgt[j] = sP[j * a.N + n] * wave_sum(d[j]);      // P_jn g_jn
+        gb[j] += wgt[j];
+      }
+    }
+    token_axpy<T>(a, row, lane, wgt, acc);
+  }
+  if (lane == 0)
+    for (int j = 0; j < a.nq; ++j) sgb[wave * a.nq + j] = gb[j];
+  __syncthreads();
+  const float one[FQ] = {1.f, 1.f, 1.f};
+  merge_waves(a, sdp, C, lane, wave, one, acc);
+  for (int i = threadIdx.x; i < a.nq * C; i += 512) {
+    const int j = i / C, c = i % C;
+    float g = 0.f;
+    for (int w = 0; w < FWAVES; ++w) g += sgb[w * a.nq + j];
+    const size_t o = (((size_t)b * a.nq + j) * a.T + t) * C + c;
+    a.G[o] = a.inv_sqrt_d * (sdp[i] - g * a.pooled[o]);
+  }
+}
+
+int fused_fill(FusedArgs& a, const void* const* taps, int n_taps, int dtype, int D, int F, int N, int T, int nq) {
+  MVF_CHECK_ARG(taps && F > 0 && N > 0 && T > 0 && F % T == 0 && (dtype == MVF_F32 || dtype == MVF_BF16));
+  if (!(n_taps >= 1 && n_taps <= FTAPS && nq >= 1 && nq <= FQ && D % 8 == 0 && D <= 8 * 64 * FSLOT)) return MVF_ERR_UNSUPPORTED;
+  const size_t lds = ((size_t)nq * n_taps * D + (size_t)nq * N + FWAVES * nq * 2) * sizeof(float);
+  if (lds > 96 * 1024) return MVF_ERR_UNSUPPORTED;
+  for (int i = 0; i < n_taps; ++i) {
+    MVF_CHECK_ARG(taps[i] && ((uintptr_t)taps[i] & 15) == 0);
+    a.taps[i] = taps[i];
+  }
+  a.n_taps = n_taps; a.D = D; a.N = N; a.T = T; a.nq = nq;
+  return MVF_OK;
+}
+
+template <typename K>
+int fused_launch(K kernel, const FusedArgs& a, int F, hipStream_t st) {
+  const size_t lds = ((size_t)a.nq * a.n_taps * a.D + (size_t)a.nq * a.N + FWAVES * a.nq * 2) * sizeof(float);
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return MVF_ERR_ARG;
+  hipLaunchKernelGGL(kernel, dim3(F), dim3(512), lds, st, a);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
 int fill_args(PoolArgs& a, const void* const* taps, int n_taps, int dtype, int D, int F, int N, int T, int nq) {
   MVF_CHECK_ARG(taps && n_taps > 0 && n_taps <= MAXTAPS && nq > 0 && nq <= MAXQ && F > 0 && N > 0 && T > 0 && F % T == 0);
   MVF_CHECK_ARG(dtype == MVF_F32 || dtype == MVF_BF16);
@@ -320,6 +606,7 @@ extern "C" int mvf_lstp_softmax_bwd(const float* P, const float* Pm, const float
   return MVF_OK;
 }
 
+// (entry points of the one-pass kernels: end of file)
 // ---- late fusion: AdaptiveMaxPool2d(1) / AdaptiveAvgPool2d(1) over a frame's tokens (models/transformer.py:258-262) ----
 // out[f, tap*D + c] = max_n | mean_n x[tap][f*N+n, c]; grid (F, n_taps), a thread owns channels, tokens in sequence
 template <typename T>
@@ -409,4 +696,32 @@ extern "C" int mvf_lstp_reduce_frames(const float* G, float* out, int Bc, int nq
   hipLaunchKernelGGL(lstp_reduce_frames_kernel, dim3(ceil_div(C, 64), nq), dim3(256), 0, st, G, out, Bc, nq, T, C);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
+}
+
+// One-pass pooling forward (see the kernel comment): pooled [Bc, nq, T, C] and P [F, nq, N] in one read of the taps.
+// MVF_ERR_UNSUPPORTED when the shape is outside the kernel's register budget (nq > 3, more than 3 taps, D > 1024): the caller
+// then runs the three-launch form (scores / softmax / weighted sum).
+extern "C" int mvf_lstp_fused_fwd(const void* const* taps, int n_taps, int dtype, int D, int F, int N, int T, int nq,
+                                  const float* vec, int per_frame, float inv_sqrt_d, float* P, float* pooled,
+                                  hipStream_t st) {
+  FusedArgs a{};
+  const int rc = fused_fill(a, taps, n_taps, dtype, D, F, N, T, nq);
+  if (rc != MVF_OK) return rc;
+  MVF_CHECK_ARG(vec && P && pooled);
+  a.vec = vec; a.per_frame = per_frame; a.inv_sqrt_d = inv_sqrt_d; a.P = P; a.pooled = pooled;
+  return dtype == MVF_BF16 ? fused_launch(lstp_fused_fwd_kernel<bf16_t>, a, F, st) : fused_launch(lstp_fused_fwd_kernel<float>, a, F, st);
+}
+
+// One-pass backward: G [Bc, nq, T, C] = d loss / d vec of every frame (rows (clip, query, frame)) from dpooled, the forward's
+// P and pooled; shared queries: sum G over frames with mvf_lstp_reduce_frames.
+extern "C" int mvf_lstp_fused_bwd(const void* const* taps, int n_taps, int dtype, int D, int F, int N, int T, int nq,
+                                  const float* dpooled, const float* P, const float* pooled, float inv_sqrt_d, float* G,
+                                  hipStream_t st) {
+  FusedArgs a{};
+  const int rc = fused_fill(a, taps, n_taps, dtype, D, F, N, T, nq);
+  if (rc != MVF_OK) return rc;
+  MVF_CHECK_ARG(dpooled && P && pooled && G);
+  a.vec = dpooled; a.per_frame = 1; a.inv_sqrt_d = inv_sqrt_d; a.P = const_cast<float*>(P); a.pooled = const_cast<float*>(pooled);
+  a.G = G;
+  return dtype == MVF_BF16 ? fused_launch(lstp_fused_bwd_kernel<bf16_t>, a, F, st) : fused_launch(lstp_fused_bwd_kernel<float>, a, F, st);
 }

@@ -991,6 +991,10 @@ def _ones(shape, device):
     return t
 
 
+# MVF_LSTP_ONE_PASS=0: the three-launch pooling (scores / softmax / weighted sum) everywhere (A/B measurements, tests)
+LSTP_ONE_PASS = os.environ.get('MVF_LSTP_ONE_PASS', '1') != '0'
+
+
 def _tap_table(taps):
     arr = (ctypes.c_void_p * len(taps))(*[ptr(t) for t in taps])
     return arr
@@ -1013,17 +1017,24 @@ class _LSTPPool(torch.autograd.Function):
         vec = vec.contiguous()
         per_frame = vec.dim() == 4
         tab = _tap_table(taps)
-        scores = torch.empty(F * N, nq, device=dev, dtype=torch.float32)
-        call('mvf_lstp_scores', tab, len(taps), dt, D, F, N, T, nq, ptr(vec), int(per_frame), ptr(scores), stream())
         P = torch.empty(F, nq, N, device=dev, dtype=torch.float32)
-        Pm = torch.empty_like(P) if disjoint else None
-        rowsum = torch.empty(F, nq, device=dev, dtype=torch.float32) if disjoint else None
-        call('mvf_lstp_softmax_fwd', ptr(scores), ptr(P), ptr(Pm), ptr(rowsum), F, N, nq, inv_sqrt_d, int(disjoint),
-             stream())
         pooled = torch.empty(F // T, nq, T, C, device=dev, dtype=torch.float32)
-        call('mvf_lstp_wsum', tab, len(taps), dt, D, F, N, T, nq, ptr(Pm if disjoint else P), ptr(pooled), stream())
+        Pm = rowsum = None
+        # one pass over the taps (online softmax) where the kernel's register budget allows it: nq <= 3, <= 3 taps, D <= 1024
+        fused = LSTP_ONE_PASS and not disjoint and not ctx.want_dx and \
+            _lib.try_call('mvf_lstp_fused_fwd', tab, len(taps), dt, D, F, N, T, nq, ptr(vec), int(per_frame), inv_sqrt_d, ptr(P),
+                          ptr(pooled), stream())
+        if not fused:
+            scores = torch.empty(F * N, nq, device=dev, dtype=torch.float32)
+            call('mvf_lstp_scores', tab, len(taps), dt, D, F, N, T, nq, ptr(vec), int(per_frame), ptr(scores), stream())
+            Pm = torch.empty_like(P) if disjoint else None
+            rowsum = torch.empty(F, nq, device=dev, dtype=torch.float32) if disjoint else None
+            call('mvf_lstp_softmax_fwd', ptr(scores), ptr(P), ptr(Pm), ptr(rowsum), F, N, nq, inv_sqrt_d, int(disjoint),
+                 stream())
+            call('mvf_lstp_wsum', tab, len(taps), dt, D, F, N, T, nq, ptr(Pm if disjoint else P), ptr(pooled), stream())
         ctx.taps = taps
-        ctx.save_for_backward(P, Pm, vec if ctx.want_dx else None)
+        ctx.fused = fused
+        ctx.save_for_backward(P, Pm, vec if ctx.want_dx else None, pooled if fused else None)
         ctx.cfg = (F, N, T, nq, inv_sqrt_d, per_frame, dt, D, C)
         if holder is not None:
             holder['attn'] = Pm if disjoint else P      # [F, nq, N], like LSTPCrossAtt.attn_matrix
@@ -1037,7 +1048,7 @@ class _LSTPPool(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dpooled, drs):
-        P, Pm, vec = ctx.saved_tensors
+        P, Pm, vec, pooled = ctx.saved_tensors
         if dpooled is None:
             dpooled = torch.zeros(ctx.cfg[0] // ctx.cfg[2], ctx.cfg[3], ctx.cfg[2], ctx.cfg[8], device=P.device, dtype=torch.float32)
         F, N, T, nq, inv_sqrt_d, per_frame, dt, D, C = ctx.cfg
@@ -1045,6 +1056,16 @@ class _LSTPPool(torch.autograd.Function):
         tab = _tap_table(taps)
         dev = dpooled.device
         dpooled = dpooled.contiguous()
+        if ctx.fused:         # one pass: G = d loss / d vec per frame from dpooled, P and the forward's pooled
+            G = torch.empty(F // T, nq, T, C, device=dev, dtype=torch.float32)
+            call('mvf_lstp_fused_bwd', tab, len(taps), dt, D, F, N, T, nq, ptr(dpooled), ptr(P), ptr(pooled), inv_sqrt_d, ptr(G),
+                 stream())
+            if per_frame:
+                dvec = G
+            else:
+                dvec = torch.empty(nq, C, device=dev, dtype=torch.float32)
+                call('mvf_lstp_reduce_frames', ptr(G), ptr(dvec), F // T, nq, T, C, stream())
+            return (dvec, None, None, None, None, None, None, None, None)
         dP = torch.empty(F * N, nq, device=dev, dtype=torch.float32)
         call('mvf_lstp_scores', tab, len(taps), dt, D, F, N, T, nq, ptr(dpooled), 1, ptr(dP), stream())
         drow = None

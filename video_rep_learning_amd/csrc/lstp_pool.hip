@@ -262,16 +262,16 @@ __global__ __launch_bounds__(256) void lstp_reduce_frames_kernel(const float* __
 //   backward: with g_jn = dpooled_j . x_n and gbar_j = sum_n P_jn g_jn, the raw-score gradient is dS_jn = c P_jn (g_jn - gbar_j)
 //             (c = 1 / sqrt(d)), so the query-vector gradient  sum_n dS_jn x_n = c (sum_n P_jn g_jn x_n - gbar_j pooled_j)
 //             needs ONE pass that accumulates A_j = sum_n P_jn g_jn x_n and gbar_j (pooled_j is the forward's output).
-// Lane layout: 16-byte (bf16: 8 values, f32: 4 values x 2) channel chunks; chunk q of tap t belongs to lane q % 64, slot q / 64.
+// Everything a lane touches is fixed at compile time -- NQ queries, NT taps, NG groups of 4 channels per lane and tap
+// (D = 256 NG: 768 -> 3, 1024 -> 4; group q of a tap belongs to lane q % 64) -- so the token loop is straight-line code:
+// with run-time trip counts hipcc branched around every load and drained the queue (vmcnt(0)) before each use, which undid the
+// register double buffering (the next token's loads in flight while this one is reduced: 2 tokens x 8 waves = 74 KB per CU).
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int FQ = 3;            // queries the one-pass kernels hold accumulators for
-constexpr int FSLOT = 2;         // chunk slots per lane and tap: D <= 8 * 64 * FSLOT = 1024
-constexpr int FTAPS = 3;
 constexpr int FWAVES = 8;
 
 struct FusedArgs {
-  const void* taps[FTAPS];
-  int n_taps, D, N, T, nq, per_frame;
+  const void* taps[MAXTAPS];
+  int D, N, T, per_frame;
   const float* vec;       // fwd: query-side vectors; bwd: dpooled [Bc, nq, T, C]
   float* P;               // [F, nq, N]  (fwd: out, bwd: in)
   float* pooled;          // [Bc, nq, T, C]  (fwd: out, bwd: in)
@@ -279,261 +279,289 @@ struct FusedArgs {
   float inv_sqrt_d;
 };
 
-template <typename T>
-__device__ __forceinline__ void load_chunk(const T* p, float (&v)[8]);
-template <>
-__device__ __forceinline__ void load_chunk<bf16_t>(const bf16_t* p, float (&v)[8]) { Ld16<bf16_t>::ld(p, v); }
-template <>
-__device__ __forceinline__ void load_chunk<float>(const float* p, float (&v)[8]) {
-  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
+template <typename T> struct Raw4;
+template <> struct Raw4<bf16_t> {
+  uint2 r;
+  __device__ __forceinline__ void ld(const bf16_t* p) { r = *reinterpret_cast<const uint2*>(p); }
+  __device__ __forceinline__ void get(float (&v)[4]) const {
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+  }
+};
+template <> struct Raw4<float> {
+  float4 r;
+  __device__ __forceinline__ void ld(const float* p) { r = *reinterpret_cast<const float4*>(p); }
+  __device__ __forceinline__ void get(float (&v)[4]) const { v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
+};
 
-// dot products of one token's channel vector with the NQ vectors in LDS: d[j] = sum over this lane's chunks; the caller reduces
-template <typename T>
-__device__ __forceinline__ void token_dots(const FusedArgs& a, const float* svec, int C, size_t row, int lane, float (&d)[FQ]) {
+template <typename T, int NT, int NG>
+struct Token {
+  Raw4<T> g[NT][NG];
+  __device__ __forceinline__ void load(const FusedArgs& a, size_t row, int lane) {
 #pragma unroll
-  for (int j = 0; j < FQ; ++j) d[j] = 0.f;
-  const int nch = a.D >> 3;
+    for (int tp = 0; tp < NT; ++tp) {
+      const T* x = reinterpret_cast<const T*>(a.taps[tp]) + row * a.D + lane * 4;
 #pragma unroll
-  for (int tp = 0; tp < FTAPS; ++tp) {
-    if (tp >= a.n_taps) break;
-    const T* x = reinterpret_cast<const T*>(a.taps[tp]) + row * a.D;
+      for (int q = 0; q < NG; ++q) g[tp][q].ld(x + q * 256);
+    }
+  }
+};
+
+// d[j] = this lane's share of x . vec_j (vec in LDS, [NQ][C]); the caller reduces over the wave
+template <typename T, int NQ, int NT, int NG>
+__device__ __forceinline__ void token_dots(const Token<T, NT, NG>& tk, const float* svec, int D, int lane, float (&d)[NQ]) {
+  const int C = NT * D;
 #pragma unroll
-    for (int sl = 0; sl < FSLOT; ++sl) {
-      const int q = lane + 64 * sl;
-      if (q < nch) {
-        float v[8];
-        load_chunk<T>(x + q * 8, v);
+  for (int j = 0; j < NQ; ++j) d[j] = 0.f;
 #pragma unroll
-        for (int j = 0; j < FQ; ++j) {
-          if (j < a.nq) {
-            const float4 w0 = *reinterpret_cast<const float4*>(svec + j * C + tp * a.D + q * 8);
-            const float4 w1 = *reinterpret_cast<const float4*>(svec + j * C + tp * a.D + q * 8 + 4);
-            d[j] += v[0] * w0.x + v[1] * w0.y + v[2] * w0.z + v[3] * w0.w + v[4] * w1.x + v[5] * w1.y + v[6] * w1.z + v[7] * w1.w;
-          }
-        }
+  for (int tp = 0; tp < NT; ++tp) {
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+      float v[4];
+      tk.g[tp][q].get(v);
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const float4 w = *reinterpret_cast<const float4*>(svec + j * C + tp * D + q * 256 + lane * 4);
+        d[j] = fmaf(v[0], w.x, fmaf(v[1], w.y, fmaf(v[2], w.z, fmaf(v[3], w.w, d[j]))));
       }
     }
+    // one tap's LDS reads at a time: hoisted together, the NQ x NT x NG float4 operands alone are 100+ registers
+    if constexpr (NQ * NT * NG > 12) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// acc[j][tp][sl][:] = acc * scale[j] + wgt[j] * x  for this lane's chunks of one token
-template <typename T>
-__device__ __forceinline__ void token_axpy(const FusedArgs& a, size_t row, int lane, const float (&wgt)[FQ],
-                                           float (&acc)[FQ][FTAPS][FSLOT][8]) {
-  const int nch = a.D >> 3;
+// acc = acc * scale + wgt * x (SCALE: the online softmax's rescaling of the running sums, 1 almost always -- applied
+// unconditionally: a wave-uniform branch around it made hipcc keep a second copy of the 108 accumulators alive and spill)
+template <typename T, int NQ, int NT, int NG, bool SCALE>
+__device__ __forceinline__ void token_axpy(const Token<T, NT, NG>& tk, const float (&wgt)[NQ], const float (&scale)[NQ],
+                                           float (&acc)[NQ][NT][NG][4]) {
 #pragma unroll
-  for (int tp = 0; tp < FTAPS; ++tp) {
-    if (tp >= a.n_taps) break;
-    const T* x = reinterpret_cast<const T*>(a.taps[tp]) + row * a.D;
+  for (int tp = 0; tp < NT; ++tp) {
 #pragma unroll
-    for (int sl = 0; sl < FSLOT; ++sl) {
-      const int q = lane + 64 * sl;
-      if (q < nch) {
-        float v[8];
-        load_chunk<T>(x + q * 8, v);        // second read of the token: served by L1 / L2 (4.6 KB read microseconds earlier)
+    for (int q = 0; q < NG; ++q) {
+      float v[4];
+      tk.g[tp][q].get(v);
 #pragma unroll
-        for (int j = 0; j < FQ; ++j)
-          if (j < a.nq)
+      for (int j = 0; j < NQ; ++j)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[j][tp][sl][e] = fmaf(wgt[j], v[e], acc[j][tp][sl][e]);
-      }
+        for (int e = 0; e < 4; ++e)
+          acc[j][tp][q][e] = SCALE ? fmaf(acc[j][tp][q][e], scale[j], wgt[j] * v[e]) : fmaf(wgt[j], v[e], acc[j][tp][q][e]);
     }
+    if constexpr (SCALE && NQ * NT * NG > 12) __builtin_amdgcn_sched_barrier(0);     // (keeps the products of one tap together)
   }
 }
 
-// the eight waves' accumulators -> red[nq][C] in LDS, each scaled by its wave's factor, added in wave order (deterministic)
-__device__ __forceinline__ void merge_waves(const FusedArgs& a, float* red, int C, int lane, int wave, const float (&f)[FQ],
-                                            const float (&acc)[FQ][FTAPS][FSLOT][8]) {
-  const int nch = a.D >> 3;
+// the eight waves' accumulators -> red[NQ][C] in LDS, each scaled by its wave's factor, added in wave order (deterministic)
+template <int NQ, int NT, int NG>
+__device__ __forceinline__ void merge_waves(float* red, int D, int lane, int wave, const float (&f)[NQ],
+                                            const float (&acc)[NQ][NT][NG][4]) {
+  const int C = NT * D;
   for (int w = 0; w < FWAVES; ++w) {
     if (wave == w) {
 #pragma unroll
-      for (int j = 0; j < FQ; ++j) {
-        if (j >= a.nq) break;
+      for (int j = 0; j < NQ; ++j)
 #pragma unroll
-        for (int tp = 0; tp < FTAPS; ++tp) {
-          if (tp >= a.n_taps) break;
+        for (int tp = 0; tp < NT; ++tp)
 #pragma unroll
-          for (int sl = 0; sl < FSLOT; ++sl) {
-            const int q = lane + 64 * sl;
-            if (q < nch) {
-              float* r = red + j * C + tp * a.D + q * 8;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) r[e] = (w == 0 ? 0.f : r[e]) + f[j] * acc[j][tp][sl][e];
-            }
+          for (int q = 0; q < NG; ++q) {
+            float4* r = reinterpret_cast<float4*>(red + j * C + tp * D + q * 256 + lane * 4);
+            float4 o = w == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : *r;
+            o.x = fmaf(f[j], acc[j][tp][q][0], o.x); o.y = fmaf(f[j], acc[j][tp][q][1], o.y);
+            o.z = fmaf(f[j], acc[j][tp][q][2], o.z); o.w = fmaf(f[j], acc[j][tp][q][3], o.w);
+            *r = o;
           }
-        }
-      }
     }
     __syncthreads();
   }
 }
 
-template <typename T>
+template <typename T, int NQ, int NT, int NG>
 __global__ __launch_bounds__(512) void lstp_fused_fwd_kernel(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int C = a.n_taps * a.D;
-  float* svec = sm;                         // [nq][C]; reused as the merge buffer
-  float* ssc = sm + a.nq * C;               // [nq][N] raw scores (scaled by 1 / sqrt(d))
-  float* sst = ssc + a.nq * a.N;            // [FWAVES][nq][2] (m, l) per wave
+  const int D = a.D, C = NT * D;
+  float* svec = sm;                         // [NQ][C]; reused as the merge buffer
+  float* ssc = sm + NQ * C;                 // [NQ][N] raw scores (scaled by 1 / sqrt(d))
+  float* sst = ssc + NQ * a.N;              // [FWAVES][NQ][2] (m, l) per wave
   const int f = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = f / a.T, t = f % a.T;
-  for (int i = threadIdx.x; i < a.nq * C; i += 512) {
+  for (int i = threadIdx.x; i < NQ * C; i += 512) {
     const int j = i / C, c = i % C;
-    svec[i] = a.per_frame ? a.vec[(((size_t)b * a.nq + j) * a.T + t) * C + c] : a.vec[(size_t)j * C + c];
+    svec[i] = a.per_frame ? a.vec[(((size_t)b * NQ + j) * a.T + t) * C + c] : a.vec[(size_t)j * C + c];
   }
   __syncthreads();
-  float acc[FQ][FTAPS][FSLOT][8];
+  float acc[NQ][NT][NG][4];
 #pragma unroll
-  for (int j = 0; j < FQ; ++j)
+  for (int j = 0; j < NQ; ++j)
 #pragma unroll
-    for (int tp = 0; tp < FTAPS; ++tp)
+    for (int tp = 0; tp < NT; ++tp)
 #pragma unroll
-      for (int sl = 0; sl < FSLOT; ++sl)
+      for (int q = 0; q < NG; ++q)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[j][tp][sl][e] = 0.f;
-  float m[FQ], l[FQ];
+        for (int e = 0; e < 4; ++e) acc[j][tp][q][e] = 0.f;
+  float m[NQ], l[NQ];
 #pragma unroll
-  for (int j = 0; j < FQ; ++j) { m[j] = -1e30f; l[j] = 0.f; }
+  for (int j = 0; j < NQ; ++j) { m[j] = -1e30f; l[j] = 0.f; }
+  // One token of look-ahead in a second register set.  Measured at configs[1] size (256 frames x 196 tokens x 2304 channels, bf16,
+  // 3 queries): 157 us forward / 108 us backward = 1.5 / 2.1 TB/s against 162 / 184 us for the three-launch chain; the step gains
+  // 0.1 ms.  It is NOT memory-bound: neither a two-token look-ahead nor an L2 prefetch three tokens ahead (LDS-DMA touches of
+  // every 128-byte line) changed the time -- with 2 waves per SIMD the per-token chain (27 LDS operand reads, 3 x 6 bpermute
+  // steps of the wave reductions, dependent FMA chains) is exposed.  Unrolling the buffer rotation made hipcc hoist the unrolled
+  // steps' loads and spill 90 - 170 registers.  The next step would be one QUERY per wave (36 accumulators instead of 108: 12 - 16
+  // waves per CU), tap rows re-read through L1 by the three query waves.
+  Token<T, NT, NG> cur, nxt;
+  const size_t row0 = (size_t)f * a.N;
+  cur.load(a, row0 + min(wave, a.N - 1), lane);
   for (int n = wave; n < a.N; n += FWAVES) {
-    const size_t row = (size_t)f * a.N + n;
-    float d[FQ], wgt[FQ];
-    token_dots<T>(a, svec, C, row, lane, d);
-    bool grow = false;
-    float al[FQ];
+    nxt.load(a, row0 + min(n + FWAVES, a.N - 1), lane);      // the next token (a harmless re-read of the last row at the end)
+    float d[NQ], wgt[NQ], al[NQ];
+    token_dots<T, NQ, NT, NG>(cur, svec, D, lane, d);
 #pragma unroll
-    for (int j = 0; j < FQ; ++j) {
-      al[j] = 1.f;
-      wgt[j] = 0.f;
-      if (j < a.nq) {
-        const float s = wave_sum(d[j]) * a.inv_sqrt_d;
-        if (lane == 0) ssc[j * a.N + n] = s;
-        const float mn = fmaxf(m[j], s);
-        al[j] = __expf(m[j] - mn);
-        grow = grow || (mn > m[j]);
-        wgt[j] = __expf(s - mn);
-        l[j] = l[j] * al[j] + wgt[j];
-        m[j] = mn;
-      }
+    for (int j = 0; j < NQ; ++j) {
+      const float s = wave_sum(d[j]) * a.inv_sqrt_d;
+      if (lane == 0) ssc[j * a.N + n] = s;
+      const float mn = fmaxf(m[j], s);
+      al[j] = __expf(m[j] - mn);
+      wgt[j] = __expf(s - mn);
+      l[j] = l[j] * al[j] + wgt[j];
+      m[j] = mn;
     }
-    if (grow) {       // wave-uniform: a running maximum moved (rare after the first few tokens)
-#pragma unroll
-      for (int j = 0; j < FQ; ++j)
-#pragma unroll
-        for (int tp = 0; tp < FTAPS; ++tp)
-#pragma unroll
-          for (int sl = 0; sl < FSLOT; ++sl)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[j][tp][sl][e] *= al[j];
-    }
-    token_axpy<T>(a, row, lane, wgt, acc);
+    token_axpy<T, NQ, NT, NG, true>(cur, wgt, al, acc);
+    cur = nxt;
   }
   if (lane == 0)
-    for (int j = 0; j < a.nq; ++j) { sst[(wave * a.nq + j) * 2] = m[j]; sst[(wave * a.nq + j) * 2 + 1] = l[j]; }
-  __syncthreads();        // every wave is done with svec; (m, l) of all waves and all raw scores are visible
-  float fac[FQ], M[FQ], L[FQ];
 #pragma unroll
-  for (int j = 0; j < FQ; ++j) {
-    fac[j] = 0.f; M[j] = 0.f; L[j] = 1.f;
-    if (j < a.nq) {
-      float mm = -1e30f;
-      for (int w = 0; w < FWAVES; ++w) mm = fmaxf(mm, sst[(w * a.nq + j) * 2]);
-      float ll = 0.f;
-      for (int w = 0; w < FWAVES; ++w) ll += sst[(w * a.nq + j) * 2 + 1] * __expf(sst[(w * a.nq + j) * 2] - mm);
-      M[j] = mm; L[j] = ll;
-      fac[j] = __expf(m[j] - mm) / ll;
-    }
+    for (int j = 0; j < NQ; ++j) { sst[(wave * NQ + j) * 2] = m[j]; sst[(wave * NQ + j) * 2 + 1] = l[j]; }
+  __syncthreads();        // every wave is done with svec; (m, l) of all waves and all raw scores are visible
+  float fac[NQ], M[NQ], L[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    float mm = -1e30f;
+    for (int w = 0; w < FWAVES; ++w) mm = fmaxf(mm, sst[(w * NQ + j) * 2]);
+    float ll = 0.f;
+    for (int w = 0; w < FWAVES; ++w) ll += sst[(w * NQ + j) * 2 + 1] * __expf(sst[(w * NQ + j) * 2] - mm);
+    M[j] = mm; L[j] = ll;
+    fac[j] = __expf(m[j] - mm) / ll;       // a wave without tokens (N < 8) has l = 0 and contributes nothing
   }
-  merge_waves(a, svec, C, lane, wave, fac, acc);
-  for (int i = threadIdx.x; i < a.nq * C; i += 512) {
+  merge_waves<NQ, NT, NG>(svec, D, lane, wave, fac, acc);
+  for (int i = threadIdx.x; i < NQ * C; i += 512) {
     const int j = i / C, c = i % C;
-    a.pooled[(((size_t)b * a.nq + j) * a.T + t) * C + c] = svec[i];
+    a.pooled[(((size_t)b * NQ + j) * a.T + t) * C + c] = svec[i];
   }
-  for (int i = threadIdx.x; i < a.nq * a.N; i += 512) {
+  for (int i = threadIdx.x; i < NQ * a.N; i += 512) {
     const int j = i / a.N;
     float Mj = M[0], Lj = L[0];
 #pragma unroll
-    for (int q = 1; q < FQ; ++q) if (j == q) { Mj = M[q]; Lj = L[q]; }
-    a.P[(size_t)f * a.nq * a.N + i] = __expf(ssc[i] - Mj) / Lj;
+    for (int q = 1; q < NQ; ++q) if (j == q) { Mj = M[q]; Lj = L[q]; }
+    a.P[(size_t)f * NQ * a.N + i] = __expf(ssc[i] - Mj) / Lj;
   }
 }
 
-template <typename T>
+template <typename T, int NQ, int NT, int NG>
 __global__ __launch_bounds__(512) void lstp_fused_bwd_kernel(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int C = a.n_taps * a.D;
-  float* sdp = sm;                          // [nq][C] dpooled of this frame; reused as the merge buffer
-  float* sP = sm + a.nq * C;                // [nq][N]
-  float* sgb = sP + a.nq * a.N;             // [FWAVES][nq] partial gbar
+  const int D = a.D, C = NT * D;
+  float* sdp = sm;                          // [NQ][C] dpooled of this frame; reused as the merge buffer
+  float* sP = sm + NQ * C;                  // [NQ][N]
+  float* sgb = sP + NQ * a.N;               // [FWAVES][NQ] partial gbar
   const int f = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = f / a.T, t = f % a.T;
-  for (int i = threadIdx.x; i < a.nq * C; i += 512) {
+  for (int i = threadIdx.x; i < NQ * C; i += 512) {
     const int j = i / C, c = i % C;
-    sdp[i] = a.vec[(((size_t)b * a.nq + j) * a.T + t) * C + c];
+    sdp[i] = a.vec[(((size_t)b * NQ + j) * a.T + t) * C + c];
   }
-  for (int i = threadIdx.x; i < a.nq * a.N; i += 512) sP[i] = a.P[(size_t)f * a.nq * a.N + i];
+  for (int i = threadIdx.x; i < NQ * a.N; i += 512) sP[i] = a.P[(size_t)f * NQ * a.N + i];
   __syncthreads();
-  float acc[FQ][FTAPS][FSLOT][8];
+  float acc[NQ][NT][NG][4];
 #pragma unroll
-  for (int j = 0; j < FQ; ++j)
+  for (int j = 0; j < NQ; ++j)
 #pragma unroll
-    for (int tp = 0; tp < FTAPS; ++tp)
+    for (int tp = 0; tp < NT; ++tp)
 #pragma unroll
-      for (int sl = 0; sl < FSLOT; ++sl)
+      for (int q = 0; q < NG; ++q)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[j][tp][sl][e] = 0.f;
-  float gb[FQ] = {0.f, 0.f, 0.f};
+        for (int e = 0; e < 4; ++e) acc[j][tp][q][e] = 0.f;
+  float gb[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) gb[j] = 0.f;
+  Token<T, NT, NG> cur, nxt;
+  const size_t row0 = (size_t)f * a.N;
+  cur.load(a, row0 + min(wave, a.N - 1), lane);
   for (int n = wave; n < a.N; n += FWAVES) {
-    const size_t row = (size_t)f * a.N + n;
-    float d[FQ], wgt[FQ];
-    token_dots<T>(a, sdp, C, row, lane, d);
+    nxt.load(a, row0 + min(n + FWAVES, a.N - 1), lane);
+    float d[NQ], wgt[NQ];
+    token_dots<T, NQ, NT, NG>(cur, sdp, D, lane, d);
 #pragma unroll
-    for (int j = 0; j < FQ; ++j) {
-      wgt[j] = 0.f;
-      if (j < a.nq) {
-        wgt[j] = sP[j * a.N + n] * wave_sum(d[j]);      // P_jn g_jn
-        gb[j] += wgt[j];
-      }
+    for (int j = 0; j < NQ; ++j) {
+      wgt[j] = sP[j * a.N + n] * wave_sum(d[j]);      // P_jn g_jn
+      gb[j] += wgt[j];
     }
-    token_axpy<T>(a, row, lane, wgt, acc);
+    token_axpy<T, NQ, NT, NG, false>(cur, wgt, wgt, acc);
+    cur = nxt;
   }
   if (lane == 0)
-    for (int j = 0; j < a.nq; ++j) sgb[wave * a.nq + j] = gb[j];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) sgb[wave * NQ + j] = gb[j];
   __syncthreads();
-  const float one[FQ] = {1.f, 1.f, 1.f};
-  merge_waves(a, sdp, C, lane, wave, one, acc);
-  for (int i = threadIdx.x; i < a.nq * C; i += 512) {
+  float one[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) one[j] = 1.f;
+  merge_waves<NQ, NT, NG>(sdp, D, lane, wave, one, acc);
+  for (int i = threadIdx.x; i < NQ * C; i += 512) {
     const int j = i / C, c = i % C;
     float g = 0.f;
-    for (int w = 0; w < FWAVES; ++w) g += sgb[w * a.nq + j];
-    const size_t o = (((size_t)b * a.nq + j) * a.T + t) * C + c;
+    for (int w = 0; w < FWAVES; ++w) g += sgb[w * NQ + j];
+    const size_t o = (((size_t)b * NQ + j) * a.T + t) * C + c;
     a.G[o] = a.inv_sqrt_d * (sdp[i] - g * a.pooled[o]);
   }
 }
 
-int fused_fill(FusedArgs& a, const void* const* taps, int n_taps, int dtype, int D, int F, int N, int T, int nq) {
-  MVF_CHECK_ARG(taps && F > 0 && N > 0 && T > 0 && F % T == 0 && (dtype == MVF_F32 || dtype == MVF_BF16));
-  if (!(n_taps >= 1 && n_taps <= FTAPS && nq >= 1 && nq <= FQ && D % 8 == 0 && D <= 8 * 64 * FSLOT)) return MVF_ERR_UNSUPPORTED;
-  const size_t lds = ((size_t)nq * n_taps * D + (size_t)nq * N + FWAVES * nq * 2) * sizeof(float);
-  if (lds > 96 * 1024) return MVF_ERR_UNSUPPORTED;
-  for (int i = 0; i < n_taps; ++i) {
-    MVF_CHECK_ARG(taps[i] && ((uintptr_t)taps[i] & 15) == 0);
-    a.taps[i] = taps[i];
-  }
-  a.n_taps = n_taps; a.D = D; a.N = N; a.T = T; a.nq = nq;
-  return MVF_OK;
+// [nq][C] vectors / merge buffer, [nq][N] scores or weights, per-wave statistics
+size_t fused_lds(int nq, int n_taps, int D, int N) { return ((size_t)nq * n_taps * D + (size_t)nq * N + FWAVES * nq * 2) * sizeof(float); }
+
+// shapes with an instantiation: nq 1..3, 1 or 3 taps, D = 768 or 1024 (ViT-B / ViT-L) -- except 3 queries on 3 taps of 1024
+// channels, whose 144 accumulators + two tokens do not fit 256 registers (160+ spills: the three-launch form is faster)
+bool fused_supported(int n_taps, int D, int N, int nq) {
+  return nq >= 1 && nq <= 3 && (n_taps == 1 || n_taps == 3) && (D == 768 || D == 1024) && N >= 1 &&
+         nq * n_taps * (D / 256) <= 27 && fused_lds(nq, n_taps, D, N) <= 96 * 1024;
 }
 
 template <typename K>
-int fused_launch(K kernel, const FusedArgs& a, int F, hipStream_t st) {
-  const size_t lds = ((size_t)a.nq * a.n_taps * a.D + (size_t)a.nq * a.N + FWAVES * a.nq * 2) * sizeof(float);
+int fused_go(K kernel, const FusedArgs& a, size_t lds, int F, hipStream_t st) {
   if (lds > 48 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return MVF_ERR_ARG;
   hipLaunchKernelGGL(kernel, dim3(F), dim3(512), lds, st, a);
   MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+template <bool BWD, typename T, int NQ, int NT>
+int fused_pick_ng(const FusedArgs& a, size_t lds, int F, hipStream_t st) {
+  if (a.D == 768) return BWD ? fused_go(lstp_fused_bwd_kernel<T, NQ, NT, 3>, a, lds, F, st) : fused_go(lstp_fused_fwd_kernel<T, NQ, NT, 3>, a, lds, F, st);
+  return BWD ? fused_go(lstp_fused_bwd_kernel<T, NQ, NT, 4>, a, lds, F, st) : fused_go(lstp_fused_fwd_kernel<T, NQ, NT, 4>, a, lds, F, st);
+}
+template <bool BWD, typename T, int NQ>
+int fused_pick_nt(const FusedArgs& a, int n_taps, size_t lds, int F, hipStream_t st) {
+  return n_taps == 1 ? fused_pick_ng<BWD, T, NQ, 1>(a, lds, F, st) : fused_pick_ng<BWD, T, NQ, 3>(a, lds, F, st);
+}
+template <bool BWD, typename T>
+int fused_pick(const FusedArgs& a, int n_taps, int nq, int F, hipStream_t st) {
+  const size_t lds = fused_lds(nq, n_taps, a.D, a.N);
+  switch (nq) {
+    case 1: return fused_pick_nt<BWD, T, 1>(a, n_taps, lds, F, st);
+    case 2: return fused_pick_nt<BWD, T, 2>(a, n_taps, lds, F, st);
+    default: return fused_pick_nt<BWD, T, 3>(a, n_taps, lds, F, st);
+  }
+}
+
+int fused_fill(FusedArgs& a, const void* const* taps, int n_taps, int dtype, int D, int F, int N, int T, int nq) {
+  MVF_CHECK_ARG(taps && F > 0 && N > 0 && T > 0 && F % T == 0 && (dtype == MVF_F32 || dtype == MVF_BF16));
+  if (!fused_supported(n_taps, D, N, nq)) return MVF_ERR_UNSUPPORTED;
+  for (int i = 0; i < n_taps; ++i) {
+    MVF_CHECK_ARG(taps[i] && ((uintptr_t)taps[i] & 15) == 0);
+    a.taps[i] = taps[i];
+  }
+  a.D = D; a.N = N; a.T = T;
   return MVF_OK;
 }
 
@@ -709,7 +737,7 @@ extern "C" int mvf_lstp_fused_fwd(const void* const* taps, int n_taps, int dtype
   if (rc != MVF_OK) return rc;
   MVF_CHECK_ARG(vec && P && pooled);
   a.vec = vec; a.per_frame = per_frame; a.inv_sqrt_d = inv_sqrt_d; a.P = P; a.pooled = pooled;
-  return dtype == MVF_BF16 ? fused_launch(lstp_fused_fwd_kernel<bf16_t>, a, F, st) : fused_launch(lstp_fused_fwd_kernel<float>, a, F, st);
+  return dtype == MVF_BF16 ? fused_pick<false, bf16_t>(a, n_taps, nq, F, st) : fused_pick<false, float>(a, n_taps, nq, F, st);
 }
 
 // One-pass backward: G [Bc, nq, T, C] = d loss / d vec of every frame (rows (clip, query, frame)) from dpooled, the forward's
@@ -723,5 +751,5 @@ extern "C" int mvf_lstp_fused_bwd(const void* const* taps, int n_taps, int dtype
   MVF_CHECK_ARG(dpooled && P && pooled && G);
   a.vec = dpooled; a.per_frame = 1; a.inv_sqrt_d = inv_sqrt_d; a.P = const_cast<float*>(P); a.pooled = const_cast<float*>(pooled);
   a.G = G;
-  return dtype == MVF_BF16 ? fused_launch(lstp_fused_bwd_kernel<bf16_t>, a, F, st) : fused_launch(lstp_fused_bwd_kernel<float>, a, F, st);
+  return dtype == MVF_BF16 ? fused_pick<true, bf16_t>(a, n_taps, nq, F, st) : fused_pick<true, float>(a, n_taps, nq, F, st);
 }

@@ -3,7 +3,7 @@
     python tools/gemm_bench.py [--variant 0|1|2] [--shapes qkv,proj,fc1,fc2] [--frames 256] [--iters 20] [--ln] [--rounds 3]
 
 --ln: the same shapes with the LN-fold epilogue extras (mvf_gemm_tc_ln: consumer side for qkv / fc1, producer side for proj /
-fc2), interleaved with the plain form in one process.  --variant 0 is the automatic choice (tail rows on the 128x128 kernel).
+fc2), interleaved with the plain form in one process.  --variant 0 is the automatic choice of mvf_gemm_tc.
 
 Run it under `rocprofv3 --kernel-trace --stats` or `rocprofv3 --pmc ...` to get per-kernel durations / counters for
 exactly the ViT-B/16 shapes of BASELINE configs[1] (M = frames * 197)."""

@@ -180,9 +180,8 @@ int mvf_layernorm_fwd(int out_dtype, const float* x, size_t in_stride, const flo
                       size_t out_stride, int rows, int D, float eps, hipStream_t stream);
 /* variant (bf16): 0 = product path (two query tiles per wave; one key block for N = 193..208, else 96-key blocks streamed
  * through a double-buffered LDS-DMA pipeline), 1 = 2-byte gather reads of V (cross-check of the transposing LDS read),
- * 2 = the earlier kernels (one tile per wave / synchronously staged 224-key blocks), 3 = variant 0 at 2 waves per SIMD,
- * 4 = streamed 64-key blocks, 5 = the streamed kernel for every N, 6 = N = 193..208 as a persistent kernel that stages the next
- * (frame, head)'s K under the current one's tail (2..6: A/B measurements; 6 measured slower than 0) */
+ * 2 = the earlier kernels (one tile per wave / synchronously staged 224-key blocks; what other values fall back to),
+ * 4 = streamed 64-key blocks */
 int mvf_vit_attn_fwd(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t stream);
 int mvf_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t stream);
 int mvf_cast_bf16_f32(const void* in, float* out, size_t n, hipStream_t stream);     /* n % 4 == 0 */

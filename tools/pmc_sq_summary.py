@@ -18,7 +18,7 @@ for f in sorted(glob.glob(os.path.join(root, '**', '*counter_collection.csv'), r
         per_disp[(int(r['Dispatch_Id']), r['Kernel_Name'])][r['Counter_Name']] = float(r['Counter_Value'])
     seen = set()
     for (did, kn), cs in sorted(per_disp.items()):
-        short = re.sub(r'\(.*', '', kn).replace('void (anonymous namespace)::', '')
+        short = re.sub(r'\(\(anonymous namespace\)::GemmTcArgs\).*|\(gemm_tc::GemmTcArgs\).*', '', kn.replace('void (anonymous namespace)::', ''))
         if short not in seen:
             seen.add(short)        # drop the first (cold) launch of each kernel in each pass
             continue

@@ -247,8 +247,8 @@ __device__ __forceinline__ f32x2_t pk_add(f32x2_t a, f32x2_t b) { return a + b; 
 struct NoHook {
   __device__ __forceinline__ void operator()() const {}
 };
-// after_s: called once the S phase's MFMAs are issued and K is no longer read by this wave (the persistent kernel meets the
-// workgroup there and starts the NEXT unit's K staging under this pair's softmax and P.V)
+// after_s: called once the S phase's MFMAs are issued and K is no longer read by this wave (hook of the persistent form that
+// was removed in round 3; the default does nothing)
 template <int NT, int NQ, typename AfterS = NoHook>
 __device__ __forceinline__ void attn_tiles(const AttnArgs& a, const char* sk, const char* sv, bf16_t* obase,
                                            const bf16x8_t (&qf)[2][2], const int (&qt)[2], int li, int g, int vsw,
@@ -416,72 +416,10 @@ __global__ __launch_bounds__(256, OCC) void vit_attn_bf16_pair_kernel(AttnArgs a
   }
 }
 
-// The same for ntile == 13 as a PERSISTENT kernel: a workgroup walks (frame, head) units blockIdx.x, blockIdx.x + gridDim.x, ...
-// with the one K / V image pair; the next unit's K pieces are issued right after every wave has finished the current unit's
-// last S phase (K is dead from there on), so their latency passes under the second pair's softmax, P.V and stores; V of the next
-// unit is issued at the top of the next iteration (V is read until the end) and lands under its first S phase as before.
-template <int NT, int OCC>
-__global__ __launch_bounds__(256, OCC) void vit_attn_bf16_pair_persist_kernel(AttnArgs a, int units) {
-  constexpr int KROWS = NT * 16;
-  constexpr int NP = KROWS / 8;
-  __shared__ __attribute__((aligned(16))) char smem[2 * KROWS * 128];
-  char* sk = smem;
-  char* sv = smem + KROWS * 128;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, g = lane >> 4;
-  const size_t ld = (size_t)3 * a.D;
-  const int vsw = ((2 * g + (li >> 3)) & 3) << 5;
-  const int prow = lane >> 3, pc = lane & 7;
-  const bool four = wave == 0;                      // 13 query tiles: wave 0 owns 4 (0, 4, 8, 12), waves 1-3 own 3
-  auto unit_base = [&](int u) { return reinterpret_cast<const bf16_t*>(a.qkv) + (size_t)(u / a.H) * a.N * ld + (u % a.H) * HD; };
-  auto issue_k = [&](int u) {
-    const bf16_t* kbp = unit_base(u) + a.D;
-    for (int p = wave; p < NP; p += 4) {
-      const int r = p * 8 + prow;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(kbp + (size_t)min(r, a.N - 1) * ld + ((pc ^ (r & 7)) << 3)), LDS_PTR(sk + p * 1024), 16, 0, 0);
-    }
-  };
-  int u = blockIdx.x;
-  if (u >= units) return;
-  issue_k(u);
-  for (; u < units; u += gridDim.x) {
-    const bf16_t* base = unit_base(u);
-    const bf16_t* qb = base;
-    const bf16_t* vbp = base + 2 * a.D;
-    bf16_t* obase = reinterpret_cast<bf16_t*>(a.out) + (size_t)(u / a.H) * a.N * a.D + (u % a.H) * HD;
-    auto load_q = [&](bf16x8_t (&qf)[2][2], const int (&qt)[2]) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int qrow = min(qt[i] * 16 + li, a.N - 1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[i][ks] = *reinterpret_cast<const bf16x8_t*>(qb + (size_t)qrow * ld + ks * 32 + g * 8);
-      }
-    };
-    bf16x8_t qf[2][2];
-    int qt[2] = {wave, wave + 4};
-    load_q(qf, qt);
-    for (int p = wave; p < NP; p += 4) {
-      const int r = p * 8 + prow;    // rows >= N repeat row N-1: finite values, their probabilities are 0
-      __builtin_amdgcn_global_load_lds(GLB_PTR(vbp + (size_t)min(r, a.N - 1) * ld + ((pc ^ (((r >> 1) & 3) << 1)) << 3)),
-                                       LDS_PTR(sv + p * 1024), 16, 0, 0);
-    }
-    // everything older than this wave's V pieces has retired: its K pieces of this unit, the previous unit's stores, Q
-    if (wave < (NP & 3)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NP + 3) / 4) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP / 4) : "memory");
-    __builtin_amdgcn_s_barrier();
-    attn_tiles<NT, 2>(a, sk, sv, obase, qf, qt, li, g, vsw, true);
-    qt[0] = wave + 8; qt[1] = wave + 12;
-    load_q(qf, qt);
-    const int un = u + gridDim.x;
-    auto next_k = [&]() {
-      __builtin_amdgcn_s_barrier();          // every wave is past its last read of K
-      if (un < units) issue_k(un);
-    };
-    if (four) attn_tiles<NT, 2>(a, sk, sv, obase, qf, qt, li, g, vsw, false, next_k);
-    else attn_tiles<NT, 1>(a, sk, sv, obase, qf, qt, li, g, vsw, false, next_k);
-    __builtin_amdgcn_s_barrier();            // every wave is past its last read of V: the next iteration re-stages it
-  }
-}
+// (A persistent form -- 3 x 256 workgroups walking the (frame, head) units with one K / V image pair, the next unit's K pieces
+// issued as soon as every wave is past the current unit's last S phase -- was built in round 2, was bit-identical and measured
+// SLOWER: 105.9 us against 78.2 us (two more workgroup barriers per unit, 24 spilled registers at the 168-VGPR budget; what it
+// saves is what the CU's other two workgroups already hide).  Removed in round 3 together with the 2-waves-per-SIMD form (114 us).)
 
 // ------------------------------------------------------------------------------------------------
 // bf16, any N: key blocks of KT*16 keys streamed through a double-buffered LDS-DMA pipeline, two query tiles per wave
@@ -800,15 +738,8 @@ int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H
     const int ntile = ceil_div(N, 16);
     const dim3 fg(F * H, ceil_div(ntile, 8));   // streamed kernels: 8 query tiles per workgroup
     if (variant == 1) hipLaunchKernelGGL((vit_attn_bf16_kernel<false, KT>), grid, dim3(256), 0, st, a);
-    else if (variant == 5) hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<6, 3>), fg, dim3(256), 0, st, a);   // any N (A/B)
     else if (a.nblk == 1 && ntile == 13 && variant == 0)
       hipLaunchKernelGGL((vit_attn_bf16_pair_kernel<13, 3>), grid, dim3(256), 0, st, a);
-    else if (a.nblk == 1 && ntile == 13 && variant == 6) {
-      const int units = F * H;
-      hipLaunchKernelGGL((vit_attn_bf16_pair_persist_kernel<13, 3>), dim3(std::min(units, 3 * 256)), dim3(256), 0, st, a, units);
-    }
-    else if (a.nblk == 1 && ntile == 13 && variant == 3)
-      hipLaunchKernelGGL((vit_attn_bf16_pair_kernel<13, 2>), grid, dim3(256), 0, st, a);
     else if (a.nblk == 1 && ntile == 13) hipLaunchKernelGGL((vit_attn_bf16_kernel<true, 13>), grid, dim3(256), 0, st, a);
     else if (variant == 0) hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<6, 3>), fg, dim3(256), 0, st, a);   // 96-key blocks
     else if (variant == 4) hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<4, 4>), fg, dim3(256), 0, st, a);   // 64-key blocks

@@ -50,8 +50,8 @@
 //    their epilogues' residual traffic does not arrive as one chip-wide burst -- 104 -> 104..112 us, 11.6 -> 11.9 ms/step.
 //  * tried and rejected (PMC): rotating the K loop per A row-panel to shorten W's L2 re-use distance -- the L2 hits come
 //    from workgroups reading the SAME slices at the SAME time; rotation cut the hit rate from 74 % to 47 % (fc2).
-//  * tried and rejected (round 2): waiting for every half-tile as late as legal (counted vmcnt(10) in P0 / P1 / P3: five
-//    half-tiles in flight instead of three; MVF_GEMM_DEEP) -- K loop 36.5 k -> 37.9 k ticks; the loop is not feed-bound
+//  * tried and rejected (round 2, code removed in round 3): waiting for every half-tile as late as legal (counted vmcnt(10) in
+//    P0 / P1 / P3: five half-tiles in flight instead of three) -- K loop 36.5 k -> 37.9 k ticks; the loop is not feed-bound
 //    (timing ablations: DESIGN.md section 4, tools/gemm_stamps.py ABL=...).
 //  * tried and rejected (round 2): every second workgroup of an XCD sleeping 0.15 .. 0.65 of a tile time before its first tile
 //    (fc2, K = 3072) so that the read-modify epilogues of half the chip meet the other half's K loops instead of each other:
@@ -96,9 +96,6 @@ constexpr int SC_OFF = LNMR_OFF + 2 * 2048;     // fp8: two K tiles' scales, [bu
 constexpr int LDS_BYTES = SC_OFF + 2 * 2048;    // 140 KiB -> one workgroup per CU
 constexpr int OFF_A0 = 0, OFF_A1 = HALF_BYTES, OFF_B0 = 2 * HALF_BYTES, OFF_B1 = 3 * HALF_BYTES;
 
-#ifndef MVF_GEMM_DEEP
-#define MVF_GEMM_DEEP 0
-#endif
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -147,7 +144,7 @@ __device__ __forceinline__ void mfma_mx(f32x4_t& acc, const i32x8_t& w, const i3
 template <int EPI, bool DBG, bool LN, bool FP8, int ABL = 0, bool ADD2 = false, int BMT = 256>   // ABL: timing ablations (dbg_abl)
 __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  static_assert(BMT == 256 || BMT == 224 || BMT == 192, "tile rows");   // (192 compiles and is correct; measured slower)
+  static_assert(BMT == 256 || BMT == 224, "tile rows");   // (192-row tiles: correct, measured slower -- 11.92 vs 11.48 ms/step)
   constexpr int WRS = BMT / 2;              // rows of a wave row (128 / 112)
   constexpr int RT1 = (WRS - 64) / 16;      // 16-row fragments of the second m-quadrant (4 / 3)
   const int tid = threadIdx.x;
@@ -311,11 +308,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   STAMP();
 
   bf16x8_t af[4][2] = {}, bf0[2][2] = {}, bf1[2][2] = {};
-  // DEEP: every half-tile is waited for right before the barrier in front of its first read, with a counted vmcnt that leaves the
-  // five younger half-tiles in flight (80 KiB per workgroup), instead of one vmcnt(6) per K tile that makes A1 land within three
-  // phases of its issue.  The issue schedule is unchanged (it always ran this far ahead).  fp8: its scale DMA rides with A1 and
-  // is read one K tile earlier than A1 itself, so it keeps the single wait.
-  constexpr bool DEEP = !FP8 && MVF_GEMM_DEEP;
   // fp8: a fragment is ONE 32-byte operand (8 consecutive registers), filled by two 16-byte LDS reads into its halves
   i32x8_t afq[4], bq0[2], bq1[2];
   unsigned sfa[4], sf0[2], sf1[2];   // fp8: the E8M0 scale of each fragment's 32-k block, in byte 0
@@ -403,9 +395,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
       stage_scales((BUF) ^ 1, t + 1 + kwrap);                                                                \
     }                                                                                                        \
     SCHED_FENCE();                                                                                           \
-    if constexpr (DEEP) { /* B1 of this K tile (read next phase): the five younger half-tiles stay in flight */\
-      if (CAN_ISSUE(1)) { WAIT_VMCNT(10); } else { WAIT_VMCNT(0); }                                          \
-    }                                                                                                        \
     WAIT_LGKM(8); /* everything in front of the eight A reads is back: the B reads (and the fp8 scales) */   \
     WG_BARRIER();                                                                                            \
     KSTAMP();                                                                                                \
@@ -429,9 +418,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     /* P1 */                                                                                                 \
     LOAD_B(bf1, bq1, sf1, OFF_B1);                                                                                \
     if (CAN_ISSUE(2)) stage((BUF), OFF_B0, a.W, wsrc[0], t + 2 + kwrap);                                     \
-    if constexpr (DEEP) { /* A1 of this K tile (read next phase) */                                          \
-      if (CAN_ISSUE(2)) { WAIT_VMCNT(10); } else { WAIT_VMCNT(0); }                                          \
-    }                                                                                                        \
     WG_BARRIER();                                                                                            \
     KSTAMP();                                                                                                \
     WAIT_LGKM(0);                                                                                            \
@@ -455,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     /* P3 */                                                                                                 \
     if (CAN_ISSUE(2)) {                                                                                      \
       stage((BUF), OFF_B1, a.W, wsrc[1], t + 2 + kwrap);                                                          \
-      if constexpr (DEEP) { WAIT_VMCNT(10); } else { WAIT_VMCNT(6); }  /* DEEP: B0, A0 of the next K tile */ \
+      WAIT_VMCNT(6);                                                                                         \
     } else {                                                                                                 \
       WAIT_VMCNT(0);                                                                                         \
     }                                                                                                        \

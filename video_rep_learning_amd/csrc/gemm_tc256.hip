@@ -60,8 +60,9 @@
 //    half registers on the unified file) with 224-row tiles, so that 64 registers per SIMD lane stay free and a wave of another
 //    stream's small kernel (LayerNorm 40 VGPRs, im2col, the head's row kernels) runs INSIDE the GEMM's CU instead of waiting
 //    for a workgroup to leave.  The kernels do co-execute (LayerNorm overlapped with the other lane's GEMM 49 % of its time
-//    instead of 29 %), but the cap costs 4 - 19 spilled registers: all GEMMs 10.14 -> 10.68 ms one kernel at a time (+5 %),
-//    step 11.75 -> 12.40 ms on the same box.  What co-execution gave back (about 0.25 ms) is less than what the spills cost.
+//    instead of 29 %), but the cap costs 4 - 19 spilled registers: all GEMMs 10.14 -> 10.68 ms one kernel at a time (+0.54 ms),
+//    step 11.75 -> 12.40 ms on the same box (+0.65 ms): co-execution returned nothing on top of what the spills cost (the guest
+//    wave takes LDS-DMA / VALU issue slots from the SIMD's two GEMM waves).
 //  * XCD-aware tile walk: workgroups b, b+8, ... share an XCD (round-robin dispatch, speed only); group x = b & 7 owns a
 //    contiguous chunk of the tile list (tiles of one A row-panel are neighbours).  A workgroup's FIRST tile is static
 //    (chunk start + b/8); every further tile is a ticket from the group's counter (a.sched, agent-scope atomic), so a

@@ -49,12 +49,24 @@ PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
 
 
 def tile_rows(M, N, nwg=256):
-    """The 256x256-thread kernel's tile rows for an [M, N] output (csrc/gemm_tc256.hip launch<>): 224 for launches of three or
-    more rounds on at most three tile columns whose last round gets at least 8 % shorter, else 256."""
+    """The 256x256-thread kernel's tile rows for an [M, N] output (csrc/gemm_tc256.hip pick_tile_rows): for launches of three
+    or more rounds the height of 256 / 240 / 224 / 208 whose rounds x rows x (1 + penalty) is smallest, else 256."""
+    forced = int(os.environ.get('MVF_GEMM_BM', '0'))
+    if forced in (256, 240, 224, 208):
+        return forced
+    allowed = int(os.environ.get('MVF_GEMM_BM_SET', '7'))
     nbn = (N + 255) // 256
-    r256 = -(-(-(-M // 256) * nbn) // nwg)
-    r224 = -(-(-(-M // 224) * nbn) // nwg)
-    return 224 if (r256 >= 3 and nbn <= 3 and r224 * 224 * 27 < r256 * 256 * 25) else 256
+    rounds = lambda bm: -(-(-(-M // bm) * nbn) // nwg)
+    if rounds(256) < 3:
+        return 256
+    best, cost = 256, rounds(256) * 256 * 1000
+    for i, (h, pen) in enumerate(((240, 1020), (224, 1080), (208, 1110))):
+        if not (allowed >> i & 1) or (rounds(256) < 8 if h == 240 else nbn > 3):
+            continue
+        c = rounds(h) * h * pen
+        if c < cost:
+            best, cost = h, c
+    return best
 
 
 def rocprof_names(groups, dtype, ln_fold, defer=True, frames=256, tokens=197):

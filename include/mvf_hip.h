@@ -152,8 +152,9 @@ int mvf_gemm_tc_batched_f32(const void* A, int lda, const void* W, int ldw, floa
                             int batch_rows, int w_batch_rows, hipStream_t stream);
 /* kernel choice for mvf_gemm_tc / mvf_vit_fwd (A/B measurements and tests): 0 automatic (bf16 and K % 128 == 0 ->
  * persistent 256x256 8-phase kernel, else 128x128), 1 always 128x128, 2 only 256x256 (MVF_ERR_UNSUPPORTED where it
- * cannot run), 3 the 256x256 kernel with one workgroup per tile instead of one per CU, 4 / 5 as 2 with the tile rows pinned to
- * 224 / 256 (0, 2, 3: 224-row tiles where they shorten the last round of a full-batch launch, else 256) */
+ * cannot run), 3 the 256x256 kernel with one workgroup per tile instead of one per CU, 4 / 5 / 6 / 7 as 2 with the tile rows
+ * pinned to 224 / 256 / 240 / 208 (0, 2, 3: the height that makes ceil(tiles / workgroups) x rows of a launch of three or
+ * more rounds smallest, else 256) */
 int mvf_gemm_tc_select(int variant);
 /* diagnostic: out[2b] = XCD id, out[2b+1] = HW_ID of workgroup b of a 1-D launch (placement study, never on the path) */
 int mvf_debug_xcc_map(int* out, int nblocks, int threads, int lds_bytes, hipStream_t stream);

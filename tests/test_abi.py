@@ -39,7 +39,7 @@ def test_argument_errors_are_reported_before_any_launch(lib):
     # NULL pointers / bad shapes are rejected on the host with MVF_ERR_ARG (10001) -- no GPU needed
     assert lib.mvf_gemm_tc(_lib.BF16, 0, None, 0, None, 0, None, None, 0, None, 0, None, 0, None, None, 0, 0, 0, 0, None) == 10001
     assert lib.mvf_scl_fwd(None, None, None, None, None, None, None, None, None, 0, 0, 0, 0, 0.1, 10.0, None) == 10001
-    assert lib.mvf_gemm_tc_select(7) == 10001
+    assert lib.mvf_gemm_tc_select(8) == 10001
     assert lib.mvf_gemm_tc_select(0) == 0
     assert lib.mvf_vit_workspace_bytes(_lib.BF16, 256, 197, 768, 16) >= 256 * 197 * 768 * (4 + 2 + 6 + 8)
     with pytest.raises(_lib.MvfError):

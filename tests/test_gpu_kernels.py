@@ -79,7 +79,7 @@ def test_gemm_tc256_equals_tc128_bitwise(M, N, K, epi):
         return Cd, R, tap
 
     ref = run(1)
-    for rep, variant in enumerate((2, 3, 4, 5, 4, 3, 0)):
+    for rep, variant in enumerate((2, 3, 4, 5, 6, 7, 4, 7, 3, 0)):
         # persistent with the tile rows chosen per launch / one workgroup per tile / persistent with 224-row tiles / with 256-row
         # tiles / the automatic choice of the product
         got = run(variant)
@@ -125,7 +125,7 @@ def test_gemm_ln_fold_producer_epilogue(M, N, K, layerscale):
         check(stats[..., 1].t(), (xs * xs).sum(-1), 1e-5, 'partial sums of squares')
         if tap is not None:
             assert torch.equal(tap, xb.view(M // tpf, tpf, N)[:, 1:].reshape(-1, N))
-    for variant in (1, 2, 4, 5):     # pinned 128x128 / 256-thread kernel (auto, 224-row, 256-row tiles): residual, xb AND the partial sums bit for bit the automatic run's
+    for variant in (1, 2, 4, 5, 6, 7):     # pinned 128x128 / 256-thread kernel (auto, 224-row, 256-row tiles): residual, xb AND the partial sums bit for bit the automatic run's
         _lib.call('mvf_gemm_tc_select', variant)
         try:
             x2 = x0.clone()
@@ -175,7 +175,7 @@ def test_gemm_ln_fold_consumer_epilogue(M, N, K, epi):
         assert e_ln <= 1e-2, e_ln
     # the 128x128 kernel (which takes the rows of a mostly empty last round) and the 256x256 kernel (tile rows chosen per launch,
     # 224, 256) agree bit for bit
-    for variant in (1, 2, 4, 5):
+    for variant in (1, 2, 4, 5, 6, 7):
         _lib.call('mvf_gemm_tc_select', variant)
         try:
             C2 = torch.full((M, N), 7.0, device=DEV, dtype=torch.bfloat16)
@@ -521,7 +521,7 @@ def test_deferred_residual_layernorm_add_and_second_addend(M, D, K):
     want = x.double() + A.double() @ W.double().t() + b.double() + delta.double()
     Ad, Wd, bb = A.to(DEV), W.to(DEV), b.to(DEV)
     outs = []
-    for variant in (2, 1, 4, 5):       # persistent kernel (auto / 224-row / 256-row tiles), 128x128 kernel
+    for variant in (2, 1, 4, 5, 6, 7):       # persistent kernel (auto / 224-row / 256-row tiles), 128x128 kernel
         _lib.call('mvf_gemm_tc_select', variant)
         r = x.clone().to(DEV)
         _lib.call('mvf_gemm_tc_resid2', Ad.data_ptr(), K, Wd.data_ptr(), K, bb.data_ptr(), r.data_ptr(), D, dd.data_ptr(), D, None, 0,

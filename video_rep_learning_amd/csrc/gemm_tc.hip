@@ -344,9 +344,10 @@ extern "C" int mvf_gemm_tc_batched_f32(const void* A, int lda, const void* W, in
 }
 
 extern "C" int mvf_gemm_tc_select(int variant) {
-  MVF_CHECK_ARG(variant >= 0 && variant <= 5);
-  // 4 / 5: the persistent 256x256-thread kernel with its tile rows pinned to 224 / 256 (0, 2, 3: chosen per launch)
-  mvf_gemm_tc256_set_bm(variant == 4 ? 224 : variant == 5 ? 256 : 0);
+  MVF_CHECK_ARG(variant >= 0 && variant <= 7);
+  // 4 .. 7: the persistent 256x256-thread kernel with its tile rows pinned to 224 / 256 / 240 / 208 (0, 2, 3: chosen per launch)
+  static const int rows[8] = {0, 0, 0, 0, 224, 256, 240, 208};
+  mvf_gemm_tc256_set_bm(rows[variant]);
   if (variant >= 4) variant = 2;
   g_variant = variant;
   return MVF_OK;

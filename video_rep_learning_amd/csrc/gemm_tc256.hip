@@ -145,13 +145,18 @@ __device__ __forceinline__ void mfma_mx(f32x4_t& acc, const i32x8_t& w, const i3
 template <int EPI, bool DBG, bool LN, bool FP8, int ABL = 0, bool ADD2 = false, int BMT = 256>   // ABL: timing ablations (dbg_abl)
 __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  static_assert(BMT == 256 || BMT == 224, "tile rows");   // (192-row tiles: correct, measured slower -- 11.92 vs 11.48 ms/step)
-  constexpr int WRS = BMT / 2;              // rows of a wave row (128 / 112)
-  constexpr int RT1 = (WRS - 64) / 16;      // 16-row fragments of the second m-quadrant (4 / 3)
+  static_assert(BMT == 256 || BMT == 240 || BMT == 224 || BMT == 208, "tile rows");   // (192: correct, slower -- 11.92 vs 11.48 ms/step)
+  // 16-row fragments of the second m-quadrant of wave row 0 / 1 (the first quadrant always has four): 4|4, 4|3, 3|3, 3|2.  The two
+  // wave rows of a SIMD share its matrix pipe, so unequal rows cost nothing: the pipe sees 64 + 16 (RTA + RTB) / 2 rows' worth
+  constexpr int RTA = (BMT == 256 || BMT == 240) ? 4 : 3;
+  constexpr int RTB = BMT == 256 ? 4 : (BMT == 208 ? 2 : 3);
+  constexpr int WR0 = 64 + 16 * RTA;        // rows of wave row 0 = first row of wave row 1
+  static_assert(WR0 + 64 + 16 * RTB == BMT, "tile rows");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+  const int rt1 = wr ? RTB : RTA;           // this wave's quadrant-1 fragments (wave-uniform)
   unsigned long long stamps[8];
   unsigned long long kst[16];   // DBG: barrier-by-barrier stamps of ONE K tile (a.dbg_kt) of the workgroup's second tile
   int nstamp = 0, nk_st = 0, tiles_done = 0;
@@ -228,8 +233,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int r = (i * 8 + wave) * 8 + prow;                 // row inside the half-tile, 0..127
-        // A: wave row r>>6, m-quadrant h (BMT 224: rows 48 .. 63 of quadrant 1 are not part of the tile; they re-read row 47)
-        const int am = (r >> 6) * WRS + h * 64 + min(r & 63, h ? RT1 * 16 - 1 : 63);
+        // A: wave row r>>6, m-quadrant h (quadrant 1 of a wave row with fewer than four fragments: the rows past its last
+        // fragment are not part of the tile; they re-read that fragment's last row)
+        const int am = (r >> 6) * WR0 + h * 64 + min(r & 63, h ? ((r >> 6) ? RTB : RTA) * 16 - 1 : 63);
         const int wn = (r >> 5) * 64 + h * 32 + (r & 31);        // W: wave column r>>5, n-quadrant h
         int gm = min(tm0 + am, a.M - 1);
         if constexpr (DBG) gm &= (int)a.dbg_rowmask;
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   }
 #define LOAD_A(OFF)                                                                                          \
   if constexpr ((ABL & 2) == 0)                                                                              \
-  _Pragma("unroll") for (int i = 0; i < ((OFF) == OFF_A1 ? RT1 : 4); ++i) {                                   \
+  _Pragma("unroll") for (int i = 0; i < ((OFF) == OFF_A1 ? RTA : 4); ++i) { /* (wave row 1 may read one fragment it does not use) */ \
     if constexpr (FP8) {                                                                                     \
       afq[i].lo = *reinterpret_cast<const i32x4_t*>(base + (OFF) + a_rd + i * 16 * ROWB);                    \
       afq[i].hi = *reinterpret_cast<const i32x4_t*>(base + (OFF) + (a_rd ^ KS1) + i * 16 * ROWB);            \
@@ -370,7 +376,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
       mfma_mx(acc[(MQ) * 4 + i][(NQ) * 2 + j], BQ[j], afq[i], SF[j], sfa[i]);                                \
   } else {                                                                                                   \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          \
-    _Pragma("unroll") for (int i = 0; i < ((MQ) == 1 ? RT1 : 4); ++i)                                         \
+    _Pragma("unroll") for (int i = 0; i < ((MQ) == 1 ? RTA : 4); ++i)                                         \
+      if (RTA == RTB || (MQ) == 0 || i < rt1) /* unequal wave rows: wave row 1 skips its missing fragment (wave-uniform) */ \
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
       acc[(MQ) * 4 + i][(NQ) * 2 + j] =                                                                      \
           __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][ks], af[i][ks], acc[(MQ) * 4 + i][(NQ) * 2 + j], 0, 0, 0); \
@@ -509,8 +516,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
 #pragma unroll
         for (int ii = 0; ii < EB; ++ii) {
           const int i = b * EB + ii;
-          if (i >= 4 + RT1) continue;            // (BMT 224: the wave row's eighth 16-row fragment does not exist)
-          const int m = m0 + wr * WRS + (i >> 2) * 64 + (i & 3) * 16 + frow;
+          if (i >= 4 + rt1) continue;            // (a fragment this wave row does not have)
+          const int m = m0 + wr * WR0 + (i >> 2) * 64 + (i & 3) * 16 + frow;
           epilogue_prefetch<EPI>(a, m, m < a.M, n0 + wc * 64, fgrp, add[MVF_EPI_PIPE ? (b & 1) : 0][ii]);
           if constexpr (ADD2) epilogue_prefetch2(a, m, m < a.M, n0 + wc * 64, fgrp, add2[ii]);
         }
@@ -521,12 +528,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
       // from this tile's LDS slot, the wave's 64 ln_c values from its own slot), then the plain epilogue with bias = d.
       // Done inside the store loop instead, the extra live values (c, mean/rstd) sat on top of the GELU temporaries and the
       // fc1 epilogue took twice as long.
-      const char* smr = smem + LNMR_OFF + tpar * 2048 + (wr * WRS + frow) * 8;
+      const char* smr = smem + LNMR_OFF + tpar * 2048 + (wr * WR0 + frow) * 8;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {     // column tile outermost: 4 ln_c values live at a time, (mean, rstd) re-read per row
         const float4 c = *reinterpret_cast<const float4*>(slnc + (j * 16 + fgrp * 4) * 4);
 #pragma unroll
-        for (int i = 0; i < 4 + RT1; ++i) {
+        for (int i = 0; i < 4 + RTA; ++i) {      // (a fragment wave row 1 lacks: unused accumulators, rows inside the slot)
           const float2 mr = *reinterpret_cast<const float2*>(smr + ((i >> 2) * 64 + (i & 3) * 16) * 8);
           const float nm = -mr.x;
           acc[i][j][0] = mr.y * fmaf(nm, c.x, acc[i][j][0]);
@@ -547,8 +554,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
 #pragma unroll
       for (int ii = 0; ii < EB; ++ii) {
         const int i = ih * EB + ii;
-        if (i >= 4 + RT1) continue;
-        const int m = m0 + wr * WRS + (i >> 2) * 64 + (i & 3) * 16 + frow;
+        if (i >= 4 + rt1) continue;
+        const int m = m0 + wr * WR0 + (i >> 2) * 64 + (i & 3) * 16 + frow;
         if constexpr (ADD2) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) addb[ii][j] = add_bf16x4(addb[ii][j], add2[ii][j]);
@@ -696,27 +703,44 @@ int launch_bm(const GemmTcArgs& a0, bool persistent, hipStream_t st) {
   return MVF_OK;
 }
 
-// tile rows: MVF_GEMM_BM = 256 | 224 pins them (A/B measurements, tests through mvf_gemm_tc_select 4 / 5), otherwise 224 where
-// ceil(tiles / workgroups) x rows comes out smaller (persistent launches; the fp8, stamped and stacked-batch forms keep 256)
+// tile rows: MVF_GEMM_BM = 256 | 240 | 224 | 208 pins them (A/B measurements, tests through mvf_gemm_tc_select 4 .. 7), otherwise
+// the height whose ceil(tiles / workgroups) x rows x (1 + penalty) comes out smallest (persistent launches; the fp8, stamped and
+// stacked-batch forms keep 256).  g_bm_set: the heights the automatic choice may use (MVF_GEMM_BM_SET, bit 0 = 240, 1 = 224, 2 = 208)
 int g_bm_mode = [] { const char* e = getenv("MVF_GEMM_BM"); return e ? atoi(e) : 0; }();
+int g_bm_set = [] { const char* e = getenv("MVF_GEMM_BM_SET"); return e ? atoi(e) : 7; }();
+
+// (mirrored by bench.py's tile_rows() -- rocprof kernel names carry the height)
+int pick_tile_rows(long M, long N, bool persistent) {
+  if (g_bm_mode == 256 || g_bm_mode == 240 || g_bm_mode == 224 || g_bm_mode == 208) return g_bm_mode;
+  if (!persistent) return 256;
+  const long nwg = std::max(8, num_cus() & ~7), nbn = (N + BN - 1) / BN;
+  auto rounds = [&](long bm) { return (((M + bm - 1) / bm) * nbn + nwg - 1) / nwg; };
+  const long r256 = rounds(256);
+  // only launches of three rounds or more on one to three tile columns: in the pipelined step (lane-sized launches of two
+  // rounds, another lane filling the tail) 224-row tiles measured 1 % slower, in a full-batch launch on its own 6 % faster (fc2)
+  if (r256 < 3) return 256;
+  // a shorter tile re-uses its W fragments over fewer rows and pays its epilogue more often: per-mille penalties
+  const int hs[3] = {240, 224, 208}, pen[3] = {1020, 1080, 1110};
+  long best = 256, cost = r256 * 256 * 1000;
+  for (int i = 0; i < 3; ++i) {
+    // 224 / 208: N <= 768 only (measured on the N = 768 shapes).  240: full-batch fc1 only (ten rounds: 258 -> 253-260 us on its
+    // own; on the lane-sized launches of the pipelined step, five rounds, 240-row tiles cost the step 1 %)
+    if (!(g_bm_set >> i & 1) || (hs[i] == 240 ? r256 < 8 : nbn > 3)) continue;
+    const long c = rounds(hs[i]) * hs[i] * pen[i];
+    if (c < cost) { cost = c; best = hs[i]; }
+  }
+  return (int)best;
+}
 
 template <int EPI, bool DBG = false, bool LN = false, bool FP8 = false, int ABL = 0, bool ADD2 = false>
 int launch(const GemmTcArgs& a, bool persistent, hipStream_t st) {
   if constexpr (!DBG && !FP8) {
-    bool use224 = false;
-    if (a.batch_rows == 0 && g_bm_mode != 256) {
-      if (g_bm_mode == 224) {
-        use224 = true;
-      } else if (persistent) {
-        const long nwg = std::max(8, num_cus() & ~7), nbn = (a.N + BN - 1) / BN;
-        const long r256 = (((a.M + 255) / 256) * nbn + nwg - 1) / nwg, r224 = (((a.M + 223) / 224) * nbn + nwg - 1) / nwg;
-        // an 8 % margin (a 224-row tile re-uses its W fragments over fewer rows), and only launches of three rounds or more
-        // on one to three tile columns: in the pipelined step (lane-sized launches of two rounds, another lane filling the
-        // tail) 224-row tiles measured 1 % slower, in a full-batch launch on its own 6 % faster (fc2)
-        use224 = r256 >= 3 && nbn <= 3 && r224 * 224 * 27 < r256 * 256 * 25;
-      }
+    if (a.batch_rows == 0) switch (pick_tile_rows(a.M, a.N, persistent)) {
+      case 240: return launch_bm<EPI, DBG, LN, FP8, ABL, ADD2, 240>(a, persistent, st);
+      case 224: return launch_bm<EPI, DBG, LN, FP8, ABL, ADD2, 224>(a, persistent, st);
+      case 208: return launch_bm<EPI, DBG, LN, FP8, ABL, ADD2, 208>(a, persistent, st);
+      default: break;
     }
-    if (use224) return launch_bm<EPI, DBG, LN, FP8, ABL, ADD2, 224>(a, persistent, st);
   }
   return launch_bm<EPI, DBG, LN, FP8, ABL, ADD2, 256>(a, persistent, st);
 }

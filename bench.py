@@ -33,6 +33,10 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md (no 2:1 sparsity)
+# what a bf16 GEMM K LOOP sustains on random operands under the chip's power management (measured, not a spec figure:
+# profiles/r03/wave4_probe.txt -- the product kernel 1 245, a four-wave loop with the matrix pipe 82 % busy 1 170-1 240 at the
+# 1.36-1.44 GHz the chip then holds).  Reported beside `peak` for context; `frac` stays priced against the nominal peak.
+SUSTAINED_BF16_LOOP_TFLOPS = 1245.0
 TFLOP_PER_CLIP = 1.1925       # algorithmic work of config #2 per clip (fwd backbone + f/b head)
 PEAK_F32_TFLOPS = 157.3       # fp32-input MFMA (= vector) peak, parity mode
 # (epilogue kind, N, K) of the ViT-B/16 GEMMs; M = frames * 197 (patch-embed: frames * 196)
@@ -392,6 +396,9 @@ def main():
                 'traffic': pmc_traffic(dom['name']), 'kernel': kern, 'launches': dom['launches'],
                 'timing': 'HIP events around each launch on its stream, kernels serialized (1 backbone lane, no lookahead)',
                 'avg_launch_us': dom['avg_us'], 'flop_per_launch': dom['flop'] / max(dom['launches'], 1),
+                **({'sustained_loop_rate': {'tflops': SUSTAINED_BF16_LOOP_TFLOPS, 'source': 'profiles/r03/wave4_probe.txt',
+                                            'all_gemm_frac_of_it': round(tot_fl / (tot_ms * 1e-3) / 1e12 / SUSTAINED_BF16_LOOP_TFLOPS, 4)}}
+                   if a.dtype == 'bf16' else {}),
                 'all_gemm': {'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 1), 'frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4),
                              'ms_per_step': round(tot_ms / max(a.profile_steps, 1), 3)},
                 'by_kernel': {r['name']: {'launches': r['launches'], 'avg_us': r['avg_us'], 'tflops': r['tflops']}

@@ -1,6 +1,6 @@
 """Mean per launch of every SQ / GRBM counter collected by tools/pmc_sq.sh (separate rocprofv3 --pmc passes over
 tools/gemm_bench.py --shapes qkv,fc1), per kernel name, first launch of each kernel dropped (cold).
-Usage: python3 tools/pmc_sq_summary.py gpurun_out/pmc_sq"""
+Usage: python3 tools/pmc_sq_summary.py gpurun_out/pmc_sq [kernel-name substring, default gemm_tc256_kernel]"""
 import csv
 import glob
 import os
@@ -9,16 +9,17 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+want = sys.argv[2] if len(sys.argv) > 2 else 'gemm_tc256_kernel'
 vals = defaultdict(lambda: defaultdict(list))
 for f in sorted(glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True)):
     per_disp = defaultdict(dict)
     for r in csv.DictReader(open(f)):
-        if 'gemm_tc256_kernel' not in r['Kernel_Name']:
+        if not any(w in r['Kernel_Name'] for w in want.split(',')):
             continue
         per_disp[(int(r['Dispatch_Id']), r['Kernel_Name'])][r['Counter_Name']] = float(r['Counter_Value'])
     seen = set()
     for (did, kn), cs in sorted(per_disp.items()):
-        short = re.sub(r'\(\(anonymous namespace\)::GemmTcArgs\).*|\(gemm_tc::GemmTcArgs\).*', '', kn.replace('void (anonymous namespace)::', ''))
+        short = re.sub(r'\(\(anonymous namespace\)::\w+\).*|\(gemm_tc::GemmTcArgs\).*', '', kn.replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', ''))
         if short not in seen:
             seen.add(short)        # drop the first (cold) launch of each kernel in each pass
             continue

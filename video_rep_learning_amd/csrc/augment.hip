@@ -85,6 +85,22 @@ __device__ __forceinline__ void point_op(int op, float f, float& r, float& g, fl
   }
 }
 
+// colour steps [lo, hi) of a clip: four fixed slots with constant indices, so that the step codes / factors are loaded into
+// SGPRs once (a run-time index into the kernel-argument block is a scalar load and a wait per use, inside the per-pixel loops)
+struct ColorSteps {
+  int op[4];
+  float fac[4];
+  __device__ __forceinline__ explicit ColorSteps(const ClipParams& c) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { op[k] = c.op[k]; fac[k] = c.fac[k]; }
+  }
+  __device__ __forceinline__ void run(int lo, int hi, float& r, float& g, float& b) const {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k >= lo && k < hi) point_op(op[k], fac[k], r, g, b);
+  }
+};
+
 // PyTorch upsample_bilinear2d, align_corners = False: source index and weight of output position d
 __device__ __forceinline__ void src_index(int d, int in, float scale, int& i0, int& i1, float& l0, float& l1) {
   float s = scale * ((float)d + 0.5f) - 0.5f;
@@ -95,7 +111,9 @@ __device__ __forceinline__ void src_index(int d, int in, float scale, int& i0, i
   l0 = 1.0f - l1;
 }
 
-// K1: one thread per output pixel, 32 x 8 pixels per workgroup (S = 224: 7 x 28 full workgroups per frame)
+// K1: one thread per output pixel, 32 x 8 pixels per workgroup (S = 224: 7 x 28 full workgroups per frame).  Measured and
+// dropped in round 3: four rows per thread (139 us against 135: the kernel queues on the gather loads, not on index
+// arithmetic) and one 8-byte load per tap pair (164 us: 8-byte loads at 4-byte alignment are slower than two dwords here)
 constexpr int RX = 32, RY = 8;
 __global__ __launch_bounds__(256) void resize_color_kernel(AugArgs a) {
   const int ft = blockIdx.z, cidx = ft / a.T;
@@ -119,8 +137,8 @@ __global__ __launch_bounds__(256) void resize_color_kernel(AugArgs a) {
       const float p00 = p[o00], p01 = p[o01], p10 = p[o10], p11 = p[o11];
       v[ch] = ly0 * (lx0 * p00 + lx1 * p01) + ly1 * (lx0 * p10 + lx1 * p11);
     }
-    const int stop = c.contrast_at >= 0 ? c.contrast_at : c.n_color;
-    for (int k = 0; k < stop; ++k) point_op(c.op[k], c.fac[k], v[0], v[1], v[2]);
+    const ColorSteps cs(c);
+    cs.run(0, c.contrast_at >= 0 ? c.contrast_at : c.n_color, v[0], v[1], v[2]);
     float* ob = a.buf + ((size_t)ft * 3) * S * S + (size_t)y * S + x;
     ob[0] = v[0]; ob[(size_t)S * S] = v[1]; ob[(size_t)2 * S * S] = v[2];
     gsum = tv_gray(v[0], v[1], v[2]);
@@ -139,6 +157,62 @@ __global__ __launch_bounds__(256) void resize_color_kernel(AugArgs a) {
 constexpr int TX = 64, TY = 16;
 __device__ __forceinline__ int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
+// The two blur passes with the tap count as a template parameter: the taps are read from the kernel arguments with constant
+// indices (SGPRs, once) and the loops unroll -- as run-time loops every tap was a scalar load + wait in front of one LDS read.
+// One fused multiply-add per tap (the reference's convolution goes through a vendor library whose summation is not specified
+// either; inside the tests' 2e-5).
+template <int NK>
+__device__ __forceinline__ void blur_h(const float (&kx)[MAXK], const float* tile, float* hrow, int tst, int hst, int tw, int th) {
+  float k[NK];
+#pragma unroll
+  for (int j = 0; j < NK; ++j) k[j] = kx[j];
+  for (int i = threadIdx.x; i < th * TX; i += 256) {      // th rows x TX columns
+    const int ly = i >> 6, lx = i & (TX - 1);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float* t = tile + ch * tst + ly * tw + lx;
+      float acc = 0.0f;
+#pragma unroll
+      for (int j = 0; j < NK; ++j) acc = __builtin_fmaf(k[j], t[j], acc);
+      hrow[ch * hst + i] = acc;
+    }
+  }
+}
+template <int NK>
+__device__ __forceinline__ void blur_v(const float (&ky)[MAXK], const float* hrow, int hst, int tx, int ty0, float (&v)[4][3]) {
+  float k[NK];
+#pragma unroll
+  for (int j = 0; j < NK; ++j) k[j] = ky[j];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    const float* hc = hrow + ch * hst + ty0 * TX + tx;
+    float w[NK + 3];
+#pragma unroll
+    for (int j = 0; j < NK + 3; ++j) w[j] = hc[j * TX];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {     // output row ty0 + r: taps 0 .. NK-1 of inputs ty0 + r + j, in that order
+      float acc = 0.0f;
+#pragma unroll
+      for (int j = 0; j < NK; ++j) acc = __builtin_fmaf(k[j], w[r + j], acc);
+      v[r][ch] = acc;
+    }
+  }
+}
+#define MVF_BLUR_CASES(F, ...)                                                                                             \
+  switch (nk) {                                                                                                            \
+    case 1: F<1>(__VA_ARGS__); break;   case 3: F<3>(__VA_ARGS__); break;   case 5: F<5>(__VA_ARGS__); break;              \
+    case 7: F<7>(__VA_ARGS__); break;   case 9: F<9>(__VA_ARGS__); break;   case 11: F<11>(__VA_ARGS__); break;            \
+    case 13: F<13>(__VA_ARGS__); break; default: F<15>(__VA_ARGS__); break;                                                \
+  }
+__device__ __forceinline__ void blur_h_dispatch(const ClipParams& c, const float* tile, float* hrow, int tst, int hst, int tw, int th) {
+  const int nk = c.nkx;     // odd, <= MAXK (validated on the host)
+  MVF_BLUR_CASES(blur_h, c.kx, tile, hrow, tst, hst, tw, th)
+}
+__device__ __forceinline__ void blur_v_dispatch(const ClipParams& c, const float* hrow, int hst, int tx, int ty0, float (&v)[4][3]) {
+  const int nk = c.nky;
+  MVF_BLUR_CASES(blur_v, c.ky, hrow, hst, tx, ty0, v)
+}
+
 // K2: per-frame mean from K1's partials (fixed order), contrast + the remaining colour steps applied while the tile
 // (with its blur halo, reflect-padded) is loaded into LDS, Gaussian as a horizontal then a vertical pass over LDS,
 // grayscale, normalisation.  64 x 16 outputs per workgroup, four per thread (a column of four rows: the vertical pass
@@ -154,73 +228,69 @@ __global__ __launch_bounds__(256) void finish_kernel(AugArgs a) {
   float* const hrow = dyn_lds + 3 * a.tile_stride;
   const int tst = a.tile_stride, hst = a.hrow_stride;
   __shared__ float red[4];
-  __shared__ float smean;
-  float mean = 0.0f;
-  if (c.contrast_at >= 0) {                   // block-uniform
+  __shared__ int colmap[TX + MAXK - 1], rowoff[TY + MAXK - 1];
+  const bool post = c.contrast_at >= 0;       // block-uniform
+  float ps = 0.0f, ps_more = 0.0f;
+  if (post) {                                 // K1's gray partial sums of this frame: in flight under the tile loads
     const float* pp = a.partial + (size_t)ft * a.NB;
-    float s = 0.0f;
-    for (int i = threadIdx.x; i < a.NB; i += 256) s += pp[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) smean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(S * S);
-    __syncthreads();
-    mean = smean;
+    if ((int)threadIdx.x < a.NB) ps = pp[threadIdx.x];
+    for (int i = threadIdx.x + 256; i < a.NB; i += 256) ps_more += pp[i];     // (S > 512 only)
   }
   const int hx = c.blur ? c.nkx >> 1 : 0, hy = c.blur ? c.nky >> 1 : 0;
   const int tw = TX + 2 * hx, th = TY + 2 * hy;
   const float* ib = a.buf + (size_t)ft * 3 * S * S;
+  // source column / row offset of every tile column / row, once per workgroup.  Reflect, then clamp: positions beyond the
+  // edge of a partial tile only feed pixels that are not stored
+  if ((int)threadIdx.x < tw) colmap[threadIdx.x] = min(max(reflect(blockIdx.x * TX + (int)threadIdx.x - hx, S), 0), S - 1);
+  if (threadIdx.x >= 128 && (int)threadIdx.x - 128 < th)
+    rowoff[threadIdx.x - 128] = min(max(reflect(blockIdx.y * TY + (int)threadIdx.x - 128 - hy, S), 0), S - 1) * S;
+  __syncthreads();
   {
     // i = ly * tw + lx walked with stride 256 without a division per element
     const int qstep = 256 / tw, rstep = 256 - qstep * tw;
     int ly = threadIdx.x / tw, lx = threadIdx.x - ly * tw;
-    const bool post = c.contrast_at >= 0;
-    const float cf = post ? c.fac[c.contrast_at] : 1.0f;
-    for (int i = threadIdx.x; i < tw * th; i += 256) {
-      // reflect, then clamp: positions beyond the edge of a partial tile only feed pixels that are not stored
-      const int gy = min(max(reflect(blockIdx.y * TY + ly - hy, S), 0), S - 1);
-      const int gx = min(max(reflect(blockIdx.x * TX + lx - hx, S), 0), S - 1);
-      const float* p = ib + (size_t)gy * S + gx;
-      float r = p[0], g = p[(size_t)S * S], b = p[(size_t)2 * S * S];
-      if (post) {
-        r = blend(r, mean, cf); g = blend(g, mean, cf); b = blend(b, mean, cf);
-        for (int k = c.contrast_at + 1; k < c.n_color; ++k) point_op(c.op[k], c.fac[k], r, g, b);
+    const ColorSteps cs(c);
+    const int clo = c.contrast_at + 1, chi = c.n_color;
+    float cf = 1.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cf = (k == c.contrast_at) ? cs.fac[k] : cf;
+    // all of a thread's loads first (up to MAXIT x 3 in flight) straight into the LDS tile, then -- a rolled loop, one copy of
+    // the colour code -- contrast and the later colour steps on the thread's own elements in place
+    constexpr int MAXIT = ((TY + MAXK - 1) * (TX + MAXK - 1) + 255) / 256;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int i = threadIdx.x + it * 256;
+      if (i < tw * th) {
+        const float* p = ib + rowoff[ly] + colmap[lx];
+        tile[i] = p[0]; tile[tst + i] = p[(size_t)S * S]; tile[2 * tst + i] = p[(size_t)2 * S * S];
       }
-      tile[i] = r; tile[tst + i] = g; tile[2 * tst + i] = b;
       lx += rstep; ly += qstep;
       if (lx >= tw) { lx -= tw; ++ly; }
+    }
+    if (post) {
+      // per-frame mean, fixed order (deterministic): every thread forms it from the four wave sums itself
+      ps += ps_more;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ps += __shfl_xor(ps, o, 64);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ps;
+      __syncthreads();
+      const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(S * S);
+#pragma unroll 1
+      for (int i = threadIdx.x; i < tw * th; i += 256) {
+        float r = tile[i], g = tile[tst + i], b = tile[2 * tst + i];
+        r = blend(r, mean, cf); g = blend(g, mean, cf); b = blend(b, mean, cf);
+        cs.run(clo, chi, r, g, b);
+        tile[i] = r; tile[tst + i] = g; tile[2 * tst + i] = b;
+      }
     }
   }
   __syncthreads();
   const int tx = threadIdx.x & (TX - 1), ty0 = (threadIdx.x >> 6) * 4;
   float v[4][3];
   if (c.blur) {
-    for (int i = threadIdx.x; i < th * TX; i += 256) {      // horizontal pass: th rows x TX columns
-      const int ly = i >> 6, lx = i & (TX - 1);
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        float acc = 0.0f;
-        for (int k = 0; k < c.nkx; ++k) acc += c.kx[k] * tile[ch * tst + ly * tw + lx + k];
-        hrow[ch * hst + i] = acc;
-      }
-    }
+    blur_h_dispatch(c, tile, hrow, tst, hst, tw, th);
     __syncthreads();
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-      // rows ty0 .. ty0 + 3: output r takes taps k = 0 .. nky - 1 of inputs ty0 + r + k, in that order
-      const float* hc = hrow + ch * hst + tx;
-      float w0 = hc[(ty0 + 0) * TX], w1 = hc[(ty0 + 1) * TX], w2 = hc[(ty0 + 2) * TX];
-      for (int k = 0; k < c.nky; ++k) {
-        const float w3 = hc[(ty0 + 3 + k) * TX];
-        const float kk = c.ky[k];
-        acc[0] += kk * w0; acc[1] += kk * w1; acc[2] += kk * w2; acc[3] += kk * w3;
-        w0 = w1; w1 = w2; w2 = w3;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r][ch] = acc[r];
-    }
+    blur_v_dispatch(c, hrow, hst, tx, ty0, v);
   } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r)

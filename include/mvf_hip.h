@@ -325,6 +325,10 @@ int mvf_lstp_fused_fwd(const void* const* taps, int n_taps, int dtype, int D, in
                        int per_frame, float inv_sqrt_d, float* P, float* pooled, hipStream_t stream);
 int mvf_lstp_fused_bwd(const void* const* taps, int n_taps, int dtype, int D, int F, int N, int T, int nq, const float* dpooled,
                        const float* P, const float* pooled, float inv_sqrt_d, float* G, hipStream_t stream);
+/* bf16 taps run the two products on the matrix cores (csrc/lstp_mfma.hip: token tiles of 16 staged once in LDS, the small fp32
+ * operands as bf16 hi + lo pairs) where the shape has an instantiation (1 or 3 taps, D = 768 | 1024, nq <= 3).  form = 1 pins the
+ * VALU kernels (tests, A/B measurements), 0 restores the automatic choice. */
+int mvf_lstp_select(int form);
 
 /* ------------------------------------------------------------------------------------------------
  * Sequence-contrastive loss (algos/scl.py:52-105), fused forward / backward

@@ -923,31 +923,37 @@ def test_lstp_pool_vs_plain_attention(dtype, nq, disjoint):
         check(pd['cross_att.linear_V2d.bias'].grad, pr['cross_att.linear_V2d.bias'].grad, 10 * tol, 'db_V')
 
 
-@pytest.mark.parametrize('dtype,D,N,nq,per_frame', [('bf16', 768, 196, 3, False), ('bf16', 768, 196, 3, True), ('f32', 384, 49, 2, False),
-                                                    ('bf16', 1024, 576, 2, False), ('bf16', 768, 784, 1, False)])
-def test_lstp_one_pass_equals_three_launch(dtype, D, N, nq, per_frame):
-    """The one-pass pooling (online softmax forward, one-sweep backward) against the scores / softmax / weighted-sum chain on
-    the same taps: pooled output, attention weights P and the query-vector gradient, at the configs' real widths."""
+@pytest.mark.parametrize('dtype,D,N,nq,per_frame,ntap', [('bf16', 768, 196, 3, False, 3), ('bf16', 768, 196, 3, True, 3),
+                                                         ('f32', 384, 49, 2, False, 3), ('bf16', 1024, 576, 2, False, 3),
+                                                         ('bf16', 768, 784, 1, False, 3), ('bf16', 768, 50, 2, True, 1),
+                                                         ('bf16', 1024, 257, 3, False, 1), ('bf16', 768, 7, 1, False, 3)])
+def test_lstp_one_pass_equals_three_launch(dtype, D, N, nq, per_frame, ntap):
+    """The one-pass pooling -- the VALU form (online softmax forward, one-sweep backward) and, for bf16 taps, the matrix-core form
+    (csrc/lstp_mfma.hip) -- against the scores / softmax / weighted-sum chain on the same taps: pooled output, attention weights
+    P and the query-vector gradient, at the configs' real widths, ragged last token tiles included."""
     code, tdt = ops._dt(dtype)
-    Bc, T, ntap = 2, 4, 3
-    F, C = Bc * T, 3 * D
+    Bc, T = 2, 4
+    F, C = Bc * T, ntap * D
     g = gen(61)
     taps = [(0.7 * torch.randn(F * N, D, generator=g)).to(DEV).to(tdt) for _ in range(ntap)]
     vec0 = 0.05 * torch.randn(*((Bc, nq, T, C) if per_frame else (nq, C)), generator=g)
     gy = torch.randn(Bc, nq, T, C, generator=g).to(DEV)
-    res = []
-    for one_pass in (False, True):
+    res = {}
+    for name, one_pass, form in (('chain', False, 0), ('valu', True, 1), ('mfma', True, 0)):
         ops.LSTP_ONE_PASS = one_pass
+        _lib.call('mvf_lstp_select', form)
         try:
             vec = vec0.clone().to(DEV).requires_grad_(True)
             holder = {}
             pooled, _rs = ops.lstp_pool(vec, taps, F, N, T, nq, 384, holder=holder)
             (pooled * gy).sum().backward()
-            res.append((pooled.detach().clone(), holder['attn'].clone(), vec.grad.clone()))
+            res[name] = (pooled.detach().clone(), holder['attn'].clone(), vec.grad.clone())
         finally:
             ops.LSTP_ONE_PASS = True
-    for name, a, b, tol in (('pooled', res[1][0], res[0][0], 2e-5), ('P', res[1][1], res[0][1], 2e-5), ('dvec', res[1][2], res[0][2], 1e-4)):
-        check(a, b, tol, 'one-pass lstp ' + name)
+            _lib.call('mvf_lstp_select', 0)
+    for form in ('valu', 'mfma'):
+        for k, (name, tol) in enumerate((('pooled', 2e-5), ('P', 2e-5), ('dvec', 1e-4))):
+            check(res[form][k], res['chain'][k], tol, 'one-pass lstp (%s) %s' % (form, name))
 
 
 @pytest.mark.parametrize('nq,disjoint,per_frame', [(3, False, False), (2, True, False), (3, False, True)])

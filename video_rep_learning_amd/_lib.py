@@ -82,6 +82,7 @@ SIGNATURES = {
     'mvf_tattn_bwd': 'ppippppiiiip',
     'mvf_lstp_fused_fwd': 'piiiiiiipifppp',
     'mvf_lstp_fused_bwd': 'piiiiiiipppfpp',
+    'mvf_lstp_select': 'i',
     'mvf_lstp_scores': 'piiiiiiipipp',
     'mvf_lstp_wsum': 'piiiiiiippp',
     'mvf_lstp_softmax_fwd': 'ppppiiifip',

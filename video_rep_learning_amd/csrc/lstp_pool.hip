@@ -16,6 +16,7 @@
 // (rows already in the (clip, entity, frame) order the temporal encoder wants).
 #include "common.h"
 #include "mvf_hip_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -729,6 +730,19 @@ extern "C" int mvf_lstp_reduce_frames(const float* G, float* out, int Bc, int nq
 // One-pass pooling forward (see the kernel comment): pooled [Bc, nq, T, C] and P [F, nq, N] in one read of the taps.
 // MVF_ERR_UNSUPPORTED when the shape is outside the kernel's register budget (nq > 3, more than 3 taps, D > 1024): the caller
 // then runs the three-launch form (scores / softmax / weighted sum).
+// (lstp_mfma.hip) the matrix-core form for bf16 taps; MVF_ERR_UNSUPPORTED where it has no instantiation
+int mvf_lstp_mfma_impl(bool bwd, const void* const* taps, int n_taps, int D, int F, int N, int T, int nq, const float* vec,
+                       int per_frame, float inv_sqrt_d, float* P, float* pooled, float* G, hipStream_t st);
+static int g_lstp_form = [] { const char* e = getenv("MVF_LSTP_FORM"); return e ? atoi(e) : 0; }();
+
+// which one-pass kernel mvf_lstp_fused_fwd / _bwd run (tests, A/B measurements): 0 = matrix-core form for bf16 taps where it has
+// an instantiation, else the VALU form; 1 = always the VALU form
+extern "C" int mvf_lstp_select(int form) {
+  MVF_CHECK_ARG(form == 0 || form == 1);
+  g_lstp_form = form;
+  return MVF_OK;
+}
+
 extern "C" int mvf_lstp_fused_fwd(const void* const* taps, int n_taps, int dtype, int D, int F, int N, int T, int nq,
                                   const float* vec, int per_frame, float inv_sqrt_d, float* P, float* pooled,
                                   hipStream_t st) {
@@ -736,6 +750,10 @@ extern "C" int mvf_lstp_fused_fwd(const void* const* taps, int n_taps, int dtype
   const int rc = fused_fill(a, taps, n_taps, dtype, D, F, N, T, nq);
   if (rc != MVF_OK) return rc;
   MVF_CHECK_ARG(vec && P && pooled);
+  if (dtype == MVF_BF16 && g_lstp_form == 0) {
+    const int r2 = mvf_lstp_mfma_impl(false, taps, n_taps, D, F, N, T, nq, vec, per_frame, inv_sqrt_d, P, pooled, nullptr, st);
+    if (r2 != MVF_ERR_UNSUPPORTED) return r2;
+  }
   a.vec = vec; a.per_frame = per_frame; a.inv_sqrt_d = inv_sqrt_d; a.P = P; a.pooled = pooled;
   return dtype == MVF_BF16 ? fused_pick<false, bf16_t>(a, n_taps, nq, F, st) : fused_pick<false, float>(a, n_taps, nq, F, st);
 }
@@ -749,6 +767,11 @@ extern "C" int mvf_lstp_fused_bwd(const void* const* taps, int n_taps, int dtype
   const int rc = fused_fill(a, taps, n_taps, dtype, D, F, N, T, nq);
   if (rc != MVF_OK) return rc;
   MVF_CHECK_ARG(dpooled && P && pooled && G);
+  if (dtype == MVF_BF16 && g_lstp_form == 0) {
+    const int r2 = mvf_lstp_mfma_impl(true, taps, n_taps, D, F, N, T, nq, dpooled, 1, inv_sqrt_d, const_cast<float*>(P),
+                                      const_cast<float*>(pooled), G, st);
+    if (r2 != MVF_ERR_UNSUPPORTED) return r2;
+  }
   a.vec = dpooled; a.per_frame = 1; a.inv_sqrt_d = inv_sqrt_d; a.P = const_cast<float*>(P); a.pooled = const_cast<float*>(pooled);
   a.G = G;
   return dtype == MVF_BF16 ? fused_pick<true, bf16_t>(a, n_taps, nq, F, st) : fused_pick<true, float>(a, n_taps, nq, F, st);

@@ -954,6 +954,12 @@ def test_lstp_one_pass_equals_three_launch(dtype, D, N, nq, per_frame, ntap):
     for form in ('valu', 'mfma'):
         for k, (name, tol) in enumerate((('pooled', 2e-5), ('P', 2e-5), ('dvec', 1e-4))):
             check(res[form][k], res['chain'][k], tol, 'one-pass lstp (%s) %s' % (form, name))
+    # fixed-order reductions (the eight waves' partial scores, the frame sum): a second run is bitwise the first
+    vec = vec0.clone().to(DEV).requires_grad_(True)
+    holder = {}
+    pooled, _rs = ops.lstp_pool(vec, taps, F, N, T, nq, 384, holder=holder)
+    (pooled * gy).sum().backward()
+    assert torch.equal(pooled.detach(), res['mfma'][0]) and torch.equal(holder['attn'], res['mfma'][1]) and torch.equal(vec.grad, res['mfma'][2])
 
 
 @pytest.mark.parametrize('nq,disjoint,per_frame', [(3, False, False), (2, True, False), (3, False, True)])

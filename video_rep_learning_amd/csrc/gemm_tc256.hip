@@ -655,7 +655,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
 #undef KSTAMP
 }
 
-int g_cu_budget = 0;   // > 0: CUs the caller's stream may use (CU-masked streams), see mvf_gemm_tc_set_cus
+// > 0: CUs the persistent launch may take, see mvf_gemm_tc_set_cus (MVF_GEMM_CUS: initial value, A/B measurements)
+int g_cu_budget = [] { const char* e = getenv("MVF_GEMM_CUS"); return e ? atoi(e) : 0; }();
 
 int num_cus() {
   if (g_cu_budget > 0) return g_cu_budget;

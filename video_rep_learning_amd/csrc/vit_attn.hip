@@ -380,7 +380,10 @@ __global__ __launch_bounds__(256, OCC) void vit_attn_bf16_pair_kernel(AttnArgs a
   bf16x8_t qf[2][2];
   int qt[2] = {wave, wave + 4};
   load_q(qf, qt);
-  asm volatile("" : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[1][0]), "+v"(qf[1][1]));   // waited for before any DMA is in flight
+  // waited for before any DMA is in flight.  (Round 3: as untracked inline-asm loads that the counted K wait covers -- the Q
+  // round trip then runs under the DMAs' -- 76.4 us against 77-79: the CU's other two workgroups already hide it.  Without any
+  // fence hipcc drains the whole queue, V included, with vmcnt(0) in front of the first MFMA: the DMA loops have run-time trips.)
+  asm volatile("" : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[1][0]), "+v"(qf[1][1]));
   {
     constexpr int NP = KROWS / 8;
     const int prow = lane >> 3, pc = lane & 7;

@@ -34,9 +34,10 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md (no 2:1 sparsity)
 # what a bf16 GEMM K LOOP sustains on random operands under the chip's power management (measured, not a spec figure:
-# profiles/r03/wave4_probe.txt -- the product kernel 1 245, a four-wave loop with the matrix pipe 82 % busy 1 170-1 240 at the
-# 1.36-1.44 GHz the chip then holds).  Reported beside `peak` for context; `frac` stays priced against the nominal peak.
-SUSTAINED_BF16_LOOP_TFLOPS = 1245.0
+# profiles/r03/power_probe.txt -- six seconds of back-to-back 4096^3 launches of the product kernel: 1 475 TFLOP/s at 1 355 W
+# socket power and 1.81 GHz; a four-wave loop with the matrix pipe 82 % busy lands on the same 1 475; all-zero operands: 1 953 at
+# 2.39 GHz / 1 050 W).  Reported beside `peak` for context; `frac` stays priced against the nominal peak.
+SUSTAINED_BF16_LOOP_TFLOPS = 1475.0
 TFLOP_PER_CLIP = 1.1925       # algorithmic work of config #2 per clip (fwd backbone + f/b head)
 PEAK_F32_TFLOPS = 157.3       # fp32-input MFMA (= vector) peak, parity mode
 # (epilogue kind, N, K) of the ViT-B/16 GEMMs; M = frames * 197 (patch-embed: frames * 196)
@@ -396,7 +397,7 @@ def main():
                 'traffic': pmc_traffic(dom['name']), 'kernel': kern, 'launches': dom['launches'],
                 'timing': 'HIP events around each launch on its stream, kernels serialized (1 backbone lane, no lookahead)',
                 'avg_launch_us': dom['avg_us'], 'flop_per_launch': dom['flop'] / max(dom['launches'], 1),
-                **({'sustained_loop_rate': {'tflops': SUSTAINED_BF16_LOOP_TFLOPS, 'source': 'profiles/r03/wave4_probe.txt',
+                **({'sustained_loop_rate': {'tflops': SUSTAINED_BF16_LOOP_TFLOPS, 'source': 'profiles/r03/power_probe.txt',
                                             'all_gemm_frac_of_it': round(tot_fl / (tot_ms * 1e-3) / 1e12 / SUSTAINED_BF16_LOOP_TFLOPS, 4)}}
                    if a.dtype == 'bf16' else {}),
                 'all_gemm': {'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 1), 'frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4),

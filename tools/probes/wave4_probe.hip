@@ -186,6 +186,24 @@ int main(int argc, char** argv) {
   hipMalloc(&dcyc, nwg * 8);
   printf("4 waves x (128 x 128) per 256 x 256 tile, %d workgroups, %d stages of 32 k, operand footprint %zu MiB%s\n", nwg, stages,
          footprint >> 20, mode == 1 ? ", all-zero operands" : mode == 2 ? ", N(0,1) operands" : "");
+  const int sustain = argc > 5 ? atoi(argv[5]) : 0;   // > 0: only the full loop, `sustain` batches of 200 back-to-back launches
+  if (sustain > 0) {
+    auto k = wave4_kernel<true, true, true>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int b = 0; b < sustain; ++b) {
+      hipEventRecord(e0, 0);
+      for (int r = 0; r < 200; ++r) hipLaunchKernelGGL(k, dim3(nwg), dim3(256), NSTAGE * STAGE_BYTES, 0, src, footprint, stages, out, dcyc);
+      hipEventRecord(e1, 0);
+      hipDeviceSynchronize();
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, e0, e1);
+      printf("   %.1f TFLOP/s\n", 2.0 * 256 * 256 * 32 * (double)stages * nwg * 200 / (ms * 1e-3) / 1e12);
+      fflush(stdout);
+    }
+    return 0;
+  }
   run<true, true>("full loop", src, footprint, stages, out, dcyc, nwg);
   run<false, true>("no LDS-DMA", src, footprint, stages, out, dcyc, nwg);
   run<true, false>("no fragment reads", src, footprint, stages, out, dcyc, nwg);

@@ -63,6 +63,10 @@
 //    instead of 29 %), but the cap costs 4 - 19 spilled registers: all GEMMs 10.14 -> 10.68 ms one kernel at a time (+0.54 ms),
 //    step 11.75 -> 12.40 ms on the same box (+0.65 ms): co-execution returned nothing on top of what the spills cost (the guest
 //    wave takes LDS-DMA / VALU issue slots from the SIMD's two GEMM waves).
+//  * tried and rejected (round 3, code removed): an L2 touch-prefetch in the epilogue -- wave 0 reading one dword per 128-byte
+//    line of K tiles 2..5 (or 2..11) of the A rows of the tile AFTER next, whose ticket has just arrived, a tile time ahead of
+//    their staging: qkv 173-178 -> 181-185 (191) us, fc1 254.5 -> 263-265 (277), step 11.00 -> 11.05-11.18 (11.27) ms.  The lines
+//    do not survive a tile time in the XCD's 4 MB L2 next to 32 workgroups' operands and outputs; the touches only add traffic.
 //  * XCD-aware tile walk: workgroups b, b+8, ... share an XCD (round-robin dispatch, speed only); group x = b & 7 owns a
 //    contiguous chunk of the tile list (tiles of one A row-panel are neighbours).  A workgroup's FIRST tile is static
 //    (chunk start + b/8); every further tile is a ticket from the group's counter (a.sched, agent-scope atomic), so a

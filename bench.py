@@ -24,6 +24,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -74,13 +75,14 @@ def tile_rows(M, N, nwg=256):
     return best
 
 
-def rocprof_names(groups, dtype, ln_fold, defer=True, frames=256, tokens=197):
+def rocprof_names(groups, dtype, ln_fold, defer=True, frames=256, tokens=197, nwg=256):
     """The same launches under the kernel names rocprofv3 prints, gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2, BMT>: one
     kernel per epilogue flavour and tile height.  LN = true for the launches that carry the LN-fold extras: of a shape's 12
     launches per forward, 11 in fold mode 2 for qkv (blocks 1..11 consume the folded norm1) and for fc2 (blocks 0..10 produce
     bf16(x) + the row sums); 12 for fc1 / proj in the modes that fold norm2.  ADD2 = true for fc2 when the attention branch's
     residual add is deferred (then proj is a plain store, <0, ...>).  BMT = the tile rows the launch picks for the shape in the
-    one-lane mode these times are taken in.  Averages are per shape group (HIP events cannot tell two names of one shape apart)."""
+    one-lane mode these times are taken in, for `nwg` workgroups per persistent launch (mvf_gemm_tc_get_wgs: 256, or 248 under the
+    collectives' CU reserve).  Averages are per shape group (HIP events cannot tell two names of one shape apart)."""
     by = {}
     for r in groups:
         e = r['epi']
@@ -95,7 +97,7 @@ def rocprof_names(groups, dtype, ln_fold, defer=True, frames=256, tokens=197):
             if (fc1 or proj) and ln_fold in (1, 3):
                 frac = 1.0
             add2 = 'true' if (fc2 and defer and ln_fold in (0, 2)) else 'false'
-            bm = tile_rows(frames * (tokens - 1 if e == 3 else tokens), r['n'])
+            bm = tile_rows(frames * (tokens - 1 if e == 3 else tokens), r['n'], nwg)
             parts = [('gemm_tc256_kernel<%d, false, true, false, 0, %s, %d>' % (e, add2, bm), frac),
                      ('gemm_tc256_kernel<%d, false, false, false, 0, %s, %d>' % (e, add2, bm), 1.0 - frac)]
         for k, f in parts:
@@ -107,6 +109,14 @@ def rocprof_names(groups, dtype, ln_fold, defer=True, frames=256, tokens=197):
 
 
 GEMM_SOURCES = ('gemm_tc256.hip', 'gemm_tc_epi.h')
+
+
+def gemm_wgs():
+    """workgroups of a persistent GEMM launch as the library will size it now (CU budget included)"""
+    from video_rep_learning_amd import _lib
+    n = ctypes.c_int(0)
+    _lib.call('mvf_gemm_tc_get_wgs', ctypes.byref(n))
+    return n.value
 
 
 def gemm_source_sha():
@@ -140,6 +150,30 @@ def pmc_traffic(name):
         return None
 
 
+STAGE = {'name': 'start'}
+
+
+def stage(name):
+    STAGE['name'] = name
+
+
+def start_init_watchdog(rank, seconds):
+    """A rank that has not finished its first step `seconds` after main() started (a peer that never arrived at the
+    rendezvous, a collective that hangs on first use) ends the run with exit code 4 and names the stage it was in, instead of
+    hanging until the driver's own limit.  Returns the event that disarms it."""
+    done = threading.Event()
+    if seconds <= 0:
+        return done
+
+    def run():
+        if not done.wait(seconds):
+            print('bench.py rank %d: no progress %d s after start, last stage: %s -- giving up (exit 4)'
+                  % (rank, seconds, STAGE['name']), file=sys.stderr, flush=True)
+            os._exit(4)
+    threading.Thread(target=run, daemon=True).start()
+    return done
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
@@ -155,6 +189,17 @@ def parse():
                    help='one kernel at a time for the whole run (one backbone lane, no lookahead): the mode the roofline '
                         'section is always timed in; use it under rocprofv3 --kernel-trace --stats so that the per-kernel '
                         'averages there are the ones of roofline.rocprof_kernels')
+    p.add_argument('--init-timeout', type=int, default=120,
+                   help='seconds a rank may take from start to the end of its first step before it exits with code 4 and its '
+                        'last stage on stderr (0 = no limit)')
+    p.add_argument('--test-hooks', action='store_true',
+                   help='honour the MVF_BENCH_BACKEND / MVF_BENCH_SHARE_GPU environment hooks (tests only: two ranks on the one '
+                        'GPU of a test box over gloo); without this flag their presence is an error, so that a stray variable '
+                        'cannot turn an RCCL measurement into a gloo one')
+    p.add_argument('--plumbing', action='store_true',
+                   help='no GPU, no kernels, no measurement (needs --test-hooks and MVF_BENCH_BACKEND=gloo): rank handling, process '
+                        'group, model / optimizer / gradient-bucket construction on the CPU and one gradient all-reduce, then the '
+                        'JSON line with value null -- what tests/test_bench_launch.py checks of the N > 1 path without a device')
     return p.parse_args()
 
 
@@ -270,6 +315,46 @@ def launch_ranks(a):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def plumbing(a, world, rank, first_step_done):
+    """bench.py's N > 1 control flow without a device: gloo process group, the benchmark's model / optimizer / gradient buckets
+    built on the CPU, ONE bucketed gradient all-reduce through GradReducer (the collectives of a step's tail), the barrier +
+    max-over-ranks reduction of the timing, and rank 0's JSON line with `value` null.  No kernel runs and nothing is measured."""
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29511')
+    stage('init_process_group(gloo) rendezvous at %s:%s' % (os.environ['MASTER_ADDR'], os.environ['MASTER_PORT']))
+    dist.init_process_group('gloo', init_method='env://', world_size=world, rank=rank)
+    from video_rep_learning_amd.utils import presets
+    from video_rep_learning_amd.utils.optimizer import construct_optimizer
+    from video_rep_learning_amd.models import build_model
+    from video_rep_learning_amd.train import DataParallelModel
+    stage('build_model (cpu)')
+    cfg = presets.baseline_config_2(compute_dtype=a.dtype)
+    torch.manual_seed(cfg.RNG_SEED)
+    model = build_model(cfg, -1)
+    wrapped = DataParallelModel(model)
+    opt = construct_optimizer(wrapped, cfg)
+    stage('gradient all-reduce (gloo)')
+    red = opt.reducer
+    opt.flat.flat_g.fill_(float(rank + 1))
+    scale = red.finish()
+    expect = sum(range(1, world + 1))
+    assert bool((opt.flat.flat_g == expect).all()) and abs(scale * dist.get_world_size() - 1.0) < 1e-12
+    first_step_done.set()
+    tmax = torch.tensor([float(rank)], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    if rank == 0:
+        ws = dist.get_world_size()
+        print(json.dumps({'metric': 'video-clips/sec/node, ViT-B/16 32-frame MV-Former', 'value': None, 'unit': 'clips/s',
+                          'n_gpus': ws, 'plumbing': True, 'data': 'none (no kernel ran)',
+                          'config': {'backend': dist.get_backend(), 'world_size_seen': ws, 'parallelism': 'dp%d' % ws,
+                                     'max_rank_seen': int(tmax.item()),
+                                     'comm': {'allreduce_bytes_per_step': red.bytes_per_step(), 'buckets': len(red.buckets),
+                                              'exposed_allreduce_ms_per_step': None}}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     a = parse()
     if a.serial:
@@ -282,18 +367,36 @@ def main():
                          'bare and let it start the ranks)' % (a.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    first_step_done = start_init_watchdog(rank, a.init_timeout)
+    # test hooks (tests/test_gpu_bench.py runs two ranks on the ONE GPU of a test box, where RCCL refuses duplicate
+    # devices): MVF_BENCH_SHARE_GPU=1 puts every rank on device 0, MVF_BENCH_BACKEND=gloo swaps the process group.
+    # Only with --test-hooks: a measurement must never change its interconnect because of a leftover variable.
+    hooks = [k for k in ('MVF_BENCH_BACKEND', 'MVF_BENCH_SHARE_GPU') if k in os.environ]
+    if hooks and not a.test_hooks:
+        raise SystemExit('bench.py: %s set in the environment without --test-hooks: refusing to run (these hooks swap RCCL for '
+                         'gloo / stack the ranks on one GPU; they are for tests/ only)' % ', '.join(hooks))
+    backend = os.environ.get('MVF_BENCH_BACKEND', 'nccl') if a.test_hooks else 'nccl'
+    if a.plumbing:
+        if not a.test_hooks or backend != 'gloo':
+            raise SystemExit('bench.py --plumbing needs --test-hooks and MVF_BENCH_BACKEND=gloo (it measures nothing)')
+        return plumbing(a, world, rank, first_step_done)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
-    # test hooks (tests/test_gpu_bench.py runs two ranks on the ONE GPU of a test box, where RCCL refuses duplicate
-    # devices): MVF_BENCH_SHARE_GPU=1 puts every rank on device 0, MVF_BENCH_BACKEND=gloo swaps the process group
-    if os.environ.get('MVF_BENCH_SHARE_GPU') == '1':
+    if a.test_hooks and os.environ.get('MVF_BENCH_SHARE_GPU') == '1':
         local = 0
+    stage('set_device %d' % local)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1 or os.environ.get('MVF_FORCE_REDUCER') == '1':
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group(os.environ.get('MVF_BENCH_BACKEND', 'nccl'), init_method='env://', world_size=world, rank=rank)
+        stage('init_process_group(%s) rendezvous at %s:%s' % (backend, os.environ['MASTER_ADDR'], os.environ['MASTER_PORT']))
+        dist.init_process_group(backend, init_method='env://', world_size=world, rank=rank)
+        # what the process group itself says, not what the environment asked for
+        if dist.get_world_size() != world:
+            raise SystemExit('bench.py: process group has %d ranks, WORLD_SIZE=%d' % (dist.get_world_size(), world))
+    backend_seen = dist.get_backend() if dist.is_initialized() else None
+    world_seen = dist.get_world_size() if dist.is_initialized() else 1
 
     from video_rep_learning_amd import _lib
     from video_rep_learning_amd.utils import presets
@@ -308,6 +411,7 @@ def main():
         ops.VIT_LANE_MIN_ROWS = 1 << 62
     cfg = presets.baseline_config_2(compute_dtype=a.dtype)     # penn_mvf.yml + ViT-B/16, T=32, B=4 (dropout 0.1 kept)
     torch.manual_seed(cfg.RNG_SEED)
+    stage('build_model')
     model = build_model(cfg, local).to(dev)
     from video_rep_learning_amd.utils import distributed as du
     gemm_cus = 0
@@ -344,16 +448,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    stage('first step (kernel library load, first collectives)')
     if not a.no_lookahead:
         wrapped.prefetch(videos)     # prime the pipeline: step k's head reads the forward launched in step k-1
-    for _ in range(a.warmup):
+    for i in range(a.warmup):
         step()
+        if i == 0:
+            torch.cuda.synchronize()
+            first_step_done.set()
+            stage('warm-up')
     fence()
+    first_step_done.set()
+    stage('timed region')
+    reducer = getattr(opt, 'reducer', None)
+    if reducer is not None and reducer.active:
+        reducer.exposed, reducer.timing = [], True
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    comm = None
+    if reducer is not None and reducer.active:
+        reducer.timing = False
+        # the gradient all-reduce as the process group ran it: payload per step and the time the compute stream spent waiting
+        # for it between the last backward kernel and the optimizer (device events; what backward did not hide)
+        comm = {'allreduce_bytes_per_step': reducer.bytes_per_step(), 'buckets': len(reducer.buckets),
+                'exposed_allreduce_ms_per_step': None if (ex := reducer.exposed_ms()) is None else round(ex, 4)}
+    stage('roofline steps')
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -406,24 +528,27 @@ def main():
                               for r in groups},
                 # the same launches under the names rocprofv3 prints: one kernel per epilogue, so proj and fc2 (and
                 # nothing else) share `gemm_tc256_kernel<2, false>`; compare with `bench.py --serial` under rocprofv3
-                'rocprof_kernels': rocprof_names(groups, a.dtype, ops.VIT_LN_FOLD, os.environ.get('MVF_PROJ_DEFER', '1') != '0'),
+                'rocprof_kernels': rocprof_names(groups, a.dtype, ops.VIT_LN_FOLD, os.environ.get('MVF_PROJ_DEFER', '1') != '0', nwg=gemm_wgs()),
                 'ln_fold': {0: 'off', 1: 'norm1 (blocks 1..) and norm2 folded into qkv / fc1', 2: 'norm1 of blocks 1.. folded into the qkv GEMM (default)', 3: 'norm2 folded into fc1'}[ops.VIT_LN_FOLD]}
     if world > 1:
         dist.barrier()
 
     if rank == 0:
-        clips = world * cfg.TRAIN.BATCH_SIZE * 2 * a.steps
+        clips = world_seen * cfg.TRAIN.BATCH_SIZE * 2 * a.steps
         value = clips / dt
         out = {
             'metric': 'video-clips/sec/node, ViT-B/16 32-frame MV-Former', 'value': round(value, 2), 'unit': 'clips/s',
-            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
+            'n_gpus': world_seen, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: PennAction MV-Former (penn_mvf.yml + ViT-B/16), 32 frames, '
                                    'batch 4/GPU = 8 clips/GPU/step, full train step (frozen backbone fwd, head fwd+bwd, SCL, '
-                                   'grad all-reduce, clip+Adam), dropout 0.1', 'global_batch': 4 * world, 'frames': 32,
-                       'parallelism': 'dp%d' % world, 'frames_per_sec': round(value * 32, 1), 'samples_per_sec': round(value / 2, 2),
-                       'step_tflops_algorithmic': round(value / world * TFLOP_PER_CLIP, 1), 'last_loss': round(last_loss, 4),
-                       'gemm_cu_budget': gemm_cus or 'all'},
+                                   'grad all-reduce, clip+Adam), dropout 0.1', 'global_batch': 4 * world_seen, 'frames': 32,
+                       'parallelism': 'dp%d' % world_seen, 'frames_per_sec': round(value * 32, 1), 'samples_per_sec': round(value / 2, 2),
+                       'step_tflops_algorithmic': round(value / world_seen * TFLOP_PER_CLIP, 1), 'last_loss': round(last_loss, 4),
+                       'gemm_cu_budget': gemm_cus or 'all',
+                       # the process group as it actually ran (None / 1: no group): never the environment's word for it
+                       'backend': backend_seen, 'world_size_seen': world_seen,
+                       **({'comm': comm} if comm is not None else {})},
             'roofline': roof,
         }
         parity_ok = True

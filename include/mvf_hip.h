@@ -319,8 +319,9 @@ int mvf_lstp_dx(float* const* dx_host, int n_taps, int D, int F, int N, int T, i
  * forward (online softmax over a frame's tokens: pooled [Bc, nq, T, C] and the normalised weights P [F, nq, N] =
  * LSTPCrossAtt.attn_matrix, mvformer.py:409-411) and once backward (G [Bc, nq, T, C] = d loss / d vec per frame, from dpooled,
  * P and the forward's pooled: sum_n dS_jn x_n = c (sum_n P_jn g_jn x_n - gbar_j pooled_j), g_jn = dpooled_j . x_n).
- * MVF_ERR_UNSUPPORTED outside the kernels' register budget (nq > 3, more than 3 taps, D > 1024 or D % 8 != 0): the caller then
- * runs the mvf_lstp_scores / _softmax_fwd / _wsum chain. */
+ * MVF_ERR_UNSUPPORTED outside the kernels' register budget (nq > 3, more than 3 taps, D > 1024 or D % 8 != 0; fp32 taps, or
+ * form 1, also 3 queries on 3 taps of 1024 channels -- that shape exists in the matrix-core form only): the caller then runs the
+ * mvf_lstp_scores / _softmax_fwd / _wsum chain. */
 int mvf_lstp_fused_fwd(const void* const* taps, int n_taps, int dtype, int D, int F, int N, int T, int nq, const float* vec,
                        int per_frame, float inv_sqrt_d, float* P, float* pooled, hipStream_t stream);
 int mvf_lstp_fused_bwd(const void* const* taps, int n_taps, int dtype, int D, int F, int N, int T, int nq, const float* dpooled,

@@ -26,6 +26,7 @@ def test_bench_single_process_contract():
                         '--no-cpu-baseline'], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _line(r.stdout)
+    assert j['config']['backend'] is None and j['config']['world_size_seen'] == 1 and 'comm' not in j['config']
     assert KEYS <= set(j) and j['n_gpus'] == 1 and j['steps'] == 3 and j['warmup'] == 2 and j['vs_baseline'] is None
     assert j['higher_is_better'] is True and j['scaling'] == 'weak' and j['unit'] == 'clips/s' and j['value'] > 0
     rf = j['roofline']
@@ -40,12 +41,15 @@ def test_bench_two_ranks_do_not_deadlock():
     env = dict(os.environ, MVF_BENCH_SHARE_GPU='1', MVF_BENCH_BACKEND='gloo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2',
-           '--profile-steps', '1']
+           '--profile-steps', '1', '--test-hooks']
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     j = _line(r.stdout)
-    assert j['n_gpus'] == 2 and j['config']['parallelism'] == 'dp2' and j['value'] > 0
-    assert 'cpu_baseline' not in j or j['cpu_baseline'] is None or True     # N > 1: no CPU leg is required
+    c = j['config']
+    assert j['n_gpus'] == 2 and c['parallelism'] == 'dp2' and j['value'] > 0
+    # the line says what the process group WAS, and what the gradient all-reduce moved / cost the compute stream
+    assert c['backend'] == 'gloo' and c['world_size_seen'] == 2
+    assert 18e6 < c['comm']['allreduce_bytes_per_step'] < 21e6 and c['comm']['exposed_allreduce_ms_per_step'] >= 0.0
 
 
 def test_bench_forced_one_rank_rccl_group_reserves_cus_for_the_collectives():
@@ -62,6 +66,8 @@ def test_bench_forced_one_rank_rccl_group_reserves_cus_for_the_collectives():
     import torch
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     assert j['n_gpus'] == 1 and j['config']['gemm_cu_budget'] == cus - 8 and j['value'] > 0
+    assert j['config']['backend'] == 'nccl' and j['config']['world_size_seen'] == 1
+    assert j['config']['comm']['allreduce_bytes_per_step'] > 18e6
 
 
 def _device_count():
@@ -78,4 +84,6 @@ def test_bench_gpus_2_bare_over_rccl():
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     j = _line(r.stdout)
     assert j['n_gpus'] == 2 and j['config']['parallelism'] == 'dp2' and j['value'] > 0
+    assert j['config']['backend'] == 'nccl' and j['config']['world_size_seen'] == 2
+    assert j['config']['comm']['exposed_allreduce_ms_per_step'] is not None
     assert isinstance(j['config']['gemm_cu_budget'], int)

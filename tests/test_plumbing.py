@@ -32,11 +32,13 @@ def test_config0_plumbing_on_cpu_gloo(tmp_path, monkeypatch):
     assert out['plumbing'] is True
     assert 'cpu' in out['stopped_at'] and 'no CPU fallback' in out['stopped_at'] or 'gfx950' in out['stopped_at'], out
     assert not torch.distributed.is_initialized()
-    # what the run left behind: the stored config and one checkpoint in the reference's naming and layout
+    # what the run left behind: the stored config -- and NO checkpoint: the round trip (reference naming and layout) happens in
+    # a scratch directory that is removed, so that a LOGDIR holding checkpoint E never gains an "E + 1" with epoch-E weights
     assert os.path.exists(tmp_path / 'log' / 'config.yml')
-    ck = torch.load(tmp_path / 'log' / 'checkpoints' / 'checkpoint_epoch_00000.pth', map_location='cpu', weights_only=False)
-    assert set(ck) == {'epoch', 'model_state', 'optimizer_state', 'cfg'} and ck['epoch'] == 0
-    assert any(k.startswith('embed.') for k in ck['model_state']) and any(k.startswith('backbone.') for k in ck['model_state'])
+    ck = out['checkpoint']
+    assert ck['file'] == 'checkpoint_epoch_00000.pth' and set(ck['keys']) == {'epoch', 'model_state', 'optimizer_state', 'cfg'}
+    assert ck['epoch'] == 0 and {'embed', 'backbone'} <= set(ck['model_prefixes'])
+    assert not os.path.exists(tmp_path / 'log' / 'plumbing_scratch') and not os.path.exists(tmp_path / 'log' / 'checkpoints')
 
 
 def test_plumbing_flag_is_not_a_cpu_training_mode(tmp_path, monkeypatch):

@@ -555,9 +555,12 @@ int fused_pick(const FusedArgs& a, int n_taps, int nq, int F, hipStream_t st) {
   }
 }
 
+// argument checks common to both one-pass forms; the VALU form's own shape limits (fused_supported) are applied by the entry
+// points only AFTER the matrix-core form has had its turn -- 3 queries on 3 taps of 1024 channels (ViT-L, BASELINE configs[4])
+// exist only there
 int fused_fill(FusedArgs& a, const void* const* taps, int n_taps, int dtype, int D, int F, int N, int T, int nq) {
   MVF_CHECK_ARG(taps && F > 0 && N > 0 && T > 0 && F % T == 0 && (dtype == MVF_F32 || dtype == MVF_BF16));
-  if (!fused_supported(n_taps, D, N, nq)) return MVF_ERR_UNSUPPORTED;
+  if (n_taps < 1 || n_taps > 3 || nq < 1) return MVF_ERR_UNSUPPORTED;
   for (int i = 0; i < n_taps; ++i) {
     MVF_CHECK_ARG(taps[i] && ((uintptr_t)taps[i] & 15) == 0);
     a.taps[i] = taps[i];
@@ -754,6 +757,7 @@ extern "C" int mvf_lstp_fused_fwd(const void* const* taps, int n_taps, int dtype
     const int r2 = mvf_lstp_mfma_impl(false, taps, n_taps, D, F, N, T, nq, vec, per_frame, inv_sqrt_d, P, pooled, nullptr, st);
     if (r2 != MVF_ERR_UNSUPPORTED) return r2;
   }
+  if (!fused_supported(n_taps, D, N, nq)) return MVF_ERR_UNSUPPORTED;
   a.vec = vec; a.per_frame = per_frame; a.inv_sqrt_d = inv_sqrt_d; a.P = P; a.pooled = pooled;
   return dtype == MVF_BF16 ? fused_pick<false, bf16_t>(a, n_taps, nq, F, st) : fused_pick<false, float>(a, n_taps, nq, F, st);
 }
@@ -772,6 +776,7 @@ extern "C" int mvf_lstp_fused_bwd(const void* const* taps, int n_taps, int dtype
                                       const_cast<float*>(pooled), G, st);
     if (r2 != MVF_ERR_UNSUPPORTED) return r2;
   }
+  if (!fused_supported(n_taps, D, N, nq)) return MVF_ERR_UNSUPPORTED;
   a.vec = dpooled; a.per_frame = 1; a.inv_sqrt_d = inv_sqrt_d; a.P = const_cast<float*>(P); a.pooled = const_cast<float*>(pooled);
   a.G = G;
   return dtype == MVF_BF16 ? fused_pick<true, bf16_t>(a, n_taps, nq, F, st) : fused_pick<true, float>(a, n_taps, nq, F, st);

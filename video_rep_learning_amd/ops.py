@@ -60,7 +60,14 @@ def grad_ready(*params):
     """Tells the gradient reducer (if any) that these parameters' slots are final -- what the post-accumulate-grad hook
     does for gradients that travel through autograd."""
     for p in params:
-        cb = getattr(p, '_mvf_ready', None) if p is not None else None
+        if p is None:
+            continue
+        # runs at BACKWARD time, right after a kernel wrote the slot: forward -> zero_grad() -> backward -> (no step) ->
+        # zero_grad() must find the buffer dirty (grad_slot() marked it at forward time only)
+        flat = getattr(p, '_mvf_flat', None)
+        if flat is not None:
+            flat.dirty = True
+        cb = getattr(p, '_mvf_ready', None)
         if cb is not None:
             cb(p)
 

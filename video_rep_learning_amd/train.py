@@ -20,6 +20,7 @@ import json
 import os
 import pprint
 import random
+import shutil
 import time
 
 import numpy as np
@@ -175,15 +176,31 @@ def plumbing_run(cfg, args, model, optimizer, scheduler, algo, train_loader, dat
     b, t = cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.NUM_FRAMES
     assert videos.shape[:3] == (b, 2, t) and tuple(seq_lens.shape) == (b, 2) and tuple(chosen_steps.shape) == (b, 2, t)
     # checkpoint round trip in the reference's format (models/__init__.py:17-60): parameters, BN buffers, Adam state
+    # ... in a scratch directory UNDER the log directory, removed afterwards: a LOGDIR that already holds checkpoint E must not
+    # gain a "checkpoint E + 1" with epoch-E weights that a later real run would resume from
     before = {k: v.detach().clone() for k, v in model.module.state_dict().items()}
-    if du.is_root_proc():
-        save_checkpoint(cfg, model, optimizer, start_epoch)
-    du.synchronize()
-    with torch.no_grad():
-        for p in model.module.parameters():
-            if p.requires_grad:
-                p.add_(1.0)
-    restored = load_checkpoint(cfg, model, optimizer)
+    logdir = cfg.LOGDIR
+    scratch = os.path.join(logdir, 'plumbing_scratch')
+    cfg.LOGDIR = scratch
+    try:
+        if du.is_root_proc():
+            shutil.rmtree(scratch, ignore_errors=True)
+            save_checkpoint(cfg, model, optimizer, start_epoch)
+        du.synchronize()
+        with torch.no_grad():
+            for p in model.module.parameters():
+                if p.requires_grad:
+                    p.add_(1.0)
+        restored = load_checkpoint(cfg, model, optimizer)
+        from .utils import checkpoint as _ckpt
+        ck = _ckpt._read(_ckpt.latest(cfg))          # what was on disk, for the caller (the file itself does not survive)
+        ck_summary = {'file': os.path.basename(_ckpt.latest(cfg)), 'keys': sorted(ck), 'epoch': ck['epoch'],
+                      'model_prefixes': sorted({k.split('.')[0] for k in ck['model_state']})}
+        du.synchronize()
+    finally:
+        cfg.LOGDIR = logdir
+        if du.is_root_proc():
+            shutil.rmtree(scratch, ignore_errors=True)
     after = model.module.state_dict()
     assert restored == start_epoch + 1 and all(torch.equal(before[k], after[k]) for k in before), 'checkpoint round trip'
     # the iteration's collectives on host tensors (gloo): gradient buckets of the flat buffer, loss all-reduce
@@ -214,7 +231,7 @@ def plumbing_run(cfg, args, model, optimizer, scheduler, algo, train_loader, dat
     du.synchronize()
     if du.is_dist():
         torch.distributed.destroy_process_group()
-    return {'plumbing': True, 'stopped_at': reached}
+    return {'plumbing': True, 'stopped_at': reached, 'checkpoint': ck_summary}
 
 
 def main(argv=None):
@@ -236,7 +253,7 @@ def main(argv=None):
     model = build_model(cfg, args.local_rank).to(device)
     if du.collectives_active():            # world > 1 (train.py:283), or a forced one-rank group
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
-        if device == 'cuda':
+        if str(device).startswith('cuda'):     # 'cuda', 'cuda:0', torch.device('cuda', 0)
             du.reserve_collective_cus()    # RCCL's kernels get CUs of their own beside the persistent GEMM
     model = DataParallelModel(model)
     optimizer = construct_optimizer(model, cfg)

@@ -37,8 +37,7 @@ def reserve_collective_cus(device=None):
     (-3 % of their throughput, measured in DESIGN.md section 5).  No-op without collectives.  Returns the GEMM's CU budget."""
     from .. import _lib
     if not collectives_active():
-        _lib.call('mvf_gemm_tc_set_cus', 0)
-        return 0
+        return 0          # nothing to reserve for; a budget set through MVF_GEMM_CUS / mvf_gemm_tc_set_cus stays as it is
     reserve = int(os.environ.get('MVF_RCCL_CUS', '8'))
     dev = torch.cuda.current_device() if device is None else device
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -209,6 +208,11 @@ class GradReducer:
         self.sizes = [sum(1 for j in self.bucket_of.values() if j == b) for b in range(len(self.buckets))]
         self.pending = None
         self.works = None
+        # bench.py: `timing = True` records, per step, a device event pair around the wait for the bucket all-reduces --
+        # the communication time the compute stream could NOT hide under backward (finish() is called right after the last
+        # backward kernel has been enqueued and right before the optimizer's kernels)
+        self.timing = False
+        self.exposed = []          # (event before the wait, event after it)
         if self.active:
             for i, p in enumerate(flat.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i, False))   # gradients that travel through autograd
@@ -250,7 +254,27 @@ class GradReducer:
             for b in range(len(self.buckets)):
                 if self.works[b] is None:
                     self._launch(b)
+            ev = None
+            if self.timing and self.flat.flat_g.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             for w in self.works:
                 w.wait()
+            if ev is not None:
+                ev[1].record()
+                self.exposed.append(ev)
         self.reset()
         return 1.0 / self.world   # scale that turns the SUM into DDP's average
+
+    def bytes_per_step(self):
+        """payload of the gradient all-reduce of one step (every bucket once): fp32 elements of the flat gradient buffer"""
+        return 4 * sum(e - s for s, e in self.buckets)
+
+    def exposed_ms(self):
+        """mean device time per step between the end of backward and the start of the optimizer that the bucket all-reduces
+        kept the compute stream waiting (call after a synchronize; clears the record)"""
+        if not self.exposed:
+            return None
+        ms = sum(a.elapsed_time(b) for a, b in self.exposed) / len(self.exposed)
+        self.exposed = []
+        return ms

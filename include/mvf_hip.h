@@ -111,6 +111,12 @@ int mvf_gemm_tc_ln(int dtype, int epi, const void* A, int lda, const void* W, in
                    float* resid, int ldr, void* tap, int ldt, const float* ls, int tokens_per_frame, void* xb, int ldxb,
                    float* stats, const float* ln_mr, const float* ln_c, int M, int N, int K, hipStream_t stream);
 int mvf_ln_stats_finalize(const float* part, int ns, float* mean_rstd, int rows, int D, float eps, hipStream_t stream);
+/* epi 0 / 1 of mvf_gemm_tc_ln fed with the partial sums themselves (part [ns][M][2], D = K): the persistent 256x256 kernel stages a
+ * tile's rows of them during the tile's first K tile and finalizes them in its second (same arithmetic as mvf_ln_stats_finalize,
+ * bit for bit) -- no launch between the producing residual GEMM and the consuming one (timm Block.forward: norm1 -> attn.qkv,
+ * reached from models/transformer.py:188).  MVF_ERR_UNSUPPORTED: ns > 12, odd M, K < 256, or the 128x128 kernel pinned. */
+int mvf_gemm_tc_ln_part(int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
+                        const float* part, int ns, float eps, const float* ln_c, int M, int N, int K, hipStream_t stream);
 /* Deferred residual of the attention branch (bf16 mode, timm Block without LayerScale: x = x + proj(attn); x = x + mlp(norm2(x))):
  * proj stores delta = bf16(A W^T + b) with the plain epilogue (mvf_gemm_tc, epi 0) instead of read-modifying the fp32 residual;
  *   mvf_layernorm_add_fwd   y = LayerNorm(x + delta)          (x untouched)
@@ -166,6 +172,11 @@ int mvf_debug_xcc_map(int* out, int nblocks, int threads, int lds_bytes, hipStre
 int mvf_gemm_tc_set_cus(int n);
 /* *out = workgroups a persistent launch uses under the current budget (a multiple of 8, at least 8) */
 int mvf_gemm_tc_get_wgs(int* out);
+/* tile-list order of the persistent 256x256 kernel (speed only, results unchanged): g > 0 = grouped by weight panels -- groups of g
+ * column tiles outermost, every row panel inside a group -- where g divides the launch's column-tile count, so that the tiles an
+ * XCD works on at one time need g W panels instead of all of them; 0 = row panel major; -1 = chosen per launch (default: 4 where 4
+ * divides a column-tile count of 8 or more, else 3 where 3 divides one of 6 or more; MVF_GEMM_NGROUP sets the initial value).  The cuBLAS analogue is a different tile rasterisation of the nn.Linear GEMMs behind models/transformer.py:188 */
+int mvf_gemm_tc_set_ngroup(int g);
 /* diagnostic build of the 256x256 kernel: per-block s_memtime stamps into buf[blocks][2][8] (NULL = off, the default) */
 int mvf_gemm_tc_debug_stamps(unsigned long long* buf);
 /* diagnostic, stamped build only: A rows are read as (row & mask), so A's footprint is mask + 1 rows (L2-resident feed rate) */

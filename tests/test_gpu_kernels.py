@@ -187,6 +187,48 @@ def test_gemm_ln_fold_consumer_epilogue(M, N, K, epi):
         assert torch.equal(C, C2), variant
 
 
+@pytest.mark.parametrize('M,N,K,epi', [(1000, 2304, 768, 0), (197 * 40 + 6, 3072, 768, 1), (25216, 2304, 768, 0), (50432, 2304, 768, 0)])
+def test_gemm_ln_fold_consumer_finalizes_partial_sums_in_kernel(M, N, K, epi):
+    """mvf_gemm_tc_ln_part: the folded-LayerNorm GEMM fed with the producer's PARTIAL sums [K/64][M][2] (what the fc2 residual
+    epilogue writes) must give, bit for bit, what mvf_ln_stats_finalize + mvf_gemm_tc_ln (mean, rstd) give -- the finalize launch
+    between fc2 and qkv is gone from the backbone.  Ragged last tile, > 256 tiles (ticket scheduler: tile switches re-stage the
+    partial-sum region), every tile height, repeated launches as a race screen; shapes the kernel cannot stage are refused."""
+    g = gen(63)
+    x = (torch.randn(M, K, generator=g) * 2.0 + 0.3).to(DEV)
+    xb = x.to(torch.bfloat16)
+    Wp = (torch.randn(N, K, generator=g) * 0.05).to(DEV).to(torch.bfloat16)
+    c = Wp.double().sum(1).float()
+    d = torch.randn(N, generator=g).to(DEV)
+    ns = K // 64
+    xs = x.view(M, ns, 64)
+    part = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).permute(1, 0, 2).contiguous()      # [ns][M][2]
+    mr = torch.empty(M, 2, device=DEV)
+    _lib.call('mvf_ln_stats_finalize', part.data_ptr(), ns, mr.data_ptr(), M, K, 1e-6, S())
+    ref = torch.full((M, N), 7.0, device=DEV, dtype=torch.bfloat16)
+    _lib.call('mvf_gemm_tc_ln', _lib.BF16, epi, xb.data_ptr(), K, Wp.data_ptr(), K, d.data_ptr(), ref.data_ptr(), N, None, 0,
+              None, 0, None, 197, None, 0, None, mr.data_ptr(), c.data_ptr(), M, N, K, S())
+    for variant in (0, 0, 0, 4, 5, 6, 7):
+        _lib.call('mvf_gemm_tc_select', variant)
+        try:
+            C = torch.full((M, N), 7.0, device=DEV, dtype=torch.bfloat16)
+            _lib.call('mvf_gemm_tc_ln_part', epi, xb.data_ptr(), K, Wp.data_ptr(), K, d.data_ptr(), C.data_ptr(), N, part.data_ptr(),
+                      ns, 1e-6, c.data_ptr(), M, N, K, S())
+            torch.cuda.synchronize()
+        finally:
+            _lib.call('mvf_gemm_tc_select', 0)
+        assert torch.equal(C, ref), (variant, (C.float() - ref.float()).abs().max().item())
+    # refused, not mis-computed: an odd row count (16-byte pieces of two rows), more slices than the LDS region holds, the
+    # 128x128 kernel pinned
+    assert not _lib.try_call('mvf_gemm_tc_ln_part', epi, xb.data_ptr(), K, Wp.data_ptr(), K, d.data_ptr(), C.data_ptr(), N,
+                             part.data_ptr(), ns, 1e-6, c.data_ptr(), M - 1, N, K, S())
+    _lib.call('mvf_gemm_tc_select', 1)
+    try:
+        assert not _lib.try_call('mvf_gemm_tc_ln_part', epi, xb.data_ptr(), K, Wp.data_ptr(), K, d.data_ptr(), C.data_ptr(), N,
+                                 part.data_ptr(), ns, 1e-6, c.data_ptr(), M, N, K, S())
+    finally:
+        _lib.call('mvf_gemm_tc_select', 0)
+
+
 # ------------------------------------------------------------------------------------------------ MX-fp8 (configs[4])
 def _mx_decode(q, scales, rows, K):
     """device MX-fp8 (e4m3 bytes [rows, K] + scales [K/128][rows] dwords, block b of a K tile in byte b) -> fp32 on the CPU"""
@@ -1099,6 +1141,31 @@ def test_scl_row_slice():
                  rows=M // 2, grad_scale=2.0).backward()
     assert ed2.grad[:M // 2].abs().max().item() == 0.0
     check(ed2.grad[M // 2:], 2.0 * full[M // 2:], 1e-6, 'scl row slice')
+
+
+@pytest.mark.parametrize('rank', [0, 5])
+def test_scl_at_the_gathered_size_of_eight_ranks(rank):
+    """BASELINE configs[2] (cross-GPU embedding all-gather, 8 ranks x 4 videos): the loss over the W * 256 = 2 048 gathered rows
+    and the gradient of ONE rank's 256 rows (row0 / rows, scaled by W as utils.distributed.gather_rows' caller does) against the
+    fp64 oracle on the rank-concatenated inputs -- W = 8 emulated on one GPU (algos/scl.py:52-105 on concatenated inputs)."""
+    W, bl, t, e = 8, 4, 32, 128
+    b = W * bl
+    embs, seq_lens, steps, masks = C.scl_inputs(b, t, e, 4242, 7)
+    lens = seq_lens.view(b, 2, 1).expand(b, 2, t)
+    M, rows = b * 2 * t, bl * 2 * t
+    ed = _leaf(embs.reshape(-1, e))
+    loss = ops.scl_loss(ed, steps.to(DEV), lens.to(DEV), masks.to(DEV), t, 'batch_noself', 0.1, 10.0, row0=rank * rows, rows=rows,
+                        grad_scale=float(W))
+    loss.backward()
+    er = embs.double().requires_grad_(True)
+    lo = OS.scl_loss(er, seq_lens, steps, masks, negative_type='batch_noself')
+    lo.backward()
+    check(loss, lo, 1e-5, 'gathered scl loss (oracle fp64, M = %d)' % M)
+    own = slice(rank * rows, (rank + 1) * rows)
+    check(ed.grad[own], W * er.grad.reshape(M, e)[own], 2e-4, 'gathered scl dE of rank %d' % rank)
+    other = torch.ones(M, dtype=torch.bool)
+    other[own] = False
+    assert ed.grad[other.to(DEV)].abs().max().item() == 0.0
 
 
 # ------------------------------------------------------------------------------------------------ optimiser

@@ -1,5 +1,5 @@
 """Mean per launch of every SQ / GRBM counter collected by tools/pmc_sq.sh (separate rocprofv3 --pmc passes over
-tools/gemm_bench.py --shapes qkv,fc1), per kernel name, first launch of each kernel dropped (cold).
+tools/gemm_bench.py --shapes qkv,proj,fc1,fc2), per kernel name, first launch of each kernel dropped (cold).
 Usage: python3 tools/pmc_sq_summary.py gpurun_out/pmc_sq [kernel-name substring, default gemm_tc256_kernel]"""
 import csv
 import glob
@@ -25,8 +25,8 @@ for f in sorted(glob.glob(os.path.join(root, '**', '*counter_collection.csv'), r
             continue
         for c, v in cs.items():
             vals[short][c].append(v)
-print('tools/pmc_sq.sh: rocprofv3 --pmc passes (4 counters each, no trace) over tools/gemm_bench.py --shapes qkv,fc1; mean per launch,')
-print('summed over the 8 XCDs (GRBM_GUI_ACTIVE / 8 = cycles of the launch).  <0,..> = qkv, <1,..> = fc1 + GELU.\n')
+print('tools/pmc_sq.sh: rocprofv3 --pmc passes (4 counters each, no trace) over tools/gemm_bench.py --shapes qkv,proj,fc1,fc2; mean per launch,')
+print('summed over the 8 XCDs (GRBM_GUI_ACTIVE / 8 = cycles of the launch).  <0,..,256> = qkv, <0,..,208> = proj, <1,..> = fc1 + GELU, <2,..> = fc2 + residual (+ deferred attention-branch addend).\n')
 for kn in sorted(vals):
     print(kn)
     cs = vals[kn]

@@ -26,6 +26,7 @@ SIGNATURES = {
     'mvf_gemm_tc_batched': 'ipipipipiiiiiip',
     'mvf_gemm_tc_ln': 'iipipippipipipipipppiiip',
     'mvf_ln_stats_finalize': 'pipiifp',
+    'mvf_gemm_tc_ln_part': 'ipipippipifpiiip',
     'mvf_layernorm_add_fwd': 'ipzpzpppziifp',
     'mvf_gemm_tc_resid2': 'pipippipipiiiiip',
     'mvf_gemm_tc_f32': 'pipippipiiip',
@@ -44,6 +45,7 @@ SIGNATURES = {
     'mvf_gemm_tc_debug_ablate': 'i',
     'mvf_gemm_tc_set_cus': 'i',
     'mvf_gemm_tc_get_wgs': 'p',
+    'mvf_gemm_tc_set_ngroup': 'i',
     'mvf_debug_xcc_map': 'piiip',
     'mvf_patchify': 'ippiiiip',
     'mvf_layernorm_fwd': 'ipzpppziifp',

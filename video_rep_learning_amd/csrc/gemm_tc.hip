@@ -238,6 +238,7 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
   a.sched = nullptr;   // set by the persistent gemm_tc256 launch
   a.batch_rows = batch_rows; a.w_batch_rows = w_batch_rows;
   a.xb = nullptr; a.ldxb = 0; a.stats = nullptr; a.ln_mr = nullptr; a.ln_c = nullptr;
+  a.ln_part = nullptr; a.ln_ns = 0; a.ln_inv_d = 0.f; a.ln_eps = 0.f; a.ngroup = 0;
   a.sa = nullptr; a.sw = nullptr; a.csc = nullptr;
   a.radd = resid;
   a.radd2 = nullptr; a.ldr2 = 0;
@@ -249,15 +250,19 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
     MVF_CHECK_ARG(epi == EPI_RESID && (ln->addend_mode == 2 || (ln->addend_mode == 1 && ln->addend && ((uintptr_t)ln->addend % 16) == 0)));
     a.radd = ln->addend_mode == 1 ? ln->addend : nullptr;
   }
-  const bool fold = ln != nullptr && (ln->xb || ln->stats || ln->ln_mr || ln->ln_c);
+  const bool fold = ln != nullptr && (ln->xb || ln->stats || ln->ln_mr || ln->ln_c || ln->ln_part);
   if (fold) {   // LN fold: epilogue extras of the 256x256 bf16 kernel
     if (ln->xb || ln->stats) MVF_CHECK_ARG(epi == EPI_RESID);
     if (ln->xb) MVF_CHECK_ARG(ln->ldxb % 8 == 0 && ln->ldxb >= N && ((uintptr_t)ln->xb % 16) == 0);
     if (ln->stats) MVF_CHECK_ARG(N % 64 == 0 && ((uintptr_t)ln->stats % 8) == 0);
-    if (ln->ln_mr || ln->ln_c)
-      MVF_CHECK_ARG((epi == EPI_STORE || epi == EPI_GELU) && ln->ln_mr && ln->ln_c && ((uintptr_t)ln->ln_mr % 8) == 0);
+    if (ln->ln_mr || ln->ln_c || ln->ln_part)
+      MVF_CHECK_ARG((epi == EPI_STORE || epi == EPI_GELU) && ln->ln_c && (ln->ln_mr != nullptr) != (ln->ln_part != nullptr) &&
+                    ((uintptr_t)ln->ln_mr % 8) == 0 && ((uintptr_t)ln->ln_part % 16) == 0 && (!ln->ln_part || ln->ln_ns > 0));
     if (!(dtype == MVF_BF16 && N % 64 == 0 && batch_rows == 0)) return MVF_ERR_UNSUPPORTED;
+    // partial sums instead of (mean, rstd): the persistent 256x256 kernel only (it refuses shapes it cannot stage)
+    if (ln->ln_part && !(g_variant != 1 && g_variant != 3 && K % 128 == 0 && N % 32 == 0)) return MVF_ERR_UNSUPPORTED;
     a.xb = (char*)ln->xb; a.ldxb = ln->ldxb; a.stats = ln->stats; a.ln_mr = ln->ln_mr; a.ln_c = ln->ln_c;
+    a.ln_part = ln->ln_part; a.ln_ns = ln->ln_ns; a.ln_inv_d = 1.0f / (float)K; a.ln_eps = ln->ln_eps;
   }
   if (batch_rows != 0) {   // stacked batches: the 256x256 kernel only
     MVF_CHECK_ARG(batch_rows > 0 && batch_rows % 256 == 0 && M % batch_rows == 0 && w_batch_rows >= N);
@@ -270,7 +275,7 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
     // takes over unless the caller pinned the kernel or asked for stacked batches
     if (rc != MVF_ERR_UNSUPPORTED || g_variant >= 2 || batch_rows != 0) return rc;
   }
-  if (g_variant >= 2) return MVF_ERR_UNSUPPORTED;
+  if (g_variant >= 2 || a.ln_part != nullptr) return MVF_ERR_UNSUPPORTED;   // (partial sums: the 256x256 kernel or nothing)
   return dtype == MVF_BF16 ? dispatch<bf16_t>(epi, a, st) : dispatch<float>(epi, a, st);
 }
 
@@ -293,6 +298,7 @@ int mvf_gemm_fp8_impl(int epi, const void* A, int lda, const unsigned* sa, const
   a.pos = nullptr; a.ls = ls; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.ldt = ldt; a.M = M; a.N = N; a.K = K; a.tpf = tpf;
   a.dbg = nullptr; a.dbg_rowmask = 0x7fffffffu; a.dbg_kt = -1; a.dbg_abl = 0; a.sched = nullptr; a.batch_rows = 0; a.w_batch_rows = 0;
   a.xb = nullptr; a.ldxb = 0; a.stats = nullptr; a.ln_mr = nullptr; a.ln_c = nullptr;
+  a.ln_part = nullptr; a.ln_ns = 0; a.ln_inv_d = 0.f; a.ln_eps = 0.f; a.ngroup = 0;
   a.sa = sa; a.sw = sw; a.csc = c_scales; a.radd = resid; a.radd2 = nullptr; a.ldr2 = 0;
   if (addend2 != nullptr) {
     MVF_CHECK_ARG(epi == EPI_RESID && ((uintptr_t)addend2 % 8) == 0 && ld2 % 4 == 0 && ld2 >= N);

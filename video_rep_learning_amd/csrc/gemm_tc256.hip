@@ -40,8 +40,10 @@
 //    the epilogue would make hipcc drain the next tile's DMAs).
 //  * operands swapped (W fragment as MFMA-A) so a lane owns 4 consecutive output columns; v_permlane16_swap pairs two
 //    tiles into 16-byte stores (gemm_tc_epi.h).
-//  * tried and rejected: N-grouping (each XCD serving only nbn/4 weight panels so that W stays L2-resident) -- no change
-//    at all on fc1 (315 us either way): W re-fetches are not what the loop waits for.
+//  * N-grouping (round 1: "no change at all on fc1, 315 us either way" -- measured on 20-launch bursts).  Round 4, sustained at
+//    the power cap (seconds of back-to-back launches): the tile list ordered by groups of 3 / 4 weight panels (GemmTcArgs.ngroup)
+//    takes qkv from 168 to 155.5 us and fc1 from 253 to 244 us although the fabric-side bytes barely move (qkv 302 -> 315 MB
+//    fetched, fc1 487 -> 427): fewer CUs of an XCD pull the SAME A panel / all W panels at the same moment.
 //  * tried and rejected: cache-policy hints on the operand DMAs (`nt` on A: 11.59 -> 11.96 ms/step; `nt` on W: 12.56; both:
 //    13.05; `sc0` on A: 11.80) -- the default policy is the best of the five.
 //  * tried and rejected: non-temporal (`nt`) output stores so that C does not displace A / W lines in L2 -- qkv 193 -> 185 us,
@@ -99,6 +101,11 @@ constexpr int LNC_OFF = SLOT_OFF + 16;
 constexpr int LNMR_OFF = LNC_OFF + 8 * 256;
 constexpr int SC_OFF = LNMR_OFF + 2 * 2048;     // fp8: two K tiles' scales, [buf][A 256 dwords | W 256 dwords]
 constexpr int LDS_BYTES = SC_OFF + 2 * 2048;    // 140 KiB -> one workgroup per CU
+// LN fold, consumer side with in-kernel finalize (a.ln_part): the (mean, rstd) slot is single (LNMR_OFF: written in K tile 1 of a
+// tile, read in that tile's epilogue, next written a whole K loop's barriers later) and the tile's partial sums
+// [ln_ns][256 rows][2] sit behind it, over the second parity slot and the fp8 scale region (never used together): ln_ns <= 12
+constexpr int LNP_OFF = LNMR_OFF + 2048;
+constexpr int LDS_MAX = 160 * 1024;
 constexpr int OFF_A0 = 0, OFF_A1 = HALF_BYTES, OFF_B0 = 2 * HALF_BYTES, OFF_B1 = 3 * HALF_BYTES;
 
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -195,6 +202,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   const int end = start + q8 + (xcd < r8 ? 1 : 0);
   int lid = start + slot;                          // tile being computed
   if (lid >= end) return;                          // whole workgroup (only when tiles are unevenly spread over XCDs)
+  // list index -> (row panel, column tile).  a.ngroup > 0 (it divides nbn; the launch checks): column groups outermost
+  const int nmt = (a.M + BMT - 1) / BMT;
+  auto tile_mn = [&](int tile, int& mt, int& nt) {
+    if (a.ngroup > 0) {
+      const int per = nmt * a.ngroup, grp = tile / per, rem = tile - grp * per;
+      mt = rem / a.ngroup;
+      nt = grp * a.ngroup + (rem - mt * a.ngroup);
+    } else {
+      mt = tile / nbn;
+      nt = tile - mt * nbn;
+    }
+  };
   const int nk = FP8 ? a.K >> 7 : a.K >> 6;        // K tiles of 128 bytes per row (even: K % 128 == 0, fp8: K % 256 == 0)
   // dynamic tickets only when this group has more tiles than workgroups (then no workgroup of it returned above)
   const bool dyn = a.sched != nullptr && nk >= 4 && start + bpx < end;
@@ -227,7 +246,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   const unsigned* const sbase = wave < 4 ? a.sa : a.sw;
   const unsigned sstride = wave < 4 ? (unsigned)a.M : (unsigned)a.N;
   auto set_sources = [&](int tile) {
-    const int tm0 = (tile / nbn) * BMT, tn0 = (tile % nbn) * BN;
+    int tmt, tnt;
+    tile_mn(tile, tmt, tnt);
+    const int tm0 = tmt * BMT, tn0 = tnt * BN;
     if constexpr (FP8)
       ssrc = wave < 4 ? (unsigned)min(tm0 + wave * 64 + lane, a.M - 1) : (unsigned)min(tn0 + (wave - 4) * 64 + lane, a.N - 1);
     // stacked batches (split-K weight gradients): the tile's batch picks its own row block of W
@@ -272,21 +293,54 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   // epilogue of THIS wave, when the parity has just flipped: slot tpar is read in this tile's epilogue only, and was last read
   // two tiles ago (every wave has passed a K loop's barriers since)
   int tpar = 0;
+  constexpr bool kLnCons = LN && (EPI == EPI_STORE || EPI == EPI_GELU);
+  const bool lnp = kLnCons && a.ln_part != nullptr;    // (mean, rstd) from the partial sums, inside the kernel
   auto stage_bias = [&](int tile) {
+    int tmt, tnt;
+    tile_mn(tile, tmt, tnt);
     if (a.bias != nullptr) {
-      const int n = min((tile % nbn) * BN + wc * 64 + lane, a.N - 1);
+      const int n = min(tnt * BN + wc * 64 + lane, a.N - 1);
       __builtin_amdgcn_global_load_lds(GLB_PTR(a.bias + n), LDS_PTR(sbias), 4, 0, 0);
     }
     if constexpr (LN && (EPI == EPI_STORE || EPI == EPI_GELU)) {
       {
-        const int n = min((tile % nbn) * BN + wc * 64 + lane, a.N - 1);
+        const int n = min(tnt * BN + wc * 64 + lane, a.N - 1);
         __builtin_amdgcn_global_load_lds(GLB_PTR(a.ln_c + n), LDS_PTR(slnc), 4, 0, 0);
         // rows m0 .. m0+255 as 512 consecutive floats; this wave copies floats [64 w, 64 w + 64) = rows m0 + 32 w ..
-        const int fi = wave * 64 + lane;
-        const int row = min((tile / nbn) * BMT + (fi >> 1), a.M - 1);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(a.ln_mr + (size_t)row * 2 + (fi & 1)),
-                                         LDS_PTR(smem + LNMR_OFF + tpar * 2048 + wave * 256), 4, 0, 0);
+        if (!lnp) {
+          const int fi = wave * 64 + lane;
+          const int row = min(tmt * BMT + (fi >> 1), a.M - 1);
+          __builtin_amdgcn_global_load_lds(GLB_PTR(a.ln_mr + (size_t)row * 2 + (fi & 1)),
+                                           LDS_PTR(smem + LNMR_OFF + tpar * 2048 + wave * 256), 4, 0, 0);
+        }
       }
+    }
+  };
+  // in-kernel finalize, step 1 (K tile 0 of a tile, after its first barrier: every wave has left the previous tile's K tile 1,
+  // the region's only reader): the tile's partial sums, 2 * ln_ns pieces of 1 KiB = 128 rows x (sum, sum of squares) of one
+  // 64-column slice; older than the three half-tiles the K tile's vmcnt(6) leaves in flight, so landed after its P3 barrier
+  auto stage_partials = [&](int m0c) {
+    for (int p = wave; p < 2 * a.ln_ns; p += 8) {
+      const int row = min(m0c + (p & 1) * 128 + lane * 2, a.M - 2);      // (M is even: checked by the launch)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(a.ln_part + ((size_t)(p >> 1) * a.M + row) * 2), LDS_PTR(smem + LNP_OFF + p * 1024), 16, 0,
+                                       0);
+    }
+  };
+  // step 2 (K tile 1, after its first barrier): wave w turns rows 32 w .. 32 w + 31 into (mean, rstd), one lane per row, slices
+  // summed in order -- the arithmetic of ln_stats_finalize_kernel (vit_misc.hip), bit for bit
+  auto finalize_partials = [&]() {
+    if (lane < 32) {
+      const int r = wave * 32 + lane;
+      const char* p = smem + LNP_OFF + r * 8;
+      float s1 = 0.f, s2 = 0.f;
+      for (int sl = 0; sl < a.ln_ns; ++sl) {
+        const float2 v = *reinterpret_cast<const float2*>(p + sl * 2048);
+        s1 += v.x;
+        s2 += v.y;
+      }
+      const float mean = s1 * a.ln_inv_d;
+      const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * a.ln_inv_d), 0.f);
+      *reinterpret_cast<float2*>(smem + LNMR_OFF + r * 8) = make_float2(mean, 1.0f / sqrtf(var + a.ln_eps));
     }
   };
 
@@ -410,6 +464,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     WAIT_LGKM(8); /* everything in front of the eight A reads is back: the B reads (and the fp8 scales) */   \
     WG_BARRIER();                                                                                            \
     KSTAMP();                                                                                                \
+    if constexpr (kLnCons) {                                                                                 \
+      if ((BUF) == 0 && lnp && t == 0) stage_partials(m0);                                                   \
+      if ((BUF) == 1 && lnp && t == 1) finalize_partials();                                                  \
+    }                                                                                                        \
     unsigned tkv = 0;                                                                                        \
     if (dyn && t == 1) tkv = *(volatile __attribute__((address_space(3))) unsigned*)LDS_PTR(smem + SLOT_OFF); \
     WAIT_LGKM(0);                                                                                            \
@@ -468,7 +526,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   for (;;) {
     int lid_next = dyn ? 0x7fffffff : lid + bpx;   // dyn: known from K tile 1 on (see K_TILE)
     bool have_next = lid_next < end;
-    const int m0 = (lid / nbn) * BMT, n0 = (lid % nbn) * BN;   // compute-side tile
+    int cmt, cnt_;
+    tile_mn(lid, cmt, cnt_);
+    const int m0 = cmt * BMT, n0 = cnt_ * BN;   // compute-side tile
     int kwrap = 0;
     if (wr == 1) WG_BARRIER();  // stagger: wave row 1 runs one barrier behind wave row 0
 
@@ -491,7 +551,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     // front of this write) finds it done.  Every wave is past its K tile 1 read of the slot.
     if (dyn && have_next) publish_ticket();
     constexpr bool kReadModify = EPI == EPI_RESID || EPI == EPI_PATCH;
-    constexpr bool kLnConsumer = LN && (EPI == EPI_STORE || EPI == EPI_GELU);
+    constexpr bool kLnConsumer = kLnCons;
     constexpr bool kLnProducer = LN && EPI == EPI_RESID;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 gj[4] = {z4, z4, z4, z4};
@@ -532,7 +592,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
       // from this tile's LDS slot, the wave's 64 ln_c values from its own slot), then the plain epilogue with bias = d.
       // Done inside the store loop instead, the extra live values (c, mean/rstd) sat on top of the GELU temporaries and the
       // fc1 epilogue took twice as long.
-      const char* smr = smem + LNMR_OFF + tpar * 2048 + (wr * WR0 + frow) * 8;
+      const char* smr = smem + LNMR_OFF + (lnp ? 0 : tpar * 2048) + (wr * WR0 + frow) * 8;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {     // column tile outermost: 4 ln_c values live at a time, (mean, rstd) re-read per row
         const float4 c = *reinterpret_cast<const float4*>(slnc + (j * 16 + fgrp * 4) * 4);
@@ -540,10 +600,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
         for (int i = 0; i < 4 + RTA; ++i) {      // (a fragment wave row 1 lacks: unused accumulators, rows inside the slot)
           const float2 mr = *reinterpret_cast<const float2*>(smr + ((i >> 2) * 64 + (i & 3) * 16) * 8);
           const float nm = -mr.x;
-          acc[i][j][0] = mr.y * fmaf(nm, c.x, acc[i][j][0]);
-          acc[i][j][1] = mr.y * fmaf(nm, c.y, acc[i][j][1]);
-          acc[i][j][2] = mr.y * fmaf(nm, c.z, acc[i][j][2]);
-          acc[i][j][3] = mr.y * fmaf(nm, c.w, acc[i][j][3]);
+          // mul_rounded: a product of its own rounding, never contracted with the bias add of the store loop below -- whether hipcc
+          // fused the two depended on the instantiation (tile height, what else the kernel carries: the unequal-wave-row variants
+          // stopped fusing the fragment wave row 1 lacks), and with it the bit-for-bit agreement of the kernels (gemm_tc.hip's
+          // epilogue4 spells the same two roundings)
+          acc[i][j][0] = mul_rounded(mr.y, fmaf(nm, c.x, acc[i][j][0]));
+          acc[i][j][1] = mul_rounded(mr.y, fmaf(nm, c.y, acc[i][j][1]));
+          acc[i][j][2] = mul_rounded(mr.y, fmaf(nm, c.z, acc[i][j][2]));
+          acc[i][j][3] = mul_rounded(mr.y, fmaf(nm, c.w, acc[i][j][3]));
         }
       }
       SCHED_FENCE();   // keep the pre-pass out of the store loop (its values would pile onto the GELU temporaries)
@@ -659,6 +723,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
 #undef KSTAMP
 }
 
+// > 0: column tiles per weight-panel group of the tile list (GemmTcArgs.ngroup); 0 = row panel major
+int g_ngroup = [] { const char* e = getenv("MVF_GEMM_NGROUP"); return e ? atoi(e) : -1; }();
+
 // > 0: CUs the persistent launch may take, see mvf_gemm_tc_set_cus (MVF_GEMM_CUS: initial value, A/B measurements)
 int g_cu_budget = [] { const char* e = getenv("MVF_GEMM_CUS"); return e ? atoi(e) : 0; }();
 
@@ -691,19 +758,35 @@ unsigned* sched_slot() {
 template <int EPI, bool DBG = false, bool LN = false, bool FP8 = false, int ABL = 0, bool ADD2 = false, int BMT = 256>
 int launch_bm(const GemmTcArgs& a0, bool persistent, hipStream_t st) {
   GemmTcArgs a = a0;
+  {   // weight-panel grouping of the tile list (MVF_GEMM_NGROUP / mvf_gemm_tc_set_ngroup; plain, unbatched launches only)
+    const int nbn_ = (a.N + BN - 1) / BN;
+    // -1 = per launch: groups of 4 column tiles where 4 divides a count of 8 or more, else of 3 where 3 divides a count of 6 or
+    // more, else none.  Sustained (seconds of back-to-back launches at the power cap, profiles/r04/ngroup_ab.txt), M = 50 432:
+    // qkv (9 column tiles) 167.8 - 169.2 -> 155.5 us with groups of 3; fc1 (12) 253.2 -> 250.7 (3) / 244.1 (4) / 249.0 (6)
+    int g = g_ngroup;
+    if (g < 0) g = (nbn_ >= 8 && nbn_ % 4 == 0) ? 4 : ((nbn_ >= 6 && nbn_ % 3 == 0) ? 3 : 0);
+    a.ngroup = (g > 0 && persistent && a.batch_rows == 0 && nbn_ > g && nbn_ % g == 0) ? g : 0;
+  }
   static const bool force_static = getenv("MVF_GEMM_STATIC") != nullptr;   // A/B measurements only
   a.sched = persistent && !force_static ? sched_slot() : nullptr;
   static bool attr_set = false;
+  constexpr bool lncons = LN && (EPI == EPI_STORE || EPI == EPI_GELU);
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2, BMT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lncons ? LDS_MAX : LDS_BYTES);
     attr_set = true;
+  }
+  int lds_bytes = LDS_BYTES;
+  if (a.ln_part != nullptr) {   // in-kernel finalize: the partial sums of a tile's 256 rows behind the single (mean, rstd) slot
+    if (!lncons || !persistent || a.ln_ns < 1 || LNP_OFF + a.ln_ns * 2048 > LDS_MAX || (a.M & 1) || (FP8 ? a.K >> 7 : a.K >> 6) < 4)
+      return MVF_ERR_UNSUPPORTED;
+    lds_bytes = std::max(LDS_BYTES, LNP_OFF + a.ln_ns * 2048);
   }
   const int ntiles = ((a.M + BMT - 1) / BMT) * ((a.N + BN - 1) / BN);
   // persistent: one workgroup per CU (a multiple of 8 so that every XCD gets the same number); otherwise (A/B
   // measurements) one workgroup per tile -- the same kernel, every workgroup then runs the cold prologue
   const int grid = persistent ? std::min(ntiles, std::max(8, num_cus() & ~7)) : ntiles;
-  hipLaunchKernelGGL((gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2, BMT>), dim3(grid), dim3(512), LDS_BYTES, st, a);
+  hipLaunchKernelGGL((gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2, BMT>), dim3(grid), dim3(512), lds_bytes, st, a);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }
@@ -760,6 +843,12 @@ extern "C" int mvf_gemm_tc_set_cus(int n) {
   return MVF_OK;
 }
 
+extern "C" int mvf_gemm_tc_set_ngroup(int g) {
+  MVF_CHECK_ARG(g >= -1 && g <= 64);
+  g_ngroup = g;
+  return MVF_OK;
+}
+
 int mvf_gemm_tc256_num_wgs() { return std::max(8, num_cus() & ~7); }
 extern "C" int mvf_gemm_tc_get_wgs(int* out) {
   MVF_CHECK_ARG(out != nullptr);
@@ -777,7 +866,8 @@ int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, bool persistent
       wrows >= (1u << 24) || a.lda >= (1 << 23) || a.ldw >= (1 << 23))
     return MVF_ERR_UNSUPPORTED;
   if (fp8) {   // MX-fp8 operands (validated by mvf_gemm_fp8): no LN fold, no stacked batches, no stamps
-    if (a.sw == nullptr || a.batch_rows != 0 || a.dbg != nullptr || a.ln_mr != nullptr || a.xb != nullptr || a.stats != nullptr)
+    if (a.sw == nullptr || a.batch_rows != 0 || a.dbg != nullptr || a.ln_mr != nullptr || a.ln_part != nullptr || a.xb != nullptr ||
+        a.stats != nullptr)
       return MVF_ERR_ARG;
     switch (epi) {
       case EPI_STORE: return launch<EPI_STORE, false, false, true>(a, persistent, st);
@@ -806,7 +896,7 @@ int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, bool persistent
     }
     return MVF_ERR_ARG;
   }
-  if (a.ln_mr != nullptr || a.xb != nullptr || a.stats != nullptr) {   // LN-fold extras (validated by mvf_gemm_tc_impl)
+  if (a.ln_mr != nullptr || a.ln_part != nullptr || a.xb != nullptr || a.stats != nullptr) {   // LN-fold extras (validated by mvf_gemm_tc_impl)
     switch (epi) {
       case EPI_STORE: return launch<EPI_STORE, false, true>(a, persistent, st);
       case EPI_GELU: return launch<EPI_GELU, false, true>(a, persistent, st);

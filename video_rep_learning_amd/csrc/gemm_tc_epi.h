@@ -39,6 +39,12 @@ struct GemmTcArgs {
   // = ln_mr[m][2] and ln_c[n] = sum_k W'[n,k]:  C = rstd * (acc - mean * ln_c[n]) + bias[n]   (bias = b + W beta)
   const float* ln_mr;
   const float* ln_c;
+  // consumer side without a finalize launch (gemm_tc256 only): instead of ln_mr the PARTIAL sums the producing residual epilogue
+  // wrote, ln_part = stats [ln_ns][M][2]; the kernel stages a tile's 256 rows x ln_ns pairs by LDS-DMA during the tile's first
+  // K tile and turns them into (mean, rstd) in its second one (one lane per row, fixed order: bitwise mvf_ln_stats_finalize)
+  const float* ln_part;
+  int ln_ns;
+  float ln_inv_d, ln_eps;
   // ---- MX-fp8 operands (gemm_tc256 FP8 variants): A / W hold OCP e4m3 bytes (lda / ldw in bytes = elements); sa[K/128][M]
   // and sw[K/128][N] hold, per row and K tile of 128, the four E8M0 block scales (32 consecutive k each) packed in one dword
   // (block b of the K tile in byte b).  NULL = bf16 operands.
@@ -54,6 +60,10 @@ struct GemmTcArgs {
   int ldr2;
   // EPI_GELU_Q: C holds e4m3 bytes [M, ldc] and csc [N/128][M] the output's block scales (same layout as sa)
   unsigned* csc;
+  // gemm_tc256: > 0 = tile-list order grouped by weight panels (speed only): the list runs through groups of `ngroup` column
+  // tiles, all row panels inside a group, so that an XCD's contiguous chunk of it needs only ngroup W panels (L2-resident)
+  // instead of all of them; 0 = row panel major (tiles of one A row panel are neighbours)
+  int ngroup;
 };
 
 // max over the four lanes that hold one output row (lane, lane^16, lane^32, lane^48), result in all of them
@@ -74,6 +84,15 @@ __device__ __forceinline__ float row_quad_sum(float v) {
   const uint32_t x = __float_as_uint(w);
   const auto b = __builtin_amdgcn_permlane32_swap(x, x, false, false);   // halves: [lo lo], [hi hi]
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// a * b rounded to fp32 on its own: the empty asm makes the product a value hipcc cannot contract with a later add into one fma
+// (HIP's __fmul_rn is a plain `a * b` on this toolchain and contracts).  The LN-fold consumer epilogues of the two GEMM kernels
+// apply rstd with it so that both round twice -- rstd * t, then + bias -- whatever else the instantiation carries.
+__device__ __forceinline__ float mul_rounded(float a, float b) {
+  float p = a * b;
+  asm volatile("" : "+v"(p));
+  return p;
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -143,10 +162,11 @@ __device__ __forceinline__ void epilogue4(const GemmTcArgs& a, int m, int n, con
   if constexpr (LN && (EPI == EPI_STORE || EPI == EPI_GELU)) {
     const float4 c = *reinterpret_cast<const float4*>(a.ln_c + n);
     const float nm = -mr.x;
-    v[0] = fmaf(mr.y, fmaf(nm, c.x, acc[0]), b.x);
-    v[1] = fmaf(mr.y, fmaf(nm, c.y, acc[1]), b.y);
-    v[2] = fmaf(mr.y, fmaf(nm, c.z, acc[2]), b.z);
-    v[3] = fmaf(mr.y, fmaf(nm, c.w, acc[3]), b.w);
+    // two roundings (product, then bias), as the 256x256 kernel's pre-pass + plain epilogue compute it (gemm_tc256.hip)
+    v[0] = mul_rounded(mr.y, fmaf(nm, c.x, acc[0])) + b.x;
+    v[1] = mul_rounded(mr.y, fmaf(nm, c.y, acc[1])) + b.y;
+    v[2] = mul_rounded(mr.y, fmaf(nm, c.z, acc[2])) + b.z;
+    v[3] = mul_rounded(mr.y, fmaf(nm, c.w, acc[3])) + b.w;
   } else {
     v[0] = acc[0] + b.x;
     v[1] = acc[1] + b.y;

@@ -20,6 +20,10 @@ struct MvfGemmLn {
   // epi 2: a second addend, bf16 [M, ld2] (NULL: none): the attention branch's output stored by the proj GEMM (deferred residual)
   const void* addend2;
   int ld2;
+  // epi 0 / 1, instead of ln_mr: the producer's partial sums [ln_ns][M][2] (finalized inside the 256x256 kernel; D = K)
+  const float* ln_part;
+  int ln_ns;
+  float ln_eps;
 };
 int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C,
                      int ldc, float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tpf, int M,

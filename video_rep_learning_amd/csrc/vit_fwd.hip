@@ -12,6 +12,8 @@
 namespace {
 enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
 
+// MVF_LN_INKERNEL=0: keep the ln_stats_finalize launch in front of the folded-LayerNorm GEMMs (A/B measurements)
+const bool g_ln_inkernel = []{ const char* e = getenv("MVF_LN_INKERNEL"); return e == nullptr || e[0] != '0'; }();
 // MVF_PROJ_DEFER=0: keep the proj GEMM's read-modify epilogue (A/B measurements)
 const bool g_proj_defer = []{ const char* e = getenv("MVF_PROJ_DEFER"); return e == nullptr || e[0] != '0'; }();
 
@@ -79,7 +81,10 @@ int timed_gemm(int dtype, int epi, const void* A, int lda, const void* W, int ld
                                          f8->addend2, f8->ld2)
                      : mvf_gemm_tc_impl(dtype, epi, A, lda, W, ldw, bias, C, ldc, resid, ldr, tap, ldt, pos, ls, tpf, M, N, K, st, 0,
                                         0, ln);
-  if (rec) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
+  if (rec) {
+    if (rc == MVF_ERR_UNSUPPORTED) --g_prof.used;     // nothing was launched (the caller takes another form): give the slot back
+    else (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
+  }
   return rc;
 }
 
@@ -187,10 +192,20 @@ int run_blocks(const MvfVitWeights* w, int dtype, bool fp8, const Ws& ws, int fc
     }
     if (folded(w->qkv_c, l)) {
       if (l == l0) return MVF_ERR_ARG;   // nothing in this call produced the layer's statistics
-      RUN(mvf_ln_stats_finalize_impl(ws.stats, ns, ws.mr, Mc, D, w->ln_eps, st));
-      const MvfGemmLn ln = {nullptr, 0, nullptr, ws.mr, w->qkv_c[l], 0, nullptr};
-      RUN(timed_gemm(dtype, EPI_STORE, ws.xb, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0,
-                     nullptr, nullptr, N, Mc, 3 * D, D, st, &ln));
+      // the GEMM turns the producer's partial sums into (mean, rstd) itself (no finalize launch between fc2 and qkv); shapes it
+      // cannot stage (more than 12 slices: D > 768, an odd row count) keep the small kernel
+      const MvfGemmLn lp = {nullptr, 0, nullptr, nullptr, w->qkv_c[l], 0, nullptr, nullptr, 0, ws.stats, ns, w->ln_eps};
+      rc = g_ln_inkernel ? timed_gemm(dtype, EPI_STORE, ws.xb, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0,
+                                      nullptr, nullptr, N, Mc, 3 * D, D, st, &lp)
+                         : MVF_ERR_UNSUPPORTED;
+      if (rc == MVF_ERR_UNSUPPORTED) {
+        RUN(mvf_ln_stats_finalize_impl(ws.stats, ns, ws.mr, Mc, D, w->ln_eps, st));
+        const MvfGemmLn ln = {nullptr, 0, nullptr, ws.mr, w->qkv_c[l], 0, nullptr};
+        RUN(timed_gemm(dtype, EPI_STORE, ws.xb, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0,
+                       nullptr, nullptr, N, Mc, 3 * D, D, st, &ln));
+      } else if (rc != MVF_OK) {
+        return rc;
+      }
     } else {
       RUN(mvf_layernorm_impl(dtype, ws.x, D, w->ln1_w[l], w->ln1_b[l], ws.h, D, Mc, D, w->ln_eps, st));
       RUN(timed_gemm(dtype, EPI_STORE, ws.h, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0,
@@ -212,10 +227,18 @@ int run_blocks(const MvfVitWeights* w, int dtype, bool fp8, const Ws& ws, int fc
                      nullptr, w->ls1 ? w->ls1[l] : nullptr, N, Mc, D, D, st, fold2 ? &ln : nullptr));
     }
     if (fold2) {
-      RUN(mvf_ln_stats_finalize_impl(ws.stats, ns, ws.mr, Mc, D, w->ln_eps, st));
-      const MvfGemmLn ln = {nullptr, 0, nullptr, ws.mr, w->fc1_c[l], 0, nullptr};
-      RUN(timed_gemm(dtype, EPI_GELU, ws.xb, D, w->fc1_w[l], D, w->fc1_b[l], ws.hid, 4 * D, nullptr, 0, nullptr, 0,
-                     nullptr, nullptr, N, Mc, 4 * D, D, st, &ln));
+      const MvfGemmLn lp = {nullptr, 0, nullptr, nullptr, w->fc1_c[l], 0, nullptr, nullptr, 0, ws.stats, ns, w->ln_eps};
+      rc = g_ln_inkernel ? timed_gemm(dtype, EPI_GELU, ws.xb, D, w->fc1_w[l], D, w->fc1_b[l], ws.hid, 4 * D, nullptr, 0, nullptr, 0,
+                                      nullptr, nullptr, N, Mc, 4 * D, D, st, &lp)
+                         : MVF_ERR_UNSUPPORTED;
+      if (rc == MVF_ERR_UNSUPPORTED) {
+        RUN(mvf_ln_stats_finalize_impl(ws.stats, ns, ws.mr, Mc, D, w->ln_eps, st));
+        const MvfGemmLn ln = {nullptr, 0, nullptr, ws.mr, w->fc1_c[l], 0, nullptr};
+        RUN(timed_gemm(dtype, EPI_GELU, ws.xb, D, w->fc1_w[l], D, w->fc1_b[l], ws.hid, 4 * D, nullptr, 0, nullptr, 0,
+                       nullptr, nullptr, N, Mc, 4 * D, D, st, &ln));
+      } else if (rc != MVF_OK) {
+        return rc;
+      }
     } else {
       RUN(mvf_layernorm_impl(dtype, ws.x, D, w->ln2_w[l], w->ln2_b[l], ws.h, D, Mc, D, w->ln_eps, st, defer ? ws.delta : nullptr, D));
       RUN(timed_gemm(dtype, EPI_GELU, ws.h, D, w->fc1_w[l], D, w->fc1_b[l], ws.hid, 4 * D, nullptr, 0, nullptr, 0,
@@ -347,6 +370,13 @@ extern "C" int mvf_gemm_tc_ln(int dtype, int epi, const void* A, int lda, const 
                               float* stats, const float* ln_mr, const float* ln_c, int M, int N, int K, hipStream_t st) {
   const MvfGemmLn ln = {xb, ldxb, stats, ln_mr, ln_c, 0, nullptr};
   return mvf_gemm_tc_impl(dtype, epi, A, lda, W, ldw, bias, C, ldc, resid, ldr, tap, ldt, nullptr, ls, tpf, M, N, K, st, 0, 0, &ln);
+}
+// mvf_gemm_tc_ln's consumer side (epi 0 / 1) fed with the producer's PARTIAL sums [ns][M][2] instead of (mean, rstd): the persistent
+// 256x256 kernel finalizes them itself; MVF_ERR_UNSUPPORTED where it cannot (ns > 12, odd M, K < 256, pinned 128x128 kernel)
+extern "C" int mvf_gemm_tc_ln_part(int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
+                                   const float* part, int ns, float eps, const float* ln_c, int M, int N, int K, hipStream_t st) {
+  const MvfGemmLn ln = {nullptr, 0, nullptr, nullptr, ln_c, 0, nullptr, nullptr, 0, part, ns, eps};
+  return mvf_gemm_tc_impl(MVF_BF16, epi, A, lda, W, ldw, bias, C, ldc, nullptr, 0, nullptr, 0, nullptr, nullptr, 1, M, N, K, st, 0, 0, &ln);
 }
 extern "C" int mvf_gemm_fp8(int epi, const void* A, int lda, const unsigned* sa, const void* W, int ldw, const unsigned* sw,
                             const float* bias, void* C, int ldc, unsigned* c_scales, float* resid, int ldr, void* tap, int ldt,

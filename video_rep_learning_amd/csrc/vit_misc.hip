@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __r
     s2 += v.y;
   }
   const float mean = s1 * inv_d;
-  const float var = fmaxf(s2 * inv_d - mean * mean, 0.f);
+  const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * inv_d), 0.f);   // (spelled as in gemm_tc256's in-kernel finalize)
   reinterpret_cast<float2*>(mr)[row] = make_float2(mean, 1.0f / sqrtf(var + eps));
 }
 

@@ -357,6 +357,10 @@ int mvf_scl_fwd(const float* emb, const float* step, const float* len, const flo
 int mvf_scl_bwd(const float* emb, const float* step, const float* len, const float* mask, const float* S, const float* R,
                 const float* c, const float* gout, float* dE, int M, int E, int T, int row0, int rows, int negative_flags,
                 float temperature, float label_variance, hipStream_t stream);
+/* E = 64 | 128 | 256 run the pair similarities (and the gradient's coefficient x embedding product) on v_mfma_f32_16x16x4_f32, exact
+ * fp32: at the gathered size of 8 ranks (M = 2 048, configs[2]) 0.35 + 4.5 ms -> see profiles/r04/scl_gathered.txt.  form = 1 pins the
+ * scalar kernels (any E <= 256; tests, A/B measurements), 0 restores the automatic choice. */
+int mvf_scl_select(int form);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser: global-norm clip + Adam(L2) on one flat buffer (train.py:124-133,147-149; utils/optimizer.py:60-66)

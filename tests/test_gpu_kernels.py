@@ -1143,6 +1143,45 @@ def test_scl_row_slice():
     check(ed2.grad[M // 2:], 2.0 * full[M // 2:], 1e-6, 'scl row slice')
 
 
+@pytest.mark.parametrize('b,t,e,pad,neg', [(4, 32, 128, 12, 'batch_noself'), (4, 32, 256, 5, 'batch_noself'), (2, 8, 64, 3, 'single_noself'),
+                                           (3, 8, 128, 0, 'batch'), (1, 8, 128, 2, 'single'), (4, 32, 128, 0, 'single_noself'),
+                                           (2, 24, 128, 4, 'batch_noself')])
+def test_scl_matrix_core_form_equals_the_scalar_form(b, t, e, pad, neg):
+    """mvf_scl_fwd / _bwd on v_mfma_f32_16x16x4_f32 (E = 64 | 128 | 256) against the scalar kernels (mvf_scl_select 1) and the
+    fp64 oracle: every negative type, padded videos, 16-row blocks that straddle two views (T = 8) or are cut by the row count
+    (T = 24: M = 96), row slices; and a second run is bitwise the first (fixed summation order, no atomics)."""
+    embs, seq_lens, steps, masks = C.scl_inputs(b, t, e, 777, pad)
+    lens = seq_lens.view(b, 2, 1).expand(b, 2, t)
+    M = b * 2 * t
+    res = {}
+    for form in (1, 0, 0):
+        _lib.call('mvf_scl_select', form)
+        try:
+            ed = _leaf(embs.reshape(-1, e))
+            loss = ops.scl_loss(ed, steps.to(DEV), lens.to(DEV), masks.to(DEV), t, neg, 0.1, 10.0)
+            loss.backward()
+            sl = None
+            if M % 32 == 0:
+                e2 = _leaf(embs.reshape(-1, e))
+                ops.scl_loss(e2, steps.to(DEV), lens.to(DEV), masks.to(DEV), t, neg, 0.1, 10.0, row0=M // 2, rows=M // 2).backward()
+                sl = e2.grad.clone()
+        finally:
+            _lib.call('mvf_scl_select', 0)
+        if form == 0 and 0 in res:
+            assert torch.equal(loss.detach(), res[0][0]) and torch.equal(ed.grad, res[0][1])
+        res[form] = (loss.detach().clone(), ed.grad.clone(), sl)
+    check(res[0][0], res[1][0], 2e-6, 'scl loss, matrix-core vs scalar form')
+    check(res[0][1], res[1][1], 2e-5, 'scl dE, matrix-core vs scalar form')
+    if res[0][2] is not None:
+        assert res[0][2][:M // 2].abs().max().item() == 0.0
+        check(res[0][2][M // 2:], res[0][1][M // 2:], 1e-6, 'row slice')
+    er = embs.double().requires_grad_(True)
+    lo = OS.scl_loss(er, seq_lens, steps, masks, negative_type=neg)
+    lo.backward()
+    check(res[0][0], lo, 1e-5, 'scl loss (oracle fp64)')
+    check(res[0][1].view(b, 2, t, e), er.grad, 2e-4, 'scl dE (oracle fp64)')
+
+
 @pytest.mark.parametrize('rank', [0, 5])
 def test_scl_at_the_gathered_size_of_eight_ranks(rank):
     """BASELINE configs[2] (cross-GPU embedding all-gather, 8 ranks x 4 videos): the loss over the W * 256 = 2 048 gathered rows

@@ -95,6 +95,7 @@ SIGNATURES = {
     'mvf_scl_rows': 'ppppiip',
     'mvf_scl_fwd': 'pppppppppiiiiffp',
     'mvf_scl_bwd': 'pppppppppiiiiiiffp',
+    'mvf_scl_select': 'i',
     'mvf_grad_norm': 'pzpppp',
     'mvf_adam_step': 'ppppzfffffifpfip',
     'mvf_augment_workspace_bytes': 'iii',

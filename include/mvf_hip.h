@@ -27,6 +27,10 @@ extern "C" {
 #define MVF_F32 0
 #define MVF_BF16 1
 #define MVF_FP8 2   /* mvf_vit_fwd only: MX-fp8 GEMM operands (OCP e4m3 + E8M0 scale per 32 k), bf16 everywhere else */
+#define MVF_F16 3   /* frozen backbone (mvf_vit_fwd, mvf_gemm_tc*, mvf_vit_attn_fwd, mvf_layernorm*_fwd, mvf_patchify): IEEE fp16 operands and
+                     * activations -- the reference's own autocast dtype (CARL_MVF/train.py:113,301) -- on v_mfma_f32_16x16x32_f16, fp32
+                     * accumulation and residual stream; the tapped features are still written as bf16.  K % 128 == 0, N % 32 == 0 (the
+                     * 256x256 kernel only); trainable backbone blocks and MX-fp8 do not combine with it. */
 
 /* gemm_tc epilogues */
 #define MVF_EPI_STORE 0 /* C = A W^T + b                                  */
@@ -196,6 +200,7 @@ int mvf_layernorm_fwd(int out_dtype, const float* x, size_t in_stride, const flo
  * 4 = streamed 64-key blocks */
 int mvf_vit_attn_fwd(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t stream);
 int mvf_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t stream);
+int mvf_cast_f32_f16(const float* in, void* out, size_t n, hipStream_t stream);      /* IEEE half, round to nearest even; n % 4 == 0 */
 int mvf_cast_bf16_f32(const void* in, float* out, size_t n, hipStream_t stream);     /* n % 4 == 0 */
 /* ViT attention of a TRAINABLE block in bf16 (timm Attention inside ViTBackEnd, models/transformer.py:364-392; fp16 autocast
  * in the reference): forward = mvf_vit_attn_fwd on the streamed kernel, also writing the per-query log2-domain log-sum-exp

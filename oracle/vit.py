@@ -114,6 +114,15 @@ def bf16_round(x):
     return x.to(torch.bfloat16).to(x.dtype)
 
 
+def _bf16_round_true(x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+def f16_round(x):
+    """Round-to-nearest-even to IEEE fp16 and back (v_cvt_pk_f16_f32); overflows to inf beyond 65504 like the device."""
+    return x.to(torch.float16).to(x.dtype)
+
+
 def _ident(x):
     return x
 
@@ -245,13 +254,23 @@ def vit_forward(img, w, heads, patch, taps=(3, 7, 11), eps=1e-6, first_block=0, 
     """
     depth = 1 + max(int(k.split('.')[1]) for k in w if k.startswith('blocks.'))
     last_block = depth if last_block is None else last_block
+    if emulate == 'fp16':
+        # MI355X.COMPUTE_DTYPE fp16 (the reference's own autocast dtype, CARL_MVF/train.py:113,301): the data flow and rounding POINTS
+        # of the bf16 mode with IEEE fp16 as the 16-bit format at every one of them -- except the tapped block outputs, which the
+        # product still hands to the head as bf16
+        global bf16_round
+        saved, bf16_round = bf16_round, f16_round
+        try:
+            return vit_forward(img, w, heads, patch, taps, eps, first_block, last_block, x_in, emulate='bf16')
+        finally:
+            bf16_round = saved
     assert emulate in (None, 'bf16', 'bf16_fold12', 'bf16_nofold', 'fp8'), emulate
     x = vit_embed(img, w, patch, emulate) if x_in is None else x_in
     feats = {}
     for i in range(first_block, last_block):
         x = vit_block(x, w, 'blocks.%d.' % i, heads, eps, emulate)
         if i in taps:
-            feats[i] = bf16_round(x) if emulate else x      # taps are stored in the compute dtype
+            feats[i] = _bf16_round_true(x) if emulate else x      # taps are stored as bf16 in every reduced-precision mode
     out = layer_norm(x, w['norm.weight'], w['norm.bias'], eps)[:, 0] if last_block == depth else x
     features = torch.cat([feats[i] for i in taps], dim=2) if taps else None
     return features, out

@@ -541,6 +541,128 @@ def test_vit_forward_bf16_error():
         assert ec < 1e-2, ec
 
 
+# ------------------------------------------------------------------------------------------------ fp16 operands (MVF_F16)
+@pytest.mark.parametrize('M,N,K,epi', [(1000, 2304, 768, 0), (197 * 40 + 6, 3072, 768, 1), (25216, 768, 3072, 2), (777, 768, 768, 3)])
+def test_gemm_fp16_operands_vs_fp64(M, N, K, epi):
+    """The 256x256 kernel's fp16 instantiations (v_mfma_f32_16x16x32_f16, v_cvt_pk_f16_f32 stores): every epilogue of the frozen
+    backbone against fp64 arithmetic on the SAME fp16 operands -- plain / GELU store, the LN-fold consumer fed with partial sums,
+    the residual epilogue with the fp16 second addend, fp16 xb, row sums and a BF16 tap, the patch scatter.  One fp16 ulp
+    (2^-11 relative) of the largest output is the bound; ragged last tiles, > 256 tiles (25216 x 768: tickets)."""
+    g = gen(71)
+    A = (torch.randn(M, K, generator=g) * 1.5).to(DEV).to(torch.float16)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(DEV).to(torch.float16)
+    b = torch.randn(N, generator=g).to(DEV)
+    Ad, Wd, bd = A.double().cpu(), W.double().cpu(), b.double().cpu()
+    ref = Ad @ Wd.t() + bd
+    half = lambda t: t.to(torch.float16)
+    if epi in (0, 1):
+        C = torch.full((M, N), 7.0, device=DEV, dtype=torch.float16)
+        _lib.call('mvf_gemm_tc', _lib.F16, epi, A.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), C.data_ptr(), N, None, 0, None, 0,
+                  None, None, 197, M, N, K, S())
+        want = OV.gelu_erf(ref) if epi == 1 else ref
+        assert relerr(C.float(), want) <= 6e-4, relerr(C.float(), want)
+        # LN-fold consumer, statistics from partial sums inside the kernel
+        ns = K // 64
+        xs = A.float().view(M, ns, 64)
+        part = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).permute(1, 0, 2).contiguous()
+        c = W.double().sum(1).float()
+        mean = A.double().mean(-1).cpu()
+        rstd = (1.0 / torch.sqrt(A.double().var(-1, unbiased=False) + 1e-6)).cpu()
+        C2 = torch.full((M, N), 7.0, device=DEV, dtype=torch.float16)
+        _lib.call('mvf_gemm_tc_ln', _lib.F16, epi, A.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), C2.data_ptr(), N, None, 0, None, 0,
+                  None, 197, None, 0, None, torch.stack([mean, rstd], 1).float().to(DEV).data_ptr(), c.data_ptr(), M, N, K, S())
+        want2 = rstd[:, None] * (Ad @ Wd.t() - mean[:, None] * c.double().cpu()) + bd
+        want2 = OV.gelu_erf(want2) if epi == 1 else want2
+        assert relerr(C2.float(), want2) <= 1.2e-3, relerr(C2.float(), want2)     # (operand cancellation mean * c vs acc: 2 ulp)
+    elif epi == 2:
+        x0 = (torch.randn(M, N, generator=g) * 3.0).to(DEV)
+        delta = half(torch.randn(M, N, generator=g)).to(DEV)
+        x = x0.clone()
+        xb = torch.full((M, N), 7.0, device=DEV, dtype=torch.float16)
+        stats = torch.full((N // 64, M, 2), -1.0, device=DEV)
+        tpf = 197
+        tap = torch.zeros((M // tpf) * (tpf - 1), N, device=DEV, dtype=torch.bfloat16)
+        lib = _lib.load()
+        # the product's fc2 form: mvf_gemm_tc_ln has no second addend -- go through the backbone's own entry in the model test;
+        # here: resid += A W^T + b, xb / stats / tap out
+        _lib.call('mvf_gemm_tc_ln', _lib.F16, 2, A.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), None, 0, x.data_ptr(), N,
+                  tap.data_ptr(), N, None, tpf, xb.data_ptr(), N, stats.data_ptr(), None, None, M, N, K, S())
+        torch.cuda.synchronize()
+        want = x0.double().cpu() + ref
+        assert relerr(x, want) <= 2e-6 * 50, relerr(x, want)            # fp32 residual: accumulation-order noise only
+        assert torch.equal(xb, x.to(torch.float16)), 'xb is not fp16(x)'
+        assert torch.equal(tap, x.to(torch.bfloat16).view(M // tpf, tpf, N)[:, 1:].reshape(-1, N)), 'tap is not bf16(x)'
+        xs = x.double().view(M, N // 64, 64)
+        check(stats[..., 0].t(), xs.sum(-1), 1e-5, 'partial sums')
+    else:
+        np_ = 196
+        Mp = (M // np_) * np_
+        pos = torch.randn(np_ + 1, N, generator=g).to(DEV)
+        x = torch.zeros((Mp // np_) * (np_ + 1), N, device=DEV)
+        _lib.call('mvf_gemm_tc', _lib.F16, 3, A.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), None, 0, x.data_ptr(), N, None, 0,
+                  pos.data_ptr(), None, np_ + 1, Mp, N, K, S())
+        want = (ref[:Mp].view(-1, np_, N) + pos.double().cpu()[1:]).reshape(-1, N)
+        got = x.view(-1, np_ + 1, N)[:, 1:].reshape(-1, N)
+        assert relerr(got, want) <= 1e-4, relerr(got, want)
+
+
+@pytest.mark.parametrize('N', [197, 208, 257, 50])
+def test_vit_attention_fp16(N):
+    """fp16 q / k / v / out on the two-tile kernel (N = 193 .. 208) and the streamed kernel (any N) against fp64 softmax attention on
+    the same fp16 inputs: the probabilities fed to P.V are rounded to fp16 (11 bits), so the bound is a few fp16 ulps."""
+    F, H, D = 3, 2, 128
+    qkv = (torch.randn(F * N, 3 * D, generator=gen(72)) * 0.8).to(DEV).to(torch.float16)
+    out = torch.full((F * N, D), 7.0, device=DEV, dtype=torch.float16)
+    _lib.call('mvf_vit_attn_fwd', _lib.F16, qkv.data_ptr(), out.data_ptr(), F, N, H, D, 0, S())
+    q, k, v = qkv.double().cpu().view(F, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) @ v).transpose(1, 2).reshape(F * N, D)
+    assert relerr(out.float(), ref) <= 2e-3, relerr(out.float(), ref)
+    assert rel_l2(out.float(), ref) <= 5e-4, rel_l2(out.float(), ref)
+
+
+def test_patchify_and_layernorm_fp16():
+    g = gen(73)
+    img = torch.randn(3, 3, 32, 32, generator=g).to(DEV)
+    out = torch.empty(3 * 4, 3 * 16 * 16, device=DEV, dtype=torch.float16)
+    _lib.call('mvf_patchify', _lib.F16, img.data_ptr(), out.data_ptr(), 3, 32, 32, 16, S())
+    assert torch.equal(out, OV.patchify(img.cpu(), 16).reshape(12, -1).to(torch.float16).to(DEV))
+    rows, D = 777, 768
+    x = (torch.randn(rows, D, generator=g) * 2 + 0.5).to(DEV)
+    add = torch.randn(rows, D, generator=g).to(DEV).to(torch.float16)
+    gam, bet = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV), (0.1 * torch.randn(D, generator=g)).to(DEV)
+    y = torch.empty(rows, D, device=DEV, dtype=torch.float16)
+    _lib.call('mvf_layernorm_fwd', _lib.F16, x.data_ptr(), D, gam.data_ptr(), bet.data_ptr(), y.data_ptr(), D, rows, D, 1e-6, S())
+    check(y.float(), OV.layer_norm(x.double().cpu(), gam.double().cpu(), bet.double().cpu(), 1e-6), 6e-4, 'LayerNorm -> fp16')
+    _lib.call('mvf_layernorm_add_fwd', _lib.F16, x.data_ptr(), D, add.data_ptr(), D, gam.data_ptr(), bet.data_ptr(), y.data_ptr(), D,
+              rows, D, 1e-6, S())
+    check(y.float(), OV.layer_norm((x.double() + add.double()).cpu(), gam.double().cpu(), bet.double().cpu(), 1e-6), 6e-4,
+          'LayerNorm(x + fp16 addend) -> fp16')
+
+
+def test_vit_forward_fp16_error():
+    """MI355X.COMPUTE_DTYPE fp16 -- the reference's own autocast dtype (CARL_MVF/train.py:113,301): ViT-B/16 taps against the oracle
+    that rounds to fp16 where the kernels store fp16 (oracle/vit.py emulate='fp16'; the taps themselves are bf16 in both), and --
+    reported, with the bf16 mode's figure beside it -- against the fp32 oracle."""
+    from conftest import record_parity
+    dim, depth, heads, patch, img, F = 768, 12, 12, 16, 224, 2
+    w = OV.init_vit_weights(dim, depth, patch, img, seed=11)
+    x = torch.randn(F, 3, img, img, generator=gen(12))
+    with torch.no_grad():
+        feats, _ = OV.vit_forward(x, w, heads, patch, (3, 7, 11))
+        feats16, _ = OV.vit_forward(x, w, heads, patch, (3, 7, 11), emulate='fp16')
+    got, gcls = ops.vit_forward(x.to(DEV), _pack(w, depth, dim, heads, patch, img, (3, 7, 11), 'fp16'))
+    gotb, _ = ops.vit_forward(x.to(DEV), _pack(w, depth, dim, heads, patch, img, (3, 7, 11), 'bf16'))
+    for j in range(3):
+        r32 = feats[:, 1:, j * dim:(j + 1) * dim].reshape(-1, dim)
+        r16 = feats16[:, 1:, j * dim:(j + 1) * dim].reshape(-1, dim)
+        l16, l32, lb = rel_l2(got[j].float(), r16), rel_l2(got[j].float(), r32), rel_l2(gotb[j].float(), r32)
+        record_parity('fp16 ViT-B/16 tap %d: rel-L2 %.3e vs fp16-emulating oracle, %.3e vs fp32 oracle (bf16 mode vs fp32 oracle: %.3e)'
+                      % ((3, 7, 11)[j], l16, l32, lb))
+        assert got[j].dtype == torch.bfloat16
+        # both sides end in the taps' bf16 rounding (2^-9 relative, rel-L2 ~ 1.1e-3 of its own when the fp32 values differ at all)
+        assert l16 < 2.5e-3 and l32 < 3e-3 and l32 < lb, (l16, l32, lb)
+
+
 @pytest.mark.parametrize('M,D,K', [(1000, 768, 3072), (300, 256, 256), (513, 1024, 1024)])
 def test_deferred_residual_layernorm_add_and_second_addend(M, D, K):
     """The two consumers of the deferred attention-branch output: LayerNorm(x + delta) with a bf16 delta (x untouched) and the

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MVF_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libmvf_hip.so')
 
-F32, BF16, FP8 = 0, 1, 2
+F32, BF16, FP8, F16 = 0, 1, 2, 3
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_PATCH = 0, 1, 2, 3
 
 _P, _I, _L, _Z, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t, ctypes.c_float
@@ -51,6 +51,7 @@ SIGNATURES = {
     'mvf_layernorm_fwd': 'ipzpppziifp',
     'mvf_vit_attn_fwd': 'ippiiiiip',
     'mvf_cast_f32_bf16': 'ppzp',
+    'mvf_cast_f32_f16': 'ppzp',
     'mvf_cast_bf16_f32': 'ppzp',
     'mvf_vit_attn_fwd_lse': 'pppiiiip',
     'mvf_vit_attn_bwd': 'ppppppiiiiip',

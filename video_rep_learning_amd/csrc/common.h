@@ -39,6 +39,42 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
+// ---- fp16 operands (MI355X.COMPUTE_DTYPE fp16: the reference's own autocast dtype, CARL_MVF/train.py:113,301) ----
+// Raw IEEE half bits travel as uint16_t like bf16 does; which of the two a buffer holds is a template parameter (`F16`) of the
+// kernels that touch it.  Conversions round to nearest even (v_cvt_f16_f32 / v_cvt_pk_f16_f32; NOT the round-toward-zero pkrtz).
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_native_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_native_t;
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+  const f16x2_native_t v = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float f16_to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ uint16_t f32_to_f16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+// two fp32 -> one dword of the 16-bit format, and back
+template <bool F16>
+__device__ __forceinline__ uint32_t pack16x2(float lo, float hi) {
+  if constexpr (F16) return pack_f16x2(lo, hi);
+  else return pack_bf16x2(lo, hi);
+}
+template <bool F16>
+__device__ __forceinline__ void unpack16x2(uint32_t u, float& lo, float& hi) {
+  if constexpr (F16) {
+    const f16x2_native_t v = __builtin_bit_cast(f16x2_native_t, u);
+    lo = (float)v[0]; hi = (float)v[1];
+  } else {
+    lo = __uint_as_float(u << 16); hi = __uint_as_float(u & 0xffff0000u);
+  }
+}
+// D = A . B + C on the 16x16x32 matrix instruction of the format (same operand lane maps, same cycles)
+template <bool F16>
+__device__ __forceinline__ f32x4_t mfma16x16x32(const bf16x8_t& a, const bf16x8_t& b, const f32x4_t& c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_native_t, a), __builtin_bit_cast(f16x8_native_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+struct f16_t { uint16_t bits; };   // distinct element type for the kernels templated on their 16-bit / fp32 element (Elem<T>)
+
 template <typename T>
 struct Elem;
 template <>
@@ -50,6 +86,12 @@ template <>
 struct Elem<bf16_t> {
   static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
   static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+template <>
+struct Elem<f16_t> {
+  static __device__ __forceinline__ float ld(const f16_t* p) { return f16_to_f32(p->bits); }
+  static __device__ __forceinline__ void st(f16_t* p, float v) { p->bits = f32_to_f16(v); }
 };
 
 // ---- 64-lane wave reductions (butterfly over DPP/ds_swizzle via __shfl_xor) ----

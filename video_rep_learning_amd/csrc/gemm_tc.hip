@@ -220,6 +220,8 @@ int dispatch(int epi, const GemmTcArgs& a, hipStream_t st) {
 int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C,
                      int ldc, float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tpf, int M,
                      int N, int K, hipStream_t st, int batch_rows, int w_batch_rows, const MvfGemmLn* ln) {
+  const bool f16 = dtype == MVF_F16;     // fp16 operands: the 256x256 kernel's F16 instantiations, nothing else
+  if (f16) dtype = MVF_BF16;             // (same element size, alignment rules and epilogues as bf16 from here on)
   const int esz = dtype == MVF_BF16 ? 2 : 4;
   const int ke = ROWB / esz;
   MVF_CHECK_ARG(dtype == MVF_BF16 || dtype == MVF_F32);
@@ -238,10 +240,11 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
   a.sched = nullptr;   // set by the persistent gemm_tc256 launch
   a.batch_rows = batch_rows; a.w_batch_rows = w_batch_rows;
   a.xb = nullptr; a.ldxb = 0; a.stats = nullptr; a.ln_mr = nullptr; a.ln_c = nullptr;
-  a.ln_part = nullptr; a.ln_ns = 0; a.ln_inv_d = 0.f; a.ln_eps = 0.f; a.ngroup = 0;
+  a.ln_part = nullptr; a.ln_ns = 0; a.ln_inv_d = 0.f; a.ln_eps = 0.f; a.ngroup = 0; a.f16 = 0;
   a.sa = nullptr; a.sw = nullptr; a.csc = nullptr;
   a.radd = resid;
   a.radd2 = nullptr; a.ldr2 = 0;
+  a.f16 = f16 ? 1 : 0;
   if (ln != nullptr && ln->addend2 != nullptr) {
     MVF_CHECK_ARG(epi == EPI_RESID && dtype == MVF_BF16 && ((uintptr_t)ln->addend2 % 8) == 0 && ln->ld2 % 4 == 0 && ln->ld2 >= N);
     a.radd2 = (const bf16_t*)ln->addend2; a.ldr2 = ln->ld2;
@@ -269,8 +272,10 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
     if (!(dtype == MVF_BF16 && g_variant != 1 && K % 128 == 0 && N % 32 == 0)) return MVF_ERR_UNSUPPORTED;
   }
   // bf16 with K a multiple of 128: the 256x256 8-phase kernel (gemm_tc256.hip); g_variant 1 pins the 128x128 kernel
+  if (f16 && !(g_variant != 1 && K % 128 == 0 && N % 32 == 0 && batch_rows == 0)) return MVF_ERR_UNSUPPORTED;
   if (dtype == MVF_BF16 && g_variant != 1 && K % 128 == 0 && N % 32 == 0) {
     const int rc = mvf_gemm_tc256_launch(epi, a, /*persistent=*/g_variant != 3, st);
+    if (f16) return rc;
     // operands of 4 GiB or more are beyond the 256x256 kernel's 32-bit offsets: the 128x128 kernel (64-bit addressing)
     // takes over unless the caller pinned the kernel or asked for stacked batches
     if (rc != MVF_ERR_UNSUPPORTED || g_variant >= 2 || batch_rows != 0) return rc;
@@ -298,7 +303,7 @@ int mvf_gemm_fp8_impl(int epi, const void* A, int lda, const unsigned* sa, const
   a.pos = nullptr; a.ls = ls; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.ldt = ldt; a.M = M; a.N = N; a.K = K; a.tpf = tpf;
   a.dbg = nullptr; a.dbg_rowmask = 0x7fffffffu; a.dbg_kt = -1; a.dbg_abl = 0; a.sched = nullptr; a.batch_rows = 0; a.w_batch_rows = 0;
   a.xb = nullptr; a.ldxb = 0; a.stats = nullptr; a.ln_mr = nullptr; a.ln_c = nullptr;
-  a.ln_part = nullptr; a.ln_ns = 0; a.ln_inv_d = 0.f; a.ln_eps = 0.f; a.ngroup = 0;
+  a.ln_part = nullptr; a.ln_ns = 0; a.ln_inv_d = 0.f; a.ln_eps = 0.f; a.ngroup = 0; a.f16 = 0;
   a.sa = sa; a.sw = sw; a.csc = c_scales; a.radd = resid; a.radd2 = nullptr; a.ldr2 = 0;
   if (addend2 != nullptr) {
     MVF_CHECK_ARG(epi == EPI_RESID && ((uintptr_t)addend2 % 8) == 0 && ld2 % 4 == 0 && ld2 >= N);

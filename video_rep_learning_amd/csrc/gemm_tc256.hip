@@ -153,7 +153,9 @@ __device__ __forceinline__ void mfma_mx(f32x4_t& acc, const i32x8_t& w, const i3
 // of each wave row (wave rows of 112 rows: A1 holds 48 live rows per wave row, its P2 / P3 issue 12 MFMAs instead of 16).  The
 // launch picks it where ceil(tiles / workgroups) x BMT is smaller: the N = 768 GEMMs of 50 432 rows are 591 tiles = 2.31 rounds at
 // 256 rows and 678 tiles = 2.65 rounds at 224 -- three rounds either way, of 12.5 % less work each.
-template <int EPI, bool DBG, bool LN, bool FP8, int ABL = 0, bool ADD2 = false, int BMT = 256>   // ABL: timing ablations (dbg_abl)
+// F16: the 16-bit operands / outputs are IEEE fp16 (v_mfma_f32_16x16x32_f16, v_cvt_pk_f16_f32) instead of bf16 -- the reference's
+// own autocast dtype (CARL_MVF/train.py:113,301): same instruction rate, three more mantissa bits, 5-bit exponent
+template <int EPI, bool DBG, bool LN, bool FP8, int ABL = 0, bool ADD2 = false, int BMT = 256, bool F16 = false>   // ABL: timing ablations (dbg_abl)
 __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(BMT == 256 || BMT == 240 || BMT == 224 || BMT == 208, "tile rows");   // (192: correct, slower -- 11.92 vs 11.48 ms/step)
@@ -437,8 +439,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
     _Pragma("unroll") for (int i = 0; i < ((MQ) == 1 ? RTA : 4); ++i)                                         \
       if (RTA == RTB || (MQ) == 0 || i < rt1) /* unequal wave rows: wave row 1 skips its missing fragment (wave-uniform) */ \
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
-      acc[(MQ) * 4 + i][(NQ) * 2 + j] =                                                                      \
-          __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][ks], af[i][ks], acc[(MQ) * 4 + i][(NQ) * 2 + j], 0, 0, 0); \
+      acc[(MQ) * 4 + i][(NQ) * 2 + j] = mfma16x16x32<F16>(BF[j][ks], af[i][ks], acc[(MQ) * 4 + i][(NQ) * 2 + j]);     \
   }                                                                                                          \
   __builtin_amdgcn_s_setprio(0);
 
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
         const int m = m0 + wr * WR0 + (i >> 2) * 64 + (i & 3) * 16 + frow;
         if constexpr (ADD2) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) addb[ii][j] = add_bf16x4(addb[ii][j], add2[ii][j]);
+          for (int j = 0; j < 4; ++j) addb[ii][j] = add_16x4<F16>(addb[ii][j], add2[ii][j]);
         }
         if constexpr (EPI == EPI_GELU_Q) {
           // the wave's 64 columns of row m = two MX blocks: quantise each, then one 2-byte store of both scales into the
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
           for (int jp = 0; jp < 2; ++jp) {
             const int nb = n0 + wc * 64 + jp * 32;
             // N % 32 == 0: a tile pair is in range or out as a whole
-            epilogue_pair_bf16<EPI>(a, m, m < a.M && nb < a.N, nb, fgrp, acc[i][2 * jp], acc[i][2 * jp + 1], bj[2 * jp],
+            epilogue_pair_bf16<EPI, F16>(a, m, m < a.M && nb < a.N, nb, fgrp, acc[i][2 * jp], acc[i][2 * jp + 1], bj[2 * jp],
                                     bj[2 * jp + 1], kReadModify ? addb[ii][2 * jp] : z4,
                                     kReadModify ? addb[ii][2 * jp + 1] : z4, gj[2 * jp], gj[2 * jp + 1]);
           }
@@ -654,7 +655,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
           for (int jp = 0; jp < 2; ++jp) {
             const int nb = n0 + wc * 64 + jp * 32;
             const float4 c0 = z4, c1 = z4;
-            epilogue_pair_bf16_ln<EPI>(a, m, m < a.M && nb < a.N, nb, fgrp, acc[i][2 * jp], acc[i][2 * jp + 1], bj[2 * jp],
+            epilogue_pair_bf16_ln<EPI, F16>(a, m, m < a.M && nb < a.N, nb, fgrp, acc[i][2 * jp], acc[i][2 * jp + 1], bj[2 * jp],
                                        bj[2 * jp + 1], kReadModify ? addb[ii][2 * jp] : z4,
                                        kReadModify ? addb[ii][2 * jp + 1] : z4, gj[2 * jp], gj[2 * jp + 1], mr, c0, c1, s1, s2);
           }
@@ -755,7 +756,7 @@ unsigned* sched_slot() {
   return ring == nullptr ? nullptr : ring + (size_t)(next.fetch_add(1) & 1023u) * 16;
 }
 
-template <int EPI, bool DBG = false, bool LN = false, bool FP8 = false, int ABL = 0, bool ADD2 = false, int BMT = 256>
+template <int EPI, bool DBG = false, bool LN = false, bool FP8 = false, int ABL = 0, bool ADD2 = false, int BMT = 256, bool F16 = false>
 int launch_bm(const GemmTcArgs& a0, bool persistent, hipStream_t st) {
   GemmTcArgs a = a0;
   {   // weight-panel grouping of the tile list (MVF_GEMM_NGROUP / mvf_gemm_tc_set_ngroup; plain, unbatched launches only)
@@ -772,7 +773,7 @@ int launch_bm(const GemmTcArgs& a0, bool persistent, hipStream_t st) {
   static bool attr_set = false;
   constexpr bool lncons = LN && (EPI == EPI_STORE || EPI == EPI_GELU);
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2, BMT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2, BMT, F16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lncons ? LDS_MAX : LDS_BYTES);
     attr_set = true;
   }
@@ -786,7 +787,7 @@ int launch_bm(const GemmTcArgs& a0, bool persistent, hipStream_t st) {
   // persistent: one workgroup per CU (a multiple of 8 so that every XCD gets the same number); otherwise (A/B
   // measurements) one workgroup per tile -- the same kernel, every workgroup then runs the cold prologue
   const int grid = persistent ? std::min(ntiles, std::max(8, num_cus() & ~7)) : ntiles;
-  hipLaunchKernelGGL((gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2, BMT>), dim3(grid), dim3(512), lds_bytes, st, a);
+  hipLaunchKernelGGL((gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2, BMT, F16>), dim3(grid), dim3(512), lds_bytes, st, a);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }
@@ -823,12 +824,23 @@ int pick_tile_rows(long M, long N, bool persistent) {
 template <int EPI, bool DBG = false, bool LN = false, bool FP8 = false, int ABL = 0, bool ADD2 = false>
 int launch(const GemmTcArgs& a, bool persistent, hipStream_t st) {
   if constexpr (!DBG && !FP8) {
+    if (a.f16) {    // fp16 operands: the plain forms of the frozen backbone only (no stacked batches, no stamps)
+      if (a.batch_rows != 0) return MVF_ERR_UNSUPPORTED;
+      switch (pick_tile_rows(a.M, a.N, persistent)) {
+        case 240: return launch_bm<EPI, DBG, LN, FP8, ABL, ADD2, 240, true>(a, persistent, st);
+        case 224: return launch_bm<EPI, DBG, LN, FP8, ABL, ADD2, 224, true>(a, persistent, st);
+        case 208: return launch_bm<EPI, DBG, LN, FP8, ABL, ADD2, 208, true>(a, persistent, st);
+        default: return launch_bm<EPI, DBG, LN, FP8, ABL, ADD2, 256, true>(a, persistent, st);
+      }
+    }
     if (a.batch_rows == 0) switch (pick_tile_rows(a.M, a.N, persistent)) {
       case 240: return launch_bm<EPI, DBG, LN, FP8, ABL, ADD2, 240>(a, persistent, st);
       case 224: return launch_bm<EPI, DBG, LN, FP8, ABL, ADD2, 224>(a, persistent, st);
       case 208: return launch_bm<EPI, DBG, LN, FP8, ABL, ADD2, 208>(a, persistent, st);
       default: break;
     }
+  } else {
+    if (a.f16) return MVF_ERR_UNSUPPORTED;
   }
   return launch_bm<EPI, DBG, LN, FP8, ABL, ADD2, 256>(a, persistent, st);
 }

@@ -64,6 +64,8 @@ struct GemmTcArgs {
   // tiles, all row panels inside a group, so that an XCD's contiguous chunk of it needs only ngroup W panels (L2-resident)
   // instead of all of them; 0 = row panel major (tiles of one A row panel are neighbours)
   int ngroup;
+  // gemm_tc256: A / W / C / xb / radd2 hold IEEE fp16 instead of bf16 (MI355X.COMPUTE_DTYPE fp16; the taps stay bf16)
+  int f16;
 };
 
 // max over the four lanes that hold one output row (lane, lane^16, lane^32, lane^48), result in all of them
@@ -218,10 +220,11 @@ __device__ __forceinline__ void epilogue4(const GemmTcArgs& a, int m, int n, con
 // registers, after which every lane owns 8 consecutive columns (fgrp 0/2: tile 0 cols 0-7 / 8-15, fgrp 1/3: tile 1):
 // one 16-byte store per lane, 64-byte row segments, half the store instructions, no LDS round trip.
 // Cross-lane: EVERY lane must execute the swaps (rows m >= M are only masked at the store).
+template <bool F16 = false>   // the 16-bit format of the buffer: bf16, or fp16 (COMPUTE_DTYPE fp16)
 __device__ __forceinline__ void swap_store_bf16x8(char* base, size_t row_elem_off, int nb, int fgrp, bool ok,
                                                    const float (&v0)[4], const float (&v1)[4]) {
-  uint32_t x0 = pack_bf16x2(v0[0], v0[1]), x1 = pack_bf16x2(v0[2], v0[3]);
-  uint32_t y0 = pack_bf16x2(v1[0], v1[1]), y1 = pack_bf16x2(v1[2], v1[3]);
+  uint32_t x0 = pack16x2<F16>(v0[0], v0[1]), x1 = pack16x2<F16>(v0[2], v0[3]);
+  uint32_t y0 = pack16x2<F16>(v1[0], v1[1]), y1 = pack16x2<F16>(v1[2], v1[3]);
   const auto r0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
   const auto r1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
   if (ok) {
@@ -267,9 +270,18 @@ __device__ __forceinline__ float4 add_bf16x4(float4 v, uint2 u) {
   v.z += __uint_as_float(u.y << 16); v.w += __uint_as_float(u.y & 0xffff0000u);
   return v;
 }
+template <bool F16>
+__device__ __forceinline__ float4 add_16x4(float4 v, uint2 u) {
+  if constexpr (!F16) return add_bf16x4(v, u);
+  float a, b, c, d;
+  unpack16x2<true>(u.x, a, b);
+  unpack16x2<true>(u.y, c, d);
+  v.x += a; v.y += b; v.z += c; v.w += d;
+  return v;
+}
 
 // add0/add1: the prefetched addends of the two tiles (EPI_RESID / EPI_PATCH), g0/g1: LayerScale (EPI_RESID with a.ls).
-template <int EPI>
+template <int EPI, bool F16 = false>   // F16: C / xb hold fp16 instead of bf16 (the TAPS stay bf16 in either mode: the pooling reads bf16)
 __device__ __forceinline__ void epilogue_pair_bf16(const GemmTcArgs& a, int m, bool ok, int nb, int fgrp,
                                                    const f32x4_t& acc0, const f32x4_t& acc1, const float4& b0,
                                                    const float4& b1, const float4& add0, const float4& add1,
@@ -278,11 +290,11 @@ __device__ __forceinline__ void epilogue_pair_bf16(const GemmTcArgs& a, int m, b
   float v1[4] = {acc1[0] + b1.x, acc1[1] + b1.y, acc1[2] + b1.z, acc1[3] + b1.w};
   const int n0 = nb + fgrp * 4, n1 = nb + 16 + fgrp * 4;   // this lane's own columns in the two tiles
   if constexpr (EPI == EPI_STORE) {
-    swap_store_bf16x8(a.C, (size_t)m * a.ldc, nb, fgrp, ok, v0, v1);
+    swap_store_bf16x8<F16>(a.C, (size_t)m * a.ldc, nb, fgrp, ok, v0, v1);
   } else if constexpr (EPI == EPI_GELU) {
     gelu_erf_fast4(v0);
     gelu_erf_fast4(v1);
-    swap_store_bf16x8(a.C, (size_t)m * a.ldc, nb, fgrp, ok, v0, v1);
+    swap_store_bf16x8<F16>(a.C, (size_t)m * a.ldc, nb, fgrp, ok, v0, v1);
   } else if constexpr (EPI == EPI_RESID) {
     bool tap_ok = false;
     size_t tap_off = 0;
@@ -317,7 +329,7 @@ __device__ __forceinline__ void epilogue_pair_bf16(const GemmTcArgs& a, int m, b
 // The LN-fold form of epilogue_pair_bf16 (a function of its own: the plain kernels keep their exact code and registers).
 // LN fold: `mr` = the row's (mean, rstd) and c0/c1 = ln_c of the two tiles (EPI_STORE / EPI_GELU with a.ln_mr);
 // s1/s2 += sum / sum of squares of the row's new residual values in these two tiles (EPI_RESID with a.stats).
-template <int EPI>
+template <int EPI, bool F16 = false>
 __device__ __forceinline__ void epilogue_pair_bf16_ln(const GemmTcArgs& a, int m, bool ok, int nb, int fgrp,
                                                    const f32x4_t& acc0, const f32x4_t& acc1, const float4& b0,
                                                    const float4& b1, const float4& add0, const float4& add1,
@@ -336,11 +348,11 @@ __device__ __forceinline__ void epilogue_pair_bf16_ln(const GemmTcArgs& a, int m
   }
   const int n0 = nb + fgrp * 4, n1 = nb + 16 + fgrp * 4;   // this lane's own columns in the two tiles
   if constexpr (EPI == EPI_STORE) {
-    swap_store_bf16x8(a.C, (size_t)m * a.ldc, nb, fgrp, ok, v0, v1);
+    swap_store_bf16x8<F16>(a.C, (size_t)m * a.ldc, nb, fgrp, ok, v0, v1);
   } else if constexpr (EPI == EPI_GELU) {
     gelu_erf_fast4(v0);
     gelu_erf_fast4(v1);
-    swap_store_bf16x8(a.C, (size_t)m * a.ldc, nb, fgrp, ok, v0, v1);
+    swap_store_bf16x8<F16>(a.C, (size_t)m * a.ldc, nb, fgrp, ok, v0, v1);
   } else if constexpr (EPI == EPI_RESID) {
     bool tap_ok = false;
     size_t tap_off = 0;
@@ -362,7 +374,7 @@ __device__ __forceinline__ void epilogue_pair_bf16_ln(const GemmTcArgs& a, int m
     }
     if (a.tap != nullptr) swap_store_bf16x8(a.tap, tap_off, nb, fgrp, tap_ok, v0, v1);   // wave-uniform branch
     {
-      if (a.xb != nullptr) swap_store_bf16x8(a.xb, (size_t)m * a.ldxb, nb, fgrp, ok, v0, v1);
+      if (a.xb != nullptr) swap_store_bf16x8<F16>(a.xb, (size_t)m * a.ldxb, nb, fgrp, ok, v0, v1);
       if (a.stats != nullptr) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

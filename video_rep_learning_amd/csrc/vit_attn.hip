@@ -249,7 +249,7 @@ struct NoHook {
 };
 // after_s: called once the S phase's MFMAs are issued and K is no longer read by this wave (hook of the persistent form that
 // was removed in round 3; the default does nothing)
-template <int NT, int NQ, typename AfterS = NoHook>
+template <int NT, int NQ, bool F16 = false, typename AfterS = NoHook>   // F16: q / k / v / out are IEEE fp16 (MVF_F16), else bf16
 __device__ __forceinline__ void attn_tiles(const AttnArgs& a, const char* sk, const char* sv, bf16_t* obase,
                                            const bf16x8_t (&qf)[2][2], const int (&qt)[2], int li, int g, int vsw,
                                            bool wait_v, AfterS after_s = AfterS()) {
@@ -264,7 +264,7 @@ __device__ __forceinline__ void attn_tiles(const AttnArgs& a, const char* sk, co
       const int row = kt * 16 + li;
       const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sk + row * 128 + (((ks * 4 + g) ^ (li & 7)) << 4));
 #pragma unroll
-      for (int i = 0; i < NQ; ++i) s[i][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[i][ks], s[i][kt], 0, 0, 0);
+      for (int i = 0; i < NQ; ++i) s[i][kt] = mfma16x16x32<F16>(kf, qf[i][ks], s[i][kt]);
     }
   }
   after_s();
@@ -313,11 +313,11 @@ __device__ __forceinline__ void attn_tiles(const AttnArgs& a, const char* sk, co
     union { bf16x8_t v; uint32_t u[4]; } pf[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-      pf[i].u[0] = pack_bf16x2(s[i][2 * st][0], s[i][2 * st][1]);
-      pf[i].u[1] = pack_bf16x2(s[i][2 * st][2], s[i][2 * st][3]);
+      pf[i].u[0] = pack16x2<F16>(s[i][2 * st][0], s[i][2 * st][1]);
+      pf[i].u[1] = pack16x2<F16>(s[i][2 * st][2], s[i][2 * st][3]);
       if (2 * st + 1 < NT) {
-        pf[i].u[2] = pack_bf16x2(s[i][2 * st + 1][0], s[i][2 * st + 1][1]);
-        pf[i].u[3] = pack_bf16x2(s[i][2 * st + 1][2], s[i][2 * st + 1][3]);
+        pf[i].u[2] = pack16x2<F16>(s[i][2 * st + 1][0], s[i][2 * st + 1][1]);
+        pf[i].u[3] = pack16x2<F16>(s[i][2 * st + 1][2], s[i][2 * st + 1][3]);
       } else {
         pf[i].u[2] = 0; pf[i].u[3] = 0;
       }
@@ -332,7 +332,7 @@ __device__ __forceinline__ void attn_tiles(const AttnArgs& a, const char* sk, co
       else
         vf.h[1] = (bf16x4_t){0, 0, 0, 0};   // keys beyond the staged block
 #pragma unroll
-      for (int i = 0; i < NQ; ++i) o[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[i].v, o[i][dt], 0, 0, 0);
+      for (int i = 0; i < NQ; ++i) o[i][dt] = mfma16x16x32<F16>(vf.v, pf[i].v, o[i][dt]);
     }
   }
 #pragma unroll
@@ -343,13 +343,13 @@ __device__ __forceinline__ void attn_tiles(const AttnArgs& a, const char* sk, co
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
         *reinterpret_cast<uint2*>(orow + dt * 16 + 4 * g) =
-            make_uint2(pack_bf16x2(o[i][dt][0] * inv[i], o[i][dt][1] * inv[i]),
-                       pack_bf16x2(o[i][dt][2] * inv[i], o[i][dt][3] * inv[i]));
+            make_uint2(pack16x2<F16>(o[i][dt][0] * inv[i], o[i][dt][1] * inv[i]),
+                       pack16x2<F16>(o[i][dt][2] * inv[i], o[i][dt][3] * inv[i]));
     }
   }
 }
 
-template <int NT, int OCC>
+template <int NT, int OCC, bool F16 = false>
 __global__ __launch_bounds__(256, OCC) void vit_attn_bf16_pair_kernel(AttnArgs a) {
   constexpr int KROWS = NT * 16;
   __shared__ __attribute__((aligned(16))) char smem[2 * KROWS * 128];
@@ -403,9 +403,9 @@ __global__ __launch_bounds__(256, OCC) void vit_attn_bf16_pair_kernel(AttnArgs a
     __builtin_amdgcn_s_barrier();
   }
   if (cnt >= 2) {
-    attn_tiles<NT, 2>(a, sk, sv, obase, qf, qt, li, g, vsw, true);
+    attn_tiles<NT, 2, F16>(a, sk, sv, obase, qf, qt, li, g, vsw, true);
   } else if (cnt == 1) {
-    attn_tiles<NT, 1>(a, sk, sv, obase, qf, qt, li, g, vsw, true);
+    attn_tiles<NT, 1, F16>(a, sk, sv, obase, qf, qt, li, g, vsw, true);
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -414,8 +414,8 @@ __global__ __launch_bounds__(256, OCC) void vit_attn_bf16_pair_kernel(AttnArgs a
   if (cnt > 2) {
     qt[0] = wave + 8; qt[1] = wave + 12;
     load_q(qf, qt);
-    if (cnt >= 4) attn_tiles<NT, 2>(a, sk, sv, obase, qf, qt, li, g, vsw, false);
-    else attn_tiles<NT, 1>(a, sk, sv, obase, qf, qt, li, g, vsw, false);
+    if (cnt >= 4) attn_tiles<NT, 2, F16>(a, sk, sv, obase, qf, qt, li, g, vsw, false);
+    else attn_tiles<NT, 1, F16>(a, sk, sv, obase, qf, qt, li, g, vsw, false);
   }
 }
 
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256, OCC) void vit_attn_bf16_pair_kernel(AttnArgs a
 // (280 TFLOP/s at N = 785, 160 at N = 257); this one keeps 2 x KT*16 keys in flight per workgroup.  Measured, F = 80,
 // N = 785: KT = 6 (96 keys, 168 VGPRs, 3 waves/SIMD) 295 us = 514 TFLOP/s; KT = 4 (4 waves/SIMD) 345; KT = 2 344; KT = 8
 // (2 waves/SIMD) 523; 8 waves per workgroup with KT = 4: 365.  N = 257 (F = 256): 149 / 166 / 192 / 355 / 240 us.
-template <int KT, int OCC, int NW = 4>
+template <int KT, int OCC, int NW = 4, bool F16 = false>
 __global__ __launch_bounds__(NW * 64, OCC) void vit_attn_bf16_flash_kernel(AttnArgs a) {
   constexpr int KROWS = KT * 16;               // keys per block
   constexpr int BLK = KROWS * 128;             // bytes of one K (or V) block
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void vit_attn_bf16_flash_kernel(AttnA
       for (int ks = 0; ks < 2; ++ks) {
         const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sk + (kt * 16 + li) * 128 + (((ks * 4 + g) ^ (li & 7)) << 4));
 #pragma unroll
-        for (int i = 0; i < 2; ++i) s[i][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[i][ks], s[i][kt], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) s[i][kt] = mfma16x16x32<F16>(kf, qf[i][ks], s[i][kt]);
       }
     }
     if (nkeys < KROWS) {                               // last block: keys beyond N never win the max and get weight 0
@@ -551,10 +551,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void vit_attn_bf16_flash_kernel(AttnA
       union { bf16x8_t v; uint32_t u[4]; } pf[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        pf[i].u[0] = pack_bf16x2(s[i][2 * st][0], s[i][2 * st][1]);
-        pf[i].u[1] = pack_bf16x2(s[i][2 * st][2], s[i][2 * st][3]);
-        pf[i].u[2] = pack_bf16x2(s[i][2 * st + 1][0], s[i][2 * st + 1][1]);
-        pf[i].u[3] = pack_bf16x2(s[i][2 * st + 1][2], s[i][2 * st + 1][3]);
+        pf[i].u[0] = pack16x2<F16>(s[i][2 * st][0], s[i][2 * st][1]);
+        pf[i].u[1] = pack16x2<F16>(s[i][2 * st][2], s[i][2 * st][3]);
+        pf[i].u[2] = pack16x2<F16>(s[i][2 * st + 1][0], s[i][2 * st + 1][1]);
+        pf[i].u[3] = pack16x2<F16>(s[i][2 * st + 1][2], s[i][2 * st + 1][3]);
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void vit_attn_bf16_flash_kernel(AttnA
         vf.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(p0));
         vf.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(p0 + 16 * 128));
 #pragma unroll
-        for (int i = 0; i < 2; ++i) o[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[i].v, o[i][dt], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) o[i][dt] = mfma16x16x32<F16>(vf.v, pf[i].v, o[i][dt]);
       }
     }
   }
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void vit_attn_bf16_flash_kernel(AttnA
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
         *reinterpret_cast<uint2*>(orow + dt * 16 + 4 * g) =
-            make_uint2(pack_bf16x2(o[i][dt][0] * inv, o[i][dt][1] * inv), pack_bf16x2(o[i][dt][2] * inv, o[i][dt][3] * inv));
+            make_uint2(pack16x2<F16>(o[i][dt][0] * inv, o[i][dt][1] * inv), pack16x2<F16>(o[i][dt][2] * inv, o[i][dt][3] * inv));
     }
   }
 }
@@ -747,6 +747,11 @@ int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H
     else if (variant == 0) hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<6, 3>), fg, dim3(256), 0, st, a);   // 96-key blocks
     else if (variant == 4) hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<4, 4>), fg, dim3(256), 0, st, a);   // 64-key blocks
     else hipLaunchKernelGGL((vit_attn_bf16_kernel<true, KT>), grid, dim3(256), 0, st, a);
+  } else if (dtype == MVF_F16) {   // fp16 q / k / v / out: the two-tile kernel (N = 193 .. 208) or the streamed kernel (any N)
+    const int ntile = ceil_div(N, 16);
+    const dim3 fg(F * H, ceil_div(ntile, 8));
+    if (a.nblk == 1 && ntile == 13) hipLaunchKernelGGL((vit_attn_bf16_pair_kernel<13, 3, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<6, 3, 4, true>), fg, dim3(256), 0, st, a);
   } else if (dtype == MVF_F32) {
     static bool attr = false;
     if (!attr) {

@@ -107,7 +107,7 @@ size_t carve(int dtype, int fc, int N, int D, int P, Ws* w, char* base) {
   char* stats = nullptr;
   char* mr = nullptr;
   if (dtype == MVF_FP8 && D % 64 == 0) delta = take(Mc * D * 2);
-  if (dtype == MVF_BF16 && D % 64 == 0) {
+  if ((dtype == MVF_BF16 || dtype == MVF_F16) && D % 64 == 0) {
     xb = take(Mc * D * 2);
     delta = take(Mc * D * 2);
     stats = take(Mc * (size_t)(D / 64) * 2 * 4);
@@ -146,13 +146,14 @@ int run_blocks(const MvfVitWeights* w, int dtype, bool fp8, const Ws& ws, int fc
                int f0, int attn_variant, hipStream_t st) {
   const int D = w->dim, H = w->heads, np = N - 1;
   const int Mc = fc * N;
-  const size_t esz = dtype == MVF_BF16 ? 2 : 4;
+  const bool h16 = dtype == MVF_BF16 || dtype == MVF_F16;     // 16-bit activations (bf16, or IEEE fp16: the same data flow)
+  const size_t esz = h16 ? 2 : 4;
   int rc;
   // LN fold (bf16): where a layer's table entry qkv_c[l] / fc1_c[l] is set, qkv_w / fc1_w hold gamma (.) W, the bias table
   // holds b + W beta, and the GEMM consumes xb = bf16(x) with the row statistics applied in its epilogue -- no LayerNorm
   // kernel.  xb and the statistics' partial sums come out of the PREVIOUS residual epilogue (proj for LN2, the previous
   // layer's fc2 for LN1); layer 0's LN1 follows the patch embedding and keeps the LayerNorm kernel.
-  const bool can_fold = !fp8 && dtype == MVF_BF16 && ws.xb != nullptr && D % 128 == 0;
+  const bool can_fold = !fp8 && h16 && ws.xb != nullptr && D % 128 == 0;
   auto folded = [&](const float* const* tab, int l) { return can_fold && tab != nullptr && l < w->depth && tab[l] != nullptr; };
   const int ns = D / 64;
   for (int l = l0; l < l1; ++l) {
@@ -217,7 +218,7 @@ int run_blocks(const MvfVitWeights* w, int dtype, bool fp8, const Ws& ws, int fc
     // epilogue instead of read-modifying the fp32 residual (310 MB per launch with the matrix cores idle); LayerNorm 2
     // normalises x + delta and the fc2 epilogue adds delta with its own residual update.  The branch output is rounded to
     // bf16 before the add -- what the reference's autocast does to it (fp16 there; transformer.py:188).
-    const bool defer = g_proj_defer && dtype == MVF_BF16 && ws.delta != nullptr && !fold2 && w->ls1 == nullptr && D % 128 == 0;
+    const bool defer = g_proj_defer && h16 && ws.delta != nullptr && !fold2 && w->ls1 == nullptr && D % 128 == 0;
     if (defer) {
       RUN(timed_gemm(dtype, EPI_STORE, ws.h, D, w->proj_w[l], D, w->proj_b[l], ws.delta, D, nullptr, 0, nullptr, 0, nullptr,
                      nullptr, N, Mc, D, D, st));
@@ -271,7 +272,7 @@ extern "C" int mvf_vit_fwd_x(const MvfVitWeights* w, int dtype, const float* fra
                              float* cls_out, float* x_out, void* workspace, size_t ws_bytes, int frames_per_chunk,
                              int attn_variant, hipStream_t st) {
   MVF_CHECK_ARG(w && frames && workspace && F > 0);
-  MVF_CHECK_ARG(dtype == MVF_F32 || dtype == MVF_BF16 || dtype == MVF_FP8);
+  MVF_CHECK_ARG(dtype == MVF_F32 || dtype == MVF_BF16 || dtype == MVF_FP8 || dtype == MVF_F16);
   const bool fp8 = dtype == MVF_FP8;
   if (fp8) {   // MX-fp8 GEMM operands, bf16 everywhere else (patch embedding, attention, taps); no LN fold
     MVF_CHECK_ARG(w->dim % 256 == 0 && w->qkv_s && w->proj_s && w->fc1_s && w->fc2_s && !w->qkv_c && !w->fc1_c);
@@ -312,7 +313,7 @@ extern "C" int mvf_vit_fwd_x(const MvfVitWeights* w, int dtype, const float* fra
 extern "C" int mvf_vit_blocks_fwd(const MvfVitWeights* w, int dtype, float* x, int F, int first_block, int n_blocks,
                                   void* workspace, size_t ws_bytes, int attn_variant, hipStream_t st) {
   MVF_CHECK_ARG(w && x && workspace && F > 0 && first_block >= 0 && n_blocks > 0 && first_block + n_blocks <= w->depth);
-  MVF_CHECK_ARG(dtype == MVF_F32 || dtype == MVF_BF16 || dtype == MVF_FP8);
+  MVF_CHECK_ARG(dtype == MVF_F32 || dtype == MVF_BF16 || dtype == MVF_FP8 || dtype == MVF_F16);
   const bool fp8 = dtype == MVF_FP8;
   if (fp8) {
     MVF_CHECK_ARG(w->dim % 256 == 0 && w->qkv_s && w->proj_s && w->fc1_s && w->fc2_s && !w->qkv_c && !w->fc1_c);

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
       if constexpr (sizeof(T) == 4) {
         *reinterpret_cast<float4*>(dst) = v;
       } else {
-        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        constexpr bool F16 = sizeof(T) == 2 && !__is_same(T, bf16_t);     // f16_t: IEEE half (MVF_F16)
+        *reinterpret_cast<uint2*>(dst) = make_uint2(pack16x2<F16>(v.x, v.y), pack16x2<F16>(v.z, v.w));
       }
     } else {
       Elem<T>::st(dst, img[idx]);
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ g, const float* __restrict__ b,
                                                         TO* __restrict__ y, size_t out_stride, int rows, int D, float eps,
                                                         const bf16_t* __restrict__ add, size_t add_stride) {
+  constexpr bool kF16 = sizeof(TO) == 2 && !__is_same(TO, bf16_t);
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -71,8 +73,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       v[i] = *reinterpret_cast<const float4*>(xr + q * 4);
       if (add != nullptr) {
         const uint2 u = *reinterpret_cast<const uint2*>(add + (size_t)row * add_stride + q * 4);
-        v[i].x += __uint_as_float(u.x << 16); v[i].y += __uint_as_float(u.x & 0xffff0000u);
-        v[i].z += __uint_as_float(u.y << 16); v[i].w += __uint_as_float(u.y & 0xffff0000u);
+        float a0, a1, a2, a3;          // (the addend is in the output's 16-bit format: bf16, or fp16 for TO = f16_t)
+        unpack16x2<kF16>(u.x, a0, a1);
+        unpack16x2<kF16>(u.y, a2, a3);
+        v[i].x += a0; v[i].y += a1; v[i].z += a2; v[i].w += a3;
       }
       s += v[i].x + v[i].y + v[i].z + v[i].w;
     }
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       if constexpr (sizeof(TO) == 4) {
         *reinterpret_cast<float4*>(yr + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
       } else {
-        *reinterpret_cast<uint2*>(yr + q * 4) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+        *reinterpret_cast<uint2*>(yr + q * 4) = make_uint2(pack16x2<kF16>(o[0], o[1]), pack16x2<kF16>(o[2], o[3]));
       }
     }
   }
@@ -175,13 +179,14 @@ int mvf_im2col_impl(int dtype, const float* img, void* out, int F, int H, int W,
   MVF_CHECK_ARG(img && out && F > 0 && H % P == 0 && W % P == 0 && ldk >= 3 * P * P);
   const bool vec = P % 4 == 0 && W % 4 == 0 && ldk % 4 == 0;
   if (ldk > 3 * P * P) {   // zero the padding columns (whole buffer: it is small and the memset is asynchronous)
-    const size_t bytes = (size_t)F * (H / P) * (W / P) * ldk * (dtype == MVF_BF16 ? 2 : 4);
+    const size_t bytes = (size_t)F * (H / P) * (W / P) * ldk * (dtype == MVF_F32 ? 4 : 2);
     if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) return MVF_ERR_ARG;
   }
   const size_t total = (size_t)F * 3 * H * (vec ? W / 4 : W);
   const int grid = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
 #define IM2COL(TT, V) hipLaunchKernelGGL((im2col_kernel<TT, V>), dim3(grid), dim3(256), 0, st, img, (TT*)out, F, H, W, P, ldk)
   if (dtype == MVF_BF16) { if (vec) IM2COL(bf16_t, true); else IM2COL(bf16_t, false); }
+  else if (dtype == MVF_F16) { if (vec) IM2COL(f16_t, true); else IM2COL(f16_t, false); }
   else { if (vec) IM2COL(float, true); else IM2COL(float, false); }
 #undef IM2COL
   MVF_LAUNCH_CHECK();
@@ -206,10 +211,30 @@ int mvf_layernorm_impl(int out_dtype, const float* x, size_t in_stride, const fl
   hipLaunchKernelGGL((layernorm_kernel<TO, MV>), dim3(grid), dim3(256), 0, st, x, in_stride, g, b, (TO*)y, out_stride, rows, D, eps, add, add_stride)
   if (out_dtype == MVF_BF16) {
     if (nv <= 1) LN_LAUNCH(bf16_t, 1); else if (nv <= 2) LN_LAUNCH(bf16_t, 2); else if (nv <= 4) LN_LAUNCH(bf16_t, 4); else LN_LAUNCH(bf16_t, 8);
+  } else if (out_dtype == MVF_F16) {
+    if (nv <= 1) LN_LAUNCH(f16_t, 1); else if (nv <= 2) LN_LAUNCH(f16_t, 2); else if (nv <= 4) LN_LAUNCH(f16_t, 4); else LN_LAUNCH(f16_t, 8);
   } else {
     if (nv <= 1) LN_LAUNCH(float, 1); else if (nv <= 2) LN_LAUNCH(float, 2); else if (nv <= 4) LN_LAUNCH(float, 4); else LN_LAUNCH(float, 8);
   }
 #undef LN_LAUNCH
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+__global__ void cast_f16_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(in)[i];
+    reinterpret_cast<uint2*>(out)[i] = make_uint2(pack_f16x2(v.x, v.y), pack_f16x2(v.z, v.w));
+  }
+}
+
+// fp32 -> IEEE fp16, round to nearest even (weights of the fp16 compute mode); n % 4 == 0
+extern "C" int mvf_cast_f32_f16(const float* in, void* out, size_t n, hipStream_t st) {
+  MVF_CHECK_ARG(in && out && n % 4 == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 8) == 0);
+  const size_t n4 = n / 4;
+  if (n4 == 0) return MVF_OK;
+  const int grid = (int)std::min<size_t>((n4 + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(cast_f16_kernel, dim3(grid), dim3(256), 0, st, in, (uint16_t*)out, n4);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }
@@ -236,7 +261,7 @@ int mvf_ln_stats_finalize_impl(const float* part, int ns, float* mr, int rows, i
 extern "C" int mvf_layernorm_add_fwd(int out_dtype, const float* x, size_t in_stride, const void* add_bf16, size_t add_stride,
                                      const float* g, const float* b, void* y, size_t out_stride, int rows, int D, float eps,
                                      hipStream_t st) {
-  MVF_CHECK_ARG(add_bf16 != nullptr && (out_dtype == MVF_F32 || out_dtype == MVF_BF16));
+  MVF_CHECK_ARG(add_bf16 != nullptr && (out_dtype == MVF_F32 || out_dtype == MVF_BF16 || out_dtype == MVF_F16));   // (F16: fp16 addend)
   return mvf_layernorm_impl(out_dtype, x, in_stride, g, b, y, out_stride, rows, D, eps, st, add_bf16, add_stride);
 }
 

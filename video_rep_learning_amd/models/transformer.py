@@ -173,6 +173,9 @@ class TransformerModel(nn.Module):
         self.compute_dtype = mi['COMPUTE_DTYPE'] if 'COMPUTE_DTYPE' in mi else \
             ('bf16' if ('USE_AMP' in cfg and cfg.USE_AMP) else 'fp32')
         self.frames_per_chunk = int(mi['FRAMES_PER_CHUNK']) if 'FRAMES_PER_CHUNK' in mi else 0
+        if self.compute_dtype in ('fp16', 'f16') and getattr(self, 'split_layer', None) is not None:
+            raise NotImplementedError('MI355X.COMPUTE_DTYPE fp16 covers the FROZEN backbone (MODEL.BASE_MODEL.LAYER >= depth); the '
+                                      'trainable back-end blocks of a partially frozen one run in bf16 or fp32')
 
     def train(self, mode=True):
         super().train(mode)

@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from ._lib import call, ptr, stream, F32, BF16, FP8
+from ._lib import call, ptr, stream, F32, BF16, FP8, F16
 
 
 def _dt(dtype):
@@ -22,6 +22,8 @@ def _dt(dtype):
         return BF16, torch.bfloat16
     if dtype in ('fp8', 'mxfp8'):          # backbone only: MX-fp8 GEMM operands, bf16 activations / taps
         return FP8, torch.bfloat16
+    if dtype in (torch.float16, 'fp16', 'f16', F16):   # frozen backbone only: IEEE fp16 operands / activations (the reference's
+        return F16, torch.bfloat16                      # autocast dtype); the tapped features handed to the head stay bf16
     raise ValueError('unsupported compute dtype %r' % (dtype,))
 
 
@@ -1315,6 +1317,10 @@ class PackedViT:
                 o = torch.empty(t.shape, device=dev, dtype=torch.bfloat16)
                 call('mvf_cast_f32_bf16', t.data_ptr(), o.data_ptr(), t.numel(), stream())
                 t = o
+            elif self.code == F16:
+                o = torch.empty(t.shape, device=dev, dtype=torch.float16)
+                call('mvf_cast_f32_f16', t.data_ptr(), o.data_ptr(), t.numel(), stream())
+                t = o
             self.keep.append(t)
             return t.data_ptr()
 
@@ -1378,13 +1384,13 @@ class PackedViT:
                 cp.append(f32(c.float())), bp.append(f32((bias + W @ beta).float()))
             return ptr_table(wp), ptr_table(bp), ptr_table(cp)
 
-        fold = int(VIT_LN_FOLD if ln_fold is None else ln_fold) if (self.code == BF16 and dim % 128 == 0 and depth > 0) else 0
+        fold = int(VIT_LN_FOLD if ln_fold is None else ln_fold) if (self.code in (BF16, F16) and dim % 128 == 0 and depth > 0) else 0
         self.ln_fold = fold
         # Deferred residual of the attention branch (csrc/vit_fwd.hip) for LayerScale models: x + gamma_1 (.) (o W^T + b) =
         # x + o (gamma_1 (.) W)^T + gamma_1 (.) b -- gamma_1 goes into proj's weights and bias here and ls1 stays NULL, so the
         # device takes the deferred path (plain-store proj, branch output added in LayerNorm 2 and the fc2 epilogue)
         has_ls = 'blocks.0.ls1.gamma' in sd
-        self.ls1_folded = bool(has_ls and depth > 0 and self.code in (BF16, FP8) and dim % 128 == 0 and fold not in (1, 3)
+        self.ls1_folded = bool(has_ls and depth > 0 and self.code in (BF16, FP8, F16) and dim % 128 == 0 and fold not in (1, 3)
                                and os.environ.get('MVF_PROJ_DEFER', '1') != '0')
 
         def proj_w(t, i):

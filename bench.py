@@ -76,7 +76,7 @@ def tile_rows(M, N, nwg=256):
 
 
 def rocprof_names(groups, dtype, ln_fold, defer=True, frames=256, tokens=197, nwg=256):
-    """The same launches under the kernel names rocprofv3 prints, gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2, BMT>: one
+    """The same launches under the kernel names rocprofv3 prints, gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2, BMT, F16>: one
     kernel per epilogue flavour and tile height.  LN = true for the launches that carry the LN-fold extras: of a shape's 12
     launches per forward, 11 in fold mode 2 for qkv (blocks 1..11 consume the folded norm1) and for fc2 (blocks 0..10 produce
     bf16(x) + the row sums); 12 for fc1 / proj in the modes that fold norm2.  ADD2 = true for fc2 when the attention branch's
@@ -86,7 +86,7 @@ def rocprof_names(groups, dtype, ln_fold, defer=True, frames=256, tokens=197, nw
     by = {}
     for r in groups:
         e = r['epi']
-        if dtype != 'bf16':
+        if dtype not in ('bf16', 'fp16'):
             parts = [('gemm_tc_kernel<float, %d, false>' % e, 1.0)]
         else:
             qkv, fc1 = e == 0 and r['n'] > r['k'], e == 1        # (epi 0 with N == K: the proj GEMM of the deferred residual)
@@ -98,8 +98,9 @@ def rocprof_names(groups, dtype, ln_fold, defer=True, frames=256, tokens=197, nw
                 frac = 1.0
             add2 = 'true' if (fc2 and defer and ln_fold in (0, 2)) else 'false'
             bm = tile_rows(frames * (tokens - 1 if e == 3 else tokens), r['n'], nwg)
-            parts = [('gemm_tc256_kernel<%d, false, true, false, 0, %s, %d>' % (e, add2, bm), frac),
-                     ('gemm_tc256_kernel<%d, false, false, false, 0, %s, %d>' % (e, add2, bm), 1.0 - frac)]
+            f16 = 'true' if dtype == 'fp16' else 'false'
+            parts = [('gemm_tc256_kernel<%d, false, true, false, 0, %s, %d, %s>' % (e, add2, bm, f16), frac),
+                     ('gemm_tc256_kernel<%d, false, false, false, 0, %s, %d, %s>' % (e, add2, bm, f16), 1.0 - frac)]
         for k, f in parts:
             if f > 0:
                 d = by.setdefault(k, {'launches': 0.0, 'ms': 0.0})
@@ -179,7 +180,8 @@ def parse():
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=50)       # >= 20 warm-up + >= 50 timed
     p.add_argument('--warmup', type=int, default=20)
-    p.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    p.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp16'],
+                   help='backbone compute dtype: bf16 (BASELINE configs[1]), fp32 (parity mode), fp16 (the reference\'s own autocast dtype)')
     p.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU legs (cpu_baseline and parity)')
     p.add_argument('--parity-videos', type=int, default=2,
                    help='videos (x 2 views x 32 frames) of the resident batch pushed through the oracle for the parity block')
@@ -236,7 +238,7 @@ def cpu_baseline(cfg, model):
                       'timed, %.1f s per step' % (nv, 2 * nv, t, iters, dt)}
 
 
-def parity_block(model, batch, nv, dev):
+def parity_block(model, batch, nv, dev, reduced='bf16'):
     """The HIP path vs the oracle on `nv` videos of the resident benchmark batch (real size: ViT-B/16, 32 frames), dropout 0
     (its masks cannot be replayed on the CPU), training-mode loss (BatchNorm batch statistics) and eval-mode per-frame
     embeddings (project=False).  The oracle's backbone runs twice: plain fp32 and bf16-emulating (oracle/vit.py)."""
@@ -256,8 +258,8 @@ def parity_block(model, batch, nv, dev):
     t0 = time.time()
     ref = {}
     with torch.no_grad():
-        for mode in ('fp32', 'bf16'):
-            vcfg = dict(vit_cfg, emulate='bf16') if mode == 'bf16' else vit_cfg
+        for mode in ('fp32', reduced):
+            vcfg = dict(vit_cfg, emulate=reduced) if mode == reduced else vit_cfg
             feat, cls = OM.backbone_features(vc.reshape(b * v * t, *vc.shape[3:]), params, vcfg)
             ref[mode] = (OM.forward_from_backbone(feat, cls, b * v, t, params, vcfg, head_cfg, mc.reshape(b * v, 1, t),
                                                   project=False, training=False),
@@ -265,37 +267,39 @@ def parity_block(model, batch, nv, dev):
     algo = get_algo(cfg0)
     out = {'sample': '%d videos = %d clips x %d frames of the resident batch, dropout 0; oracle %.0f s'
                      % (nv, b * v, t, time.time() - t0),
-           'oracle_loss_fp32': round(float(ref['fp32'][1]), 6), 'oracle_loss_bf16_emulating': round(float(ref['bf16'][1]), 6)}
+           'oracle_loss_fp32': round(float(ref['fp32'][1]), 6), 'oracle_loss_%s_emulating' % reduced: round(float(ref[reduced][1]), 6)}
     # Every device pass sees the parameters AND BatchNorm running statistics the oracle's `params` snapshot holds: the
     # train-mode loss pass updates running_mean / running_var even under no_grad, so the eval-mode embeddings of both modes
     # are taken first and the buffers are restored after each loss pass.
     embs, losses = {}, {}
     buffers = {k: b_.clone() for k, b_ in m0.named_buffers()}
-    for mode in ('fp32', 'bf16'):
+    for mode in ('fp32', reduced):
         m0.compute_dtype = mode
         m0.eval()
         with torch.no_grad():
             embs[mode] = m0(videos.reshape(b * v, t, *videos.shape[3:]), t, video_masks=masks.reshape(b * v, 1, t).to(dev))
-    for mode in ('fp32', 'bf16'):
+    for mode in ('fp32', reduced):
         m0.compute_dtype = mode
         m0.train()
         with torch.no_grad():
             losses[mode] = algo.compute_loss(m0, videos, seq_lens, steps, masks)['loss']
             for k, b_ in m0.named_buffers():
                 b_.copy_(buffers[k])
-    for mode in ('fp32', 'bf16'):
+    for mode in ('fp32', reduced):
         emb, loss = embs[mode], losses[mode]
         out['hip_loss_' + mode] = round(float(loss), 6)
         out['loss_rel_' + mode] = float('%.3e' % T.relerr(loss, ref[mode][1]))
         out['emb_maxrel_' + mode] = float('%.3e' % T.relerr(emb, ref[mode][0]))
-        if mode == 'bf16':     # the dtype's own error: bf16 HIP against the plain fp32 oracle
-            out['loss_rel_bf16_vs_fp32_oracle'] = float('%.3e' % T.relerr(loss, ref['fp32'][1]))
-            out['emb_maxrel_bf16_vs_fp32_oracle'] = float('%.3e' % T.relerr(emb, ref['fp32'][0]))
-    out['gate'] = ('fp32 loss and embeddings <= 1e-3 rel (north star); bf16 (the benchmarked dtype) against the bf16-emulating '
-                   'oracle: loss <= %g of max(|loss|, 0.25), embeddings <= %g (eval-mode outputs of the TRAINED head of this run)' % BF16_GATES)
-    loss_err_bf16 = abs(out['hip_loss_bf16'] - out['oracle_loss_bf16_emulating']) / max(abs(out['oracle_loss_bf16_emulating']), 0.25)
+        if mode == reduced:     # the dtype's own error: reduced-precision HIP against the plain fp32 oracle
+            out['loss_rel_%s_vs_fp32_oracle' % reduced] = float('%.3e' % T.relerr(loss, ref['fp32'][1]))
+            out['emb_maxrel_%s_vs_fp32_oracle' % reduced] = float('%.3e' % T.relerr(emb, ref['fp32'][0]))
+    out['gate'] = ('fp32 loss and embeddings <= 1e-3 rel (north star); %s (the benchmarked dtype) against the %s-emulating '
+                   'oracle: loss <= %g of max(|loss|, 0.25), embeddings <= %g (eval-mode outputs of the TRAINED head of this run)'
+                   % ((reduced, reduced) + BF16_GATES))
+    lemu = out['oracle_loss_%s_emulating' % reduced]
+    loss_err_red = abs(out['hip_loss_' + reduced] - lemu) / max(abs(lemu), 0.25)
     out['ok'] = bool(out['loss_rel_fp32'] <= 1e-3 and out['emb_maxrel_fp32'] <= 1e-3 and
-                     loss_err_bf16 <= BF16_GATES[0] and out['emb_maxrel_bf16'] <= BF16_GATES[1])
+                     loss_err_red <= BF16_GATES[0] and out['emb_maxrel_' + reduced] <= BF16_GATES[1])
     return out
 
 
@@ -511,17 +515,17 @@ def main():
                            'avg_us': round(ms[g] * 1e3 / max(cnt[g], 1), 1),
                            'tflops': round(fl[g] / (ms[g] * 1e-3) / 1e12, 1) if ms[g] > 0 else 0.0})
         dom = max(groups, key=lambda r: r['ms'])       # the GEMM shape the step spends most time in
-        peak = PEAK_BF16_TFLOPS if a.dtype == 'bf16' else PEAK_F32_TFLOPS
+        peak = PEAK_BF16_TFLOPS if a.dtype in ('bf16', 'fp16') else PEAK_F32_TFLOPS     # (fp16 MFMA: the bf16 rate)
         ach = dom['flop'] / (dom['ms'] * 1e-3) / 1e12
         tot_ms, tot_fl = sum(r['ms'] for r in groups), sum(r['flop'] for r in groups)
-        kern = ('gemm_tc256_kernel' if a.dtype == 'bf16' else 'gemm_tc_kernel<float>') + ' / ' + dom['name']
+        kern = ('gemm_tc256_kernel' if a.dtype in ('bf16', 'fp16') else 'gemm_tc_kernel<float>') + ' / ' + dom['name']
         roof = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                 'traffic': pmc_traffic(dom['name']), 'kernel': kern, 'launches': dom['launches'],
                 'timing': 'HIP events around each launch on its stream, kernels serialized (1 backbone lane, no lookahead)',
                 'avg_launch_us': dom['avg_us'], 'flop_per_launch': dom['flop'] / max(dom['launches'], 1),
                 **({'sustained_loop_rate': {'tflops': SUSTAINED_BF16_LOOP_TFLOPS, 'source': 'profiles/r03/power_probe.txt',
                                             'all_gemm_frac_of_it': round(tot_fl / (tot_ms * 1e-3) / 1e12 / SUSTAINED_BF16_LOOP_TFLOPS, 4)}}
-                   if a.dtype == 'bf16' else {}),
+                   if a.dtype in ('bf16', 'fp16') else {}),
                 'all_gemm': {'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 1), 'frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4),
                              'ms_per_step': round(tot_ms / max(a.profile_steps, 1), 3)},
                 'by_kernel': {r['name']: {'launches': r['launches'], 'avg_us': r['avg_us'], 'tflops': r['tflops']}
@@ -558,7 +562,8 @@ def main():
             except Exception as e:  # the baseline must never sink the measurement
                 out['cpu_baseline'] = {'value': None, 'unit': 'clips/s', 'cores': os.cpu_count(), 'kind': 'port',
                                        'sample': 'failed: %r' % (e,)}
-            out['parity'] = parity_block(model, (videos, seq_lens, steps, masks), max(1, min(a.parity_videos, videos.shape[0])), dev)
+            out['parity'] = parity_block(model, (videos, seq_lens, steps, masks), max(1, min(a.parity_videos, videos.shape[0])), dev,
+                                         reduced='fp16' if a.dtype == 'fp16' else 'bf16')
             parity_ok = out['parity']['ok']
         print(json.dumps(out), flush=True)
         if not parity_ok:

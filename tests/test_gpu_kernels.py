@@ -451,7 +451,7 @@ def _attn_ref(qkv, F, N, H):
 # variants: 0 default (two query tiles per wave; streamed 96-key blocks unless N = 193..208), 1 gather reads (cross-check of the
 # transposing LDS read), 2 the earlier kernels (one tile per wave / synchronously staged 224-key blocks: the fallback of odd
 # shapes), 4 streamed 64-key blocks
-@pytest.mark.parametrize('dtype,variant', [('f32', 0), ('bf16', 0), ('bf16', 1), ('bf16', 2), ('bf16', 4)])
+@pytest.mark.parametrize('dtype,variant', [('f32', 0), ('bf16', 0), ('bf16', 1), ('bf16', 2), ('bf16', 4), ('bf16', 6)])
 def test_vit_attention(N, dtype, variant):
     code, tdt = ops._dt(dtype)
     F, H, D = 2, 3, 192

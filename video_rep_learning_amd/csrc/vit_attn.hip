@@ -249,7 +249,7 @@ struct NoHook {
 };
 // after_s: called once the S phase's MFMAs are issued and K is no longer read by this wave (hook of the persistent form that
 // was removed in round 3; the default does nothing)
-template <int NT, int NQ, bool F16 = false, typename AfterS = NoHook>   // F16: q / k / v / out are IEEE fp16 (MVF_F16), else bf16
+template <int NT, int NQ, bool F16 = false, bool MSUM = false, typename AfterS = NoHook>   // F16: q / k / v / out are IEEE fp16 (MVF_F16), else bf16
 __device__ __forceinline__ void attn_tiles(const AttnArgs& a, const char* sk, const char* sv, bf16_t* obase,
                                            const bf16x8_t (&qf)[2][2], const int (&qt)[2], int li, int g, int vsw,
                                            bool wait_v, AfterS after_s = AfterS()) {
@@ -291,12 +291,14 @@ __device__ __forceinline__ void attn_tiles(const AttnArgs& a, const char* sk, co
       const f32x2_t p0 = {__builtin_amdgcn_exp2f(e0[0]), __builtin_amdgcn_exp2f(e0[1])};
       const f32x2_t p1 = {__builtin_amdgcn_exp2f(e1[0]), __builtin_amdgcn_exp2f(e1[1])};
       s[i][kt][0] = p0[0]; s[i][kt][1] = p0[1]; s[i][kt][2] = p1[0]; s[i][kt][3] = p1[1];
-      ls2 = pk_add(ls2, pk_add(p0, p1));
+      if constexpr (!MSUM) ls2 = pk_add(ls2, pk_add(p0, p1));
     }
-    float ls = ls2[0] + ls2[1];
-    ls += __shfl_xor(ls, 16, 64);
-    ls += __shfl_xor(ls, 32, 64);
-    inv[i] = 1.0f / ls;
+    if constexpr (!MSUM) {
+      float ls = ls2[0] + ls2[1];
+      ls += __shfl_xor(ls, 16, 64);
+      ls += __shfl_xor(ls, 32, 64);
+      inv[i] = 1.0f / ls;
+    }
   }
   if (wait_v) {   // V landed (every wave waits for its own pieces, then the workgroup meets)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -304,10 +306,18 @@ __device__ __forceinline__ void attn_tiles(const AttnArgs& a, const char* sk, co
   }
   // ---- O^T = V^T P^T : k-step = 32 keys = score tiles (2s, 2s+1) ----
   f32x4_t o[NQ][4];
+  // MSUM: the row sums as a fifth P.V product against an all-ones V^T tile -- 7 MFMAs per query tile on a matrix pipe that is
+  // 18 % busy instead of 26 packed adds + two cross-lane steps on the VALU this kernel runs out of; every lane (query li, any g)
+  // receives its row's sum (of the ROUNDED probabilities, the values P.V multiplies) in all four result registers
+  f32x4_t rs[NQ];
+  union { bf16x8_t v; uint32_t u[4]; } ones;
+  ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = F16 ? 0x3C003C00u : 0x3F803F80u;
 #pragma unroll
-  for (int i = 0; i < NQ; ++i)
+  for (int i = 0; i < NQ; ++i) {
+    rs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[i][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
   for (int st = 0; st < (NT + 1) / 2; ++st) {
     union { bf16x8_t v; uint32_t u[4]; } pf[NQ];
@@ -334,6 +344,14 @@ __device__ __forceinline__ void attn_tiles(const AttnArgs& a, const char* sk, co
 #pragma unroll
       for (int i = 0; i < NQ; ++i) o[i][dt] = mfma16x16x32<F16>(vf.v, pf[i].v, o[i][dt]);
     }
+    if constexpr (MSUM) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) rs[i] = mfma16x16x32<F16>(ones.v, pf[i].v, rs[i]);
+    }
+  }
+  if constexpr (MSUM) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) inv[i] = 1.0f / rs[i][0];
   }
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
@@ -349,7 +367,7 @@ __device__ __forceinline__ void attn_tiles(const AttnArgs& a, const char* sk, co
   }
 }
 
-template <int NT, int OCC, bool F16 = false>
+template <int NT, int OCC, bool F16 = false, bool MSUM = false>
 __global__ __launch_bounds__(256, OCC) void vit_attn_bf16_pair_kernel(AttnArgs a) {
   constexpr int KROWS = NT * 16;
   __shared__ __attribute__((aligned(16))) char smem[2 * KROWS * 128];
@@ -403,9 +421,9 @@ __global__ __launch_bounds__(256, OCC) void vit_attn_bf16_pair_kernel(AttnArgs a
     __builtin_amdgcn_s_barrier();
   }
   if (cnt >= 2) {
-    attn_tiles<NT, 2, F16>(a, sk, sv, obase, qf, qt, li, g, vsw, true);
+    attn_tiles<NT, 2, F16, MSUM>(a, sk, sv, obase, qf, qt, li, g, vsw, true);
   } else if (cnt == 1) {
-    attn_tiles<NT, 1, F16>(a, sk, sv, obase, qf, qt, li, g, vsw, true);
+    attn_tiles<NT, 1, F16, MSUM>(a, sk, sv, obase, qf, qt, li, g, vsw, true);
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -414,8 +432,8 @@ __global__ __launch_bounds__(256, OCC) void vit_attn_bf16_pair_kernel(AttnArgs a
   if (cnt > 2) {
     qt[0] = wave + 8; qt[1] = wave + 12;
     load_q(qf, qt);
-    if (cnt >= 4) attn_tiles<NT, 2, F16>(a, sk, sv, obase, qf, qt, li, g, vsw, false);
-    else attn_tiles<NT, 1, F16>(a, sk, sv, obase, qf, qt, li, g, vsw, false);
+    if (cnt >= 4) attn_tiles<NT, 2, F16, MSUM>(a, sk, sv, obase, qf, qt, li, g, vsw, false);
+    else attn_tiles<NT, 1, F16, MSUM>(a, sk, sv, obase, qf, qt, li, g, vsw, false);
   }
 }
 
@@ -743,6 +761,8 @@ int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H
     if (variant == 1) hipLaunchKernelGGL((vit_attn_bf16_kernel<false, KT>), grid, dim3(256), 0, st, a);
     else if (a.nblk == 1 && ntile == 13 && variant == 0)
       hipLaunchKernelGGL((vit_attn_bf16_pair_kernel<13, 3>), grid, dim3(256), 0, st, a);
+    else if (a.nblk == 1 && ntile == 13 && variant == 6)     // row sums on the matrix pipe (A/B measurement form)
+      hipLaunchKernelGGL((vit_attn_bf16_pair_kernel<13, 3, false, true>), grid, dim3(256), 0, st, a);
     else if (a.nblk == 1 && ntile == 13) hipLaunchKernelGGL((vit_attn_bf16_kernel<true, 13>), grid, dim3(256), 0, st, a);
     else if (variant == 0) hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<6, 3>), fg, dim3(256), 0, st, a);   // 96-key blocks
     else if (variant == 4) hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<4, 4>), fg, dim3(256), 0, st, a);   // 64-key blocks

@@ -16,7 +16,7 @@ published algorithm:
 
 `emulate='bf16'` restates the SAME algorithm with a round-to-nearest-even bf16 rounding at exactly the points where
 the product's bf16 mode stores bf16 (csrc/vit_fwd.hip, vit_attn.hip, gemm_tc_epi.h): GEMM weights, the im2col'd
-patches, qkv, the softmax probabilities fed to P.V (their row sum stays fp32), the attention output, fc1+GELU output
+patches, qkv, the softmax probabilities fed to P.V (and to their row sum, accumulated in fp32), the attention output, fc1+GELU output
 and the tapped block outputs; accumulation, biases, position embedding, LayerScale and the residual stream stay fp32.
 LayerNorm is FOLDED into the GEMM that consumes it where the product folds it (include/mvf_hip.h qkv_c / fc1_c; default
 MVF_LN_FOLD=2: norm1 of blocks > 0):   LN(x) W^T + b  ==  rstd * (x W'^T - mean * c) + d   with W' = gamma (.) W,
@@ -210,7 +210,8 @@ def vit_block_bf16(x, w, p, heads, eps=1e-6, fold1=False, fold2=False, mx=False,
     q, k, v = qkv[0], qkv[1], qkv[2]
     s = (q @ k.transpose(-1, -2)) * hd ** -0.5
     pr = torch.exp(s - s.max(-1, keepdim=True)[0])
-    a = r((r(pr) @ v) / pr.sum(-1, keepdim=True))          # P in bf16 for P.V, its row sum in fp32
+    prr = r(pr)                                            # P in bf16 for P.V; its row sum is taken over the SAME rounded values
+    a = r((prr @ v) / prr.sum(-1, keepdim=True))           # (fp32 accumulation: the product sums them as a fifth P.V column of ones)
     a = a.transpose(1, 2).reshape(f, n, d)
     if defer_proj:
         # deferred residual: the branch output (LayerScale folded into proj's weights and bias) is stored as bf16 before it is

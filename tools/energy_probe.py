@@ -148,8 +148,12 @@ def main():
     def k_attn():
         call('mvf_vit_attn_fwd', _lib.BF16, qkv.data_ptr(), h.data_ptr(), F, N, H, D, 0, st)
 
-    def k_attn_msum():     # row sums on the matrix pipe (variant 6)
+    def k_attn_msum():     # variant 6: row sums on the VALU (the form before round 4; variant 0 takes them on the matrix pipe)
         call('mvf_vit_attn_fwd', _lib.BF16, qkv.data_ptr(), h.data_ptr(), F, N, H, D, 6, st)
+
+    def k_qkv_attn():      # qkv projection fused into the attention kernel (folded-LayerNorm form, as blocks 1.. run it)
+        call('mvf_vit_qkv_attn_fwd', _lib.BF16, xb.data_ptr(), D, Wqkv.data_ptr(), b3.data_ptr(), c3.data_ptr(), mr.data_ptr(), h.data_ptr(),
+             F, N, H, D, st)
 
     def k_ln():
         call('mvf_layernorm_fwd', _lib.BF16, x.data_ptr(), D, g.data_ptr(), be.data_ptr(), h.data_ptr(), D, M, D, 1e-6, st)
@@ -165,13 +169,14 @@ def main():
         call('mvf_patchify', _lib.BF16, frames.data_ptr(), hid.data_ptr(), F, 224, 224, 16, st)
 
     flops = {'qkv': 2.0 * M * 3 * D * D, 'proj': 2.0 * M * D * D, 'fc1': 2.0 * M * 4 * D * D, 'fc2': 2.0 * M * 4 * D * D,
-             'fc2_resid2': 2.0 * M * 4 * D * D, 'fc2_plain': 2.0 * M * 4 * D * D, 'attn': 4.0 * F * H * N * N * 64, 'attn_msum': 4.0 * F * H * N * N * 64}
+             'fc2_resid2': 2.0 * M * 4 * D * D, 'fc2_plain': 2.0 * M * 4 * D * D, 'attn': 4.0 * F * H * N * N * 64, 'attn_msum': 4.0 * F * H * N * N * 64,
+             'qkv_attn': 2.0 * M * 3 * D * D + 4.0 * F * H * N * N * 64}
     mbytes = {'qkv': (M * D * 2 + M * 3 * D * 2) / 1e6, 'proj': 2 * M * D * 2 / 1e6, 'fc1': (M * D * 2 + M * 4 * D * 2) / 1e6,
               'fc2': (M * 4 * D * 2 + M * D * (4 + 4 + 2)) / 1e6, 'fc2_resid2': (M * 4 * D * 2 + M * D * (4 + 4 + 2)) / 1e6,
-              'fc2_plain': (M * 4 * D * 2 + M * D * 2) / 1e6, 'attn': M * 4 * D * 2 / 1e6, 'attn_msum': M * 4 * D * 2 / 1e6, 'ln': M * D * 6 / 1e6,
+              'fc2_plain': (M * 4 * D * 2 + M * D * 2) / 1e6, 'attn': M * 4 * D * 2 / 1e6, 'attn_msum': M * 4 * D * 2 / 1e6, 'qkv_attn': 2 * M * D * 2 / 1e6, 'ln': M * D * 6 / 1e6,
               'ln_add': M * D * 8 / 1e6, 'finalize': M * (D // 64 + 1) * 8 / 1e6, 'im2col': (F * 3 * 224 * 224 * 4 + F * 196 * 768 * 2) / 1e6}
     table = {'qkv': k_qkv, 'proj': k_proj, 'fc1': k_fc1, 'fc2': k_fc2, 'fc2_resid2': k_fc2_resid2, 'fc2_plain': k_fc2_plain,
-             'attn': k_attn, 'attn_msum': k_attn_msum, 'ln': k_ln, 'ln_add': k_ln_add, 'finalize': k_finalize, 'im2col': k_im2col}
+             'attn': k_attn, 'attn_msum': k_attn_msum, 'qkv_attn': k_qkv_attn, 'ln': k_ln, 'ln_add': k_ln_add, 'finalize': k_finalize, 'im2col': k_im2col}
 
     sampler = PowerSampler(smi=a.smi)
     idle = sampler.read()

@@ -45,6 +45,11 @@ int mvf_layernorm_impl(int out_dtype, const float* x, size_t in_stride, const fl
                        size_t out_stride, int rows, int D, float eps, hipStream_t st, const void* add_bf16 = nullptr, size_t add_stride = 0);
 int mvf_cast_bf16_impl(const float* in, void* out, size_t n, hipStream_t st);
 int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t st);
+// vit_qkv_attn.hip: the qkv projection fused into the attention kernel (N = 193 .. 208); MVF_ERR_UNSUPPORTED outside its shapes
+int mvf_qkv_attn_impl(int dtype, const void* A, int lda, const void* W, const float* bias, const float* ln_c, const float* ln_mr,
+                      void* out, int F, int N, int H, int D, hipStream_t st);
+// shapes the fused kernel takes (and MVF_FUSE_QKV != 0: the variable keeps the GEMM + attention launches for A/B measurements)
+bool mvf_qkv_attn_supported(int dtype, int F, int N, int H, int D, int lda);
 
 // ---- head ----
 // MFMA temporal attention (head_attn_mfma.hip); which: 0 forward, 1 backward; MVF_ERR_UNSUPPORTED unless dk in {16,32,64}

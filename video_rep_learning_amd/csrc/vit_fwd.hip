@@ -191,7 +191,23 @@ int run_blocks(const MvfVitWeights* w, int dtype, bool fp8, const Ws& ws, int fc
                      nullptr, w->ls2 ? w->ls2[l] : nullptr, N, Mc, D, 4 * D, st, nullptr, &s2));
       continue;
     }
-    if (folded(w->qkv_c, l)) {
+    // qkv projection fused into the attention kernel (vit_qkv_attn.hip): the [Mc, 3D] qkv tensor never reaches HBM
+    const bool fused_attn = attn_variant == 0 && mvf_qkv_attn_supported(dtype, fc, N, H, D, D);
+    if (fused_attn) {
+      if (folded(w->qkv_c, l)) {
+        if (l == l0) return MVF_ERR_ARG;   // nothing in this call produced the layer's statistics
+        RUN(mvf_ln_stats_finalize_impl(ws.stats, ns, ws.mr, Mc, D, w->ln_eps, st));
+        RUN(mvf_qkv_attn_impl(dtype, ws.xb, D, w->qkv_w[l], w->qkv_b[l], w->qkv_c[l], ws.mr, ws.h, fc, N, H, D, st));
+      } else {
+        // the LayerNorm output is parked in the (otherwise unused) qkv buffer: the kernel's output goes to ws.h, and a unit's
+        // output columns must not land in rows another (frame, head) unit of the same launch still reads as its operand
+        RUN(mvf_layernorm_impl(dtype, ws.x, D, w->ln1_w[l], w->ln1_b[l], ws.qkv, D, Mc, D, w->ln_eps, st));
+        RUN(mvf_qkv_attn_impl(dtype, ws.qkv, D, w->qkv_w[l], w->qkv_b[l], nullptr, nullptr, ws.h, fc, N, H, D, st));
+      }
+    }
+    if (fused_attn) {
+      // done
+    } else if (folded(w->qkv_c, l)) {
       if (l == l0) return MVF_ERR_ARG;   // nothing in this call produced the layer's statistics
       // the GEMM turns the producer's partial sums into (mean, rstd) itself (no finalize launch between fc2 and qkv); shapes it
       // cannot stage (more than 12 slices: D > 768, an odd row count) keep the small kernel
@@ -212,7 +228,7 @@ int run_blocks(const MvfVitWeights* w, int dtype, bool fp8, const Ws& ws, int fc
       RUN(timed_gemm(dtype, EPI_STORE, ws.h, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0,
                      nullptr, nullptr, N, Mc, 3 * D, D, st));
     }
-    RUN(mvf_vit_attn_impl(dtype, ws.qkv, ws.h, fc, N, H, D, attn_variant, st));
+    if (!fused_attn) RUN(mvf_vit_attn_impl(dtype, ws.qkv, ws.h, fc, N, H, D, attn_variant, st));
     const bool fold2 = folded(w->fc1_c, l);
     // Deferred residual (bf16, no LayerScale, norm2 not folded): proj stores its result (+ bias) as bf16 with the plain
     // epilogue instead of read-modifying the fp32 residual (310 MB per launch with the matrix cores idle); LayerNorm 2

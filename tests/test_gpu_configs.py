@@ -165,12 +165,13 @@ def test_full_size_fp32_and_bf16_vs_oracle(tag):
     # the 1536-wide fg99 head; 6e-4 .. 4.5e-3 on the other two configs): those stay under the 1e-2 gate
     assert flips <= T.flip_bound(nelem) and worst_raw[0] <= 5e-2, (flips, worst_raw, worst)
     # ---- bf16 mode (the benchmarked dtype)
-    r = T.bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, ref_emb_fp32=remb)
+    r = T.bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, ref_feats_fp32=(feat, cls))
     record_parity('%s HIP bf16: %s' % (tag, r['text']))
-    # bounds: at most 3x what was measured on MI355X (profiles/r02/parity.txt: embeddings 5.3e-4 .. 6.3e-4, loss 9e-5 .. 6e-4,
-    # 1.6e-2 .. 1.8e-2 against the fp32 oracle).  The two sides differ by fp32 summation order and by bf16 roundings that flip
+    # bounds: at most 3x what was measured on MI355X (profiles/r02/parity.txt: embeddings 5.3e-4 .. 6.3e-4, loss 9e-5 .. 6e-4;
+    # against the fp32 oracle 2.7e-3 -- the 1.6e-2 .. 1.8e-2 of rounds 2-3 compared with a reference taken BEFORE this test's
+    # training-mode passes had moved the BatchNorm running statistics, test_gpu_model.bf16_mode_report).  The two sides differ by fp32 summation order and by bf16 roundings that flip
     # where a value sits on a rounding boundary (one bf16 ulp of a tap's largest element is 3.9e-3)
-    assert r['emb'] <= 2e-3 and r['loss'] <= 2e-3 and r['emb_fp32'] <= 5e-2, r
+    assert r['emb'] <= 2e-3 and r['loss'] <= 2e-3 and r['emb_fp32'] <= 1e-2, r
     # head_grad_raw: the largest single element a flipped ReLU unit moves (one (row, unit) contribution added or removed from a
     # weight-gradient row: its size is that row's share, not a rounding error).  Which units sit on the kink changes with every
     # last-bit change of the taps: measured 2.6e-2 (round 2), 1.0e-1 (round 4, two flipped rows of fc_layers.5): counted by
@@ -180,10 +181,11 @@ def test_full_size_fp32_and_bf16_vs_oracle(tag):
     # ---- fp16 mode (the reference's own autocast dtype, CARL_MVF/train.py:113,301) at the benchmarked shape: closer to the fp32
     # oracle than bf16 is, by about the three mantissa bits it has more
     if tag.startswith('configs[1]'):
-        r16 = T.bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, ref_emb_fp32=remb, mode='fp16')
+        r16 = T.bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, ref_feats_fp32=(feat, cls), mode='fp16')
         record_parity('%s HIP fp16: %s' % (tag, r16['text']))
         assert r16['emb'] <= 2e-3 and r16['loss'] <= 2e-3, r16
-        assert r16['emb_fp32'] <= 1e-2 and r16['emb_fp32'] < 0.5 * r['emb_fp32'], (r16['emb_fp32'], r['emb_fp32'])
+        # the north-star tolerance (1e-3 of the fp32 reference) is met by this mode at the benchmarked shape
+        assert r16['emb_fp32'] <= 1e-3 and r16['emb_fp32'] < 0.5 * r['emb_fp32'], (r16['emb_fp32'], r['emb_fp32'])
         assert r16['loss_head'] <= 1e-3 and r16['grad_cos'] >= 0.98, r16
 
 

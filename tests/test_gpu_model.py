@@ -316,7 +316,8 @@ def flip_census(got, ref, scale, gate):
     return n, (d.max().item() if d.numel() else 0.0), (rest.max().item() if rest.numel() else 0.0), rows
 
 
-def bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, ref_emb_fp32=None, mode='bf16', end_to_end=True, gate=2e-2):
+def bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, ref_emb_fp32=None, mode='bf16', end_to_end=True, gate=2e-2,
+                     ref_feats_fp32=None):
     """Reduced-precision mode (`mode` = 'bf16' or 'fp8': the backbone's GEMM operand dtype) of `model` on one batch (dropout 0)
     against
       (1) end_to_end: the EMULATING oracle (oracle/vit.py emulate=mode): eval embeddings (max-rel), training loss (rel), and the
@@ -332,6 +333,13 @@ def bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, ref_emb_fp32=No
     x = videos.view(b * 2, t, *videos.shape[3:])
     m2 = masks.view(b * 2, 1, t)
     params = cpu_params(model)
+    if ref_feats_fp32 is not None:
+        # the fp32 oracle's eval embeddings from ITS backbone features and the model's CURRENT parameters and BatchNorm running
+        # statistics: a reference computed before earlier training-mode passes of the same model would charge their running-
+        # statistics drift to the dtype (that was the "1.7e-2 against the fp32 oracle" of rounds 2-3; the dtype's own share is 2.7e-3)
+        with torch.no_grad():
+            ref_emb_fp32 = OM.forward_from_backbone(ref_feats_fp32[0], ref_feats_fp32[1], b * 2, t, params, vit_cfg, head_cfg, m2,
+                                                    project=False, training=False)
 
     def oracle_loss_grads(feat, cls):
         leaves = {k: params[k].clone().requires_grad_(True) for k in OM.trainable_names(params)}

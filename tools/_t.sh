@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -k "qkv_projection_fused" 2>&1 | grep -v amdgpu | tail -8
-python tools/energy_probe.py --smi --seconds 3 --kernels qkv,attn,qkv_attn,qkv_attn 2>&1 | grep -E "^qkv|^attn|^kernel"
+python -m pytest tests/test_gpu_configs.py -x -q -k "test_full_size and not fg99 and not 192" 2>&1 | grep -v amdgpu | tail -4
+grep -E "HIP (bf16|fp16):" gpurun_out/parity.txt | tail -2 | cut -c1-330
+bash tools/r4_head_ab.sh

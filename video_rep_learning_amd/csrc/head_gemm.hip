@@ -57,25 +57,38 @@ __device__ __forceinline__ int lds_at(int k, int c) { return k * LDT + (c ^ (((k
 // GUARD == false: the tile is known to be fully in range and 16-byte loadable (M, N multiples of 64, K of 32, aligned
 // strides) -- straight-line code, all loads of a k step issue back to back.  GUARD == true (ragged shapes such as the
 // 387-wide first FC layer, tiny query GEMMs) pays per-load range checks.
-template <bool KMAJOR, bool GUARD>
+// ROWS = 64 | 32 rows of the tile (32: the half-height output tiles of small problems; two passes instead of four): KMAJOR
+// thread -> (k = t / (ROWS/4) [+ 1024/ROWS per pass], rows 4 (t % (ROWS/4))), else thread -> (row = t/8 [+32], k = 4 (t%8) [+32])
+template <int ROWS>
+struct TileGeom {
+  static constexpr int TPK = ROWS / 4;          // threads along the rows of one k (KMAJOR)
+  static constexpr int KPP = 256 / TPK;         // k rows per pass (KMAJOR)
+  static constexpr int PASSES = ROWS == 64 ? 4 : 2;
+  // pass h of the k-contiguous form: row half (ROWS = 64 only) and k half
+  static __device__ __forceinline__ int row_off(int h) { return ROWS == 64 ? 32 * (h & 1) : 0; }
+  static __device__ __forceinline__ int k_off(int h) { return ROWS == 64 ? 32 * (h >> 1) : 32 * h; }
+};
+
+template <bool KMAJOR, bool GUARD, int ROWS = 64>
 __device__ __forceinline__ void tile_load(const float* X, long sr, long sk, int r0, int R, int k0, int K, bool vec,
                                           f32x4_t (&v)[NPASS]) {
+  using G = TileGeom<ROWS>;
   const int t = threadIdx.x;
   if constexpr (!GUARD) {
 #pragma unroll
-    for (int h = 0; h < NPASS; ++h) {
+    for (int h = 0; h < G::PASSES; ++h) {
       if constexpr (KMAJOR)
-        v[h] = *reinterpret_cast<const f32x4_t*>(X + (long)(k0 + (t >> 4) + 16 * h) * sk + r0 + (t & 15) * 4);
+        v[h] = *reinterpret_cast<const f32x4_t*>(X + (long)(k0 + t / G::TPK + G::KPP * h) * sk + r0 + (t % G::TPK) * 4);
       else
-        v[h] = *reinterpret_cast<const f32x4_t*>(X + (long)(r0 + (t >> 3) + 32 * (h & 1)) * sr + k0 + (t & 7) * 4 + 32 * (h >> 1));
+        v[h] = *reinterpret_cast<const f32x4_t*>(X + (long)(r0 + (t >> 3) + G::row_off(h)) * sr + k0 + (t & 7) * 4 + G::k_off(h));
     }
     return;
   }
 #pragma unroll
-  for (int h = 0; h < NPASS; ++h) {
+  for (int h = 0; h < G::PASSES; ++h) {
     f32x4_t x = {0.f, 0.f, 0.f, 0.f};
     if constexpr (KMAJOR) {
-      const int k = k0 + (t >> 4) + 16 * h, r = r0 + (t & 15) * 4;
+      const int k = k0 + t / G::TPK + G::KPP * h, r = r0 + (t % G::TPK) * 4;
       if (k < K) {
         const float* p = X + (long)k * sk + r;
         if (vec && r + 3 < R) x = *reinterpret_cast<const f32x4_t*>(p);
@@ -85,7 +98,7 @@ __device__ __forceinline__ void tile_load(const float* X, long sr, long sk, int 
         }
       }
     } else {
-      const int r = r0 + (t >> 3) + 32 * (h & 1), k = k0 + (t & 7) * 4 + 32 * (h >> 1);
+      const int r = r0 + (t >> 3) + G::row_off(h), k = k0 + (t & 7) * 4 + G::k_off(h);
       if (r < R) {
         const float* p = X + (long)r * sr + k;
         if (vec && k + 3 < K) x = *reinterpret_cast<const f32x4_t*>(p);
@@ -100,28 +113,31 @@ __device__ __forceinline__ void tile_load(const float* X, long sr, long sk, int 
 }
 
 // registers -> LDS tile [k][row]
-template <bool KMAJOR>
+template <bool KMAJOR, int ROWS = 64>
 __device__ __forceinline__ void tile_store(float* T, const f32x4_t (&v)[NPASS]) {
+  using G = TileGeom<ROWS>;
   const int t = threadIdx.x;
 #pragma unroll
-  for (int h = 0; h < NPASS; ++h) {
+  for (int h = 0; h < G::PASSES; ++h) {
     if constexpr (KMAJOR) {
-      *reinterpret_cast<f32x4_t*>(T + lds_at((t >> 4) + 16 * h, (t & 15) * 4)) = v[h];
+      *reinterpret_cast<f32x4_t*>(T + lds_at(t / G::TPK + G::KPP * h, (t % G::TPK) * 4)) = v[h];
     } else {
-      const int r = (t >> 3) + 32 * (h & 1), k = (t & 7) * 4 + 32 * (h >> 1);
+      const int r = (t >> 3) + G::row_off(h), k = (t & 7) * 4 + G::k_off(h);
 #pragma unroll
       for (int s = 0; s < 4; ++s) T[lds_at(k + s, r)] = v[h][s];
     }
   }
 }
 
-// one 64x64 output tile (bx, by) of the problem `a`; lds: 4 * TILE_F floats
-template <bool AKM, bool BKM, bool GUARD>
+// one TM x 64 output tile (bx, by) of the problem `a` (TM = 64, or 32 for problems that would not cover the chip with 64-row tiles:
+// M = 768 rows x N <= 1024 is 48 .. 192 workgroups, each a serial chain of K/4 x 4 fp32 MFMAs per wave); lds: 4 * TILE_F floats
+template <bool AKM, bool BKM, bool GUARD, int TM = 64>
 __device__ __forceinline__ void hgemm_tile(const HGemmArgs& a, int bx, int by, float* lds, bool avec, bool bvec) {
+  constexpr int MI = TM / 32;             // 16-row accumulator tiles per wave along m
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int m0 = by * 64, n0 = bx * 64;
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int m0 = by * TM, n0 = bx * 64;
+  const int wm = (wave >> 1) * (TM / 2), wn = (wave & 1) * 32;
   f32x4_t acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -132,35 +148,35 @@ __device__ __forceinline__ void hgemm_tile(const HGemmArgs& a, int bx, int by, f
 
   f32x4_t ra[NPASS], rb[NPASS];
   const int nt = (a.K + TK - 1) / TK;
-  tile_load<AKM, GUARD>(a.A, a.sam, a.sak, m0, a.M, 0, a.K, avec, ra);
+  tile_load<AKM, GUARD, TM>(a.A, a.sam, a.sak, m0, a.M, 0, a.K, avec, ra);
   tile_load<BKM, GUARD>(a.B, a.sbn, a.sbk, n0, a.N, 0, a.K, bvec, rb);
-  tile_store<AKM>(lds, ra);
+  tile_store<AKM, TM>(lds, ra);
   tile_store<BKM>(lds + TILE_F, rb);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const float* As = lds + (t & 1) * 2 * TILE_F;
     const float* Bs = As + TILE_F;
     if (t + 1 < nt) {   // request the next tile before this tile's MFMAs
-      tile_load<AKM, GUARD>(a.A, a.sam, a.sak, m0, a.M, (t + 1) * TK, a.K, avec, ra);
+      tile_load<AKM, GUARD, TM>(a.A, a.sam, a.sak, m0, a.M, (t + 1) * TK, a.K, avec, ra);
       tile_load<BKM, GUARD>(a.B, a.sbn, a.sbk, n0, a.N, (t + 1) * TK, a.K, bvec, rb);
       __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the MFMAs (the scheduler would sink them)
     }
 #pragma unroll
     for (int q = 0; q < TK / 4; ++q) {
-      float af[2], bf[2];
+      float af[2] = {0.f, 0.f}, bf[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = As[lds_at(4 * q + g, wm + i * 16 + li)];
+      for (int i = 0; i < MI; ++i) af[i] = As[lds_at(4 * q + g, wm + i * 16 + li)];
 #pragma unroll
       for (int j = 0; j < 2; ++j) bf[j] = Bs[lds_at(4 * q + g, wn + j * 16 + li)];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[i][j], 0, 0, 0);
       if (want_rs) { rs[0] += af[0]; rs[1] += af[1]; }
     }
     if (t + 1 < nt) {
       float* An = lds + ((t + 1) & 1) * 2 * TILE_F;
-      tile_store<AKM>(An, ra);
+      tile_store<AKM, TM>(An, ra);
       tile_store<BKM>(An + TILE_F, rb);
     }
     __syncthreads();
@@ -169,7 +185,7 @@ __device__ __forceinline__ void hgemm_tile(const HGemmArgs& a, int bx, int by, f
   const int m_base = m0 + wm, n_base = n0 + wn;
   if (want_rs) {   // combine the 4 k-groups (lanes li, li+16, li+32, li+48)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
       float v = rs[i];
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
@@ -181,7 +197,7 @@ __device__ __forceinline__ void hgemm_tile(const HGemmArgs& a, int bx, int by, f
   const bool vec_out = (a.ldc % 4 == 0) && (a.N % 4 == 0) && (((uintptr_t)a.C & 15) == 0) &&
                        (a.resid == nullptr || (a.ldr % 4 == 0 && ((uintptr_t)a.resid & 15) == 0));
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < MI; ++i) {
     const int m = m_base + i * 16 + li;
     if (m >= a.M) continue;
     const float* trow = a.table ? a.table + (long)((m / a.tab_div) % a.tab_mod) * a.tab_si : nullptr;
@@ -227,22 +243,26 @@ __device__ __forceinline__ void hgemm_tile(const HGemmArgs& a, int bx, int by, f
 }
 
 // operand forms: A k-major <=> sak != 1 (then sam == 1); B k-major <=> sbk != 1 (then sbn == 1)
-template <bool AKM, bool BKM, bool GUARD>
+template <bool AKM, bool BKM, bool GUARD, int TM = 64>
 __global__ __launch_bounds__(256) void hgemm_kernel(HGemmArgs a, int avec, int bvec) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // 4 * TILE_F floats (80 KiB)
-  hgemm_tile<AKM, BKM, GUARD>(a, blockIdx.x, blockIdx.y, lds, avec != 0, bvec != 0);
+  hgemm_tile<AKM, BKM, GUARD, TM>(a, blockIdx.x, blockIdx.y, lds, avec != 0, bvec != 0);
 }
 
 // Backward of y = x W^T + b in one launch: tiles [0, nx) compute dX = dy . W (A = dy k-contiguous, B = W k-major),
 // tiles [nx, nx + nw) compute dW (+)= dy^T . x (both k-major) and, in their first tile column, db (+)= colsum(dy).
-template <bool GUARD>
+template <bool GUARD, int TM = 64>
 __global__ __launch_bounds__(256) void hlinear_bwd_kernel(HGemmArgs dx, HGemmArgs dw, int nx, int dx_tiles_n, int dw_tiles_n,
                                                           int dx_avec, int dx_bvec, int dw_avec, int dw_bvec) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // 4 * TILE_F floats (80 KiB)
   const int b = blockIdx.x;
-  if (b < nx) hgemm_tile<false, true, GUARD>(dx, b % dx_tiles_n, b / dx_tiles_n, lds, dx_avec != 0, dx_bvec != 0);
-  else hgemm_tile<true, true, GUARD>(dw, (b - nx) % dw_tiles_n, (b - nx) / dw_tiles_n, lds, dw_avec != 0, dw_bvec != 0);
+  if (b < nx) hgemm_tile<false, true, GUARD, TM>(dx, b % dx_tiles_n, b / dx_tiles_n, lds, dx_avec != 0, dx_bvec != 0);
+  else hgemm_tile<true, true, GUARD, TM>(dw, (b - nx) % dw_tiles_n, (b - nx) / dw_tiles_n, lds, dw_avec != 0, dw_bvec != 0);
 }
+
+// half-height tiles where 64-row tiles would leave most of the chip idle (MVF_HGEMM_TM=64 | 32 pins the height: A/B measurements)
+int g_hgemm_tm = [] { const char* e = getenv("MVF_HGEMM_TM"); return e ? atoi(e) : 0; }();
+int pick_tm(long tiles64) { return g_hgemm_tm == 64 || g_hgemm_tm == 32 ? g_hgemm_tm : (tiles64 < 192 ? 32 : 64); }
 
 // out[c] (+)= sum_r x[r*ld + c]   -- bias gradients that are not attached to a weight-gradient GEMM
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ld, int rows, int cols,
@@ -318,20 +338,25 @@ extern "C" int mvf_hgemm_ex(const float* A, long sam, long sak, const float* B, 
   // a [1, K] or [K, 1] operand has both strides "1": prefer the k-contiguous reading
   const bool akm = sak != 1, bkm = sbk != 1;
   const int avec = can_vec(A, akm ? sak : sam), bvec = can_vec(B, bkm ? sbk : sbn);
-  dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
+  const int tm = pick_tm((long)ceil_div(N, 64) * ceil_div(M, 64));
+  dim3 grid(ceil_div(N, 64), ceil_div(M, tm));
   const bool full = avec && bvec && M % 64 == 0 && N % 64 == 0 && K % TK == 0;
+#define HG2(AK, BK, GD, TMV)                                                                                \
+  do {                                                                                                      \
+    allow_lds(hgemm_kernel<AK, BK, GD, TMV>);                                                               \
+    hipLaunchKernelGGL((hgemm_kernel<AK, BK, GD, TMV>), grid, dim3(256), LDS_B, st, a, avec, bvec);         \
+  } while (0)
 #define HG(AK, BK)                                                                                          \
   do {                                                                                                      \
-    allow_lds(hgemm_kernel<AK, BK, false>);                                                                 \
-    allow_lds(hgemm_kernel<AK, BK, true>);                                                                  \
-    if (full) hipLaunchKernelGGL((hgemm_kernel<AK, BK, false>), grid, dim3(256), LDS_B, st, a, avec, bvec);     \
-    else hipLaunchKernelGGL((hgemm_kernel<AK, BK, true>), grid, dim3(256), LDS_B, st, a, avec, bvec);           \
+    if (tm == 32) { if (full) HG2(AK, BK, false, 32); else HG2(AK, BK, true, 32); }                         \
+    else { if (full) HG2(AK, BK, false, 64); else HG2(AK, BK, true, 64); }                                  \
   } while (0)
   if (akm && bkm) HG(true, true);
   else if (akm) HG(true, false);
   else if (bkm) HG(false, true);
   else HG(false, false);
 #undef HG
+#undef HG2
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }
@@ -351,16 +376,20 @@ extern "C" int mvf_hlinear_bwd(const float* dy, long ldy, const float* x, long l
   gw.A = dy; gw.sam = 1; gw.sak = ldy; gw.B = x; gw.sbk = ldx; gw.sbn = 1; gw.C = dW; gw.ldc = lddw;
   gw.M = N; gw.N = K; gw.K = M; gw.alpha = 1.f; gw.tab_div = gw.tab_mod = 1; gw.d_scale = 1.f;
   gw.accumulate = accumulate_params; gw.rowsum = db; gw.rowsum_acc = accumulate_params;
-  const int dxn = ceil_div(K, 64), dxm = ceil_div(M, 64), dwn = ceil_div(K, 64), dwm = ceil_div(N, 64);
+  const long t64 = (long)(dx != nullptr ? ceil_div(K, 64) * ceil_div(M, 64) : 0) + (long)ceil_div(K, 64) * ceil_div(N, 64);
+  const int tm = pick_tm(t64);
+  const int dxn = ceil_div(K, 64), dxm = ceil_div(M, tm), dwn = ceil_div(K, 64), dwm = ceil_div(N, tm);
   const int nx = dx != nullptr ? dxn * dxm : 0, nw = dwn * dwm;
   const bool full = can_vec(dy, ldy) && can_vec(W, ldw) && can_vec(x, ldx) && M % 64 == 0 && N % 64 == 0 && K % 64 == 0;
-  allow_lds(hlinear_bwd_kernel<false>);
-  allow_lds(hlinear_bwd_kernel<true>);
-  if (full)
-    hipLaunchKernelGGL(hlinear_bwd_kernel<false>, dim3(nx + nw), dim3(256), LDS_B, st, gx, gw, nx, dxn, dwn, 1, 1, 1, 1);
-  else
-    hipLaunchKernelGGL(hlinear_bwd_kernel<true>, dim3(nx + nw), dim3(256), LDS_B, st, gx, gw, nx, dxn, dwn,
-                       (int)can_vec(dy, ldy), (int)can_vec(W, ldw), (int)can_vec(dy, ldy), (int)can_vec(x, ldx));
+  const int v0 = full ? 1 : (int)can_vec(dy, ldy), v1 = full ? 1 : (int)can_vec(W, ldw), v3 = full ? 1 : (int)can_vec(x, ldx);
+#define HB(GD, TMV)                                                                                                         \
+  do {                                                                                                                      \
+    allow_lds(hlinear_bwd_kernel<GD, TMV>);                                                                                 \
+    hipLaunchKernelGGL((hlinear_bwd_kernel<GD, TMV>), dim3(nx + nw), dim3(256), LDS_B, st, gx, gw, nx, dxn, dwn, v0, v1, v0, v3); \
+  } while (0)
+  if (tm == 32) { if (full) HB(false, 32); else HB(true, 32); }
+  else { if (full) HB(false, 64); else HB(true, 64); }
+#undef HB
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

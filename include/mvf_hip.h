@@ -201,11 +201,12 @@ int mvf_layernorm_fwd(int out_dtype, const float* x, size_t in_stride, const flo
 int mvf_vit_attn_fwd(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t stream);
 /* timm Attention.qkv FUSED into the attention core (reached from models/transformer.py:188): out [F*N, D] = per (frame, head)
  * softmax(q k^T / 8) v with [q | k | v] = A[f] W_h^T + bias (ln_c / ln_mr NULL), or the folded-LayerNorm form
- * rstd (A W'^T - mean ln_c) + bias of mvf_gemm_tc_ln (ln_c [3D], ln_mr [F*N][2]).  A [F*N, lda] and W [3D, D] bf16 (MVF_BF16) or
+ * rstd (A W'^T - mean ln_c) + bias of mvf_gemm_tc_ln (ln_c [3D]; the rows' statistics as ln_mr [F*N][2], or -- ln_mr NULL -- as the
+ * producer's partial sums ln_part [ln_ns][F*N][2] with ln_eps, as mvf_gemm_tc_ln_part takes them).  A [F*N, lda] and W [3D, D] bf16 (MVF_BF16) or
  * fp16 (MVF_F16); A != out.  The [F*N, 3D] qkv tensor never reaches HBM; bit-identical to mvf_gemm_tc(_ln) + mvf_vit_attn_fwd.
  * MVF_ERR_UNSUPPORTED unless N = 193 .. 208, D = 64 H, D % 96 == 0. */
 int mvf_vit_qkv_attn_fwd(int dtype, const void* A, int lda, const void* W, const float* bias, const float* ln_c, const float* ln_mr,
-                         void* out, int F, int N, int H, int D, hipStream_t stream);
+                         const float* ln_part, int ln_ns, float ln_eps, void* out, int F, int N, int H, int D, hipStream_t stream);
 int mvf_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t stream);
 int mvf_cast_f32_f16(const float* in, void* out, size_t n, hipStream_t stream);      /* IEEE half, round to nearest even; n % 4 == 0 */
 int mvf_cast_bf16_f32(const void* in, float* out, size_t n, hipStream_t stream);     /* n % 4 == 0 */

@@ -210,8 +210,12 @@ def vit_block_bf16(x, w, p, heads, eps=1e-6, fold1=False, fold2=False, mx=False,
     q, k, v = qkv[0], qkv[1], qkv[2]
     s = (q @ k.transpose(-1, -2)) * hd ** -0.5
     pr = torch.exp(s - s.max(-1, keepdim=True)[0])
-    prr = r(pr)                                            # P in bf16 for P.V; its row sum is taken over the SAME rounded values
-    a = r((prr @ v) / prr.sum(-1, keepdim=True))           # (fp32 accumulation: the product sums them as a fifth P.V column of ones)
+    prr = r(pr)                                            # P in bf16 for P.V
+    # the row sum: over the SAME rounded values where the product's kernel takes it on the matrix pipe (a fifth P.V column of ones,
+    # fp32 accumulation: the 193..208-token kernels of vit_attn.hip / vit_qkv_attn.hip), over the unrounded fp32 values in its
+    # streamed kernel for every other sequence length
+    rs = prr.sum(-1, keepdim=True) if 193 <= n <= 208 else pr.sum(-1, keepdim=True)
+    a = r((prr @ v) / rs)
     a = a.transpose(1, 2).reshape(f, n, d)
     if defer_proj:
         # deferred residual: the branch output (LayerScale folded into proj's weights and bias) is stored as bf16 before it is

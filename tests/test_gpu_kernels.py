@@ -468,13 +468,15 @@ def _pack(w, depth, dim, heads, patch, img, taps, dtype):
 
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
 @pytest.mark.parametrize('F,N,D,H,fold', [(3, 197, 768, 12, True), (70, 197, 768, 12, True), (70, 197, 768, 12, False), (5, 208, 384, 6, True),
-                                          (9, 193, 768, 12, False), (256, 197, 768, 12, True)])
+                                          (9, 193, 768, 12, False), (256, 197, 768, 12, True), (70, 197, 768, 12, 'part'),
+                                          (5, 208, 384, 6, 'part'), (256, 197, 768, 12, 'part')])
 def test_qkv_projection_fused_into_attention_is_bitwise_the_two_kernels(F, N, D, H, fold, dtype):
     """mvf_vit_qkv_attn_fwd (one head's Q, K, V of one frame computed into LDS and attended there: the [F*N, 3D] qkv tensor never
     reaches HBM) against mvf_gemm_tc / mvf_gemm_tc_ln + mvf_vit_attn_fwd on the same operands: the same MFMA k-order, the same fold
     and rounding points, the same attention body -- the outputs must agree BIT FOR BIT.  Plain-bias and folded-LayerNorm forms,
-    bf16 and fp16, padded last token tile (197, 193) and none (208), several units per workgroup (70, 256 frames), repeated launches
-    as a race screen."""
+    bf16 and fp16, padded last token tile (197, 193) and none (208), 70 and 256 frames, repeated launches as a race screen.
+    fold = 'part': the rows' statistics handed over as the producer's PARTIAL sums [D/64][M][2] (what the fc2 residual epilogue writes)
+    and finalized in the kernel -- against mvf_ln_stats_finalize + the (mean, rstd) form, bit for bit."""
     code, tdt = (_lib.F16, torch.float16) if dtype == 'fp16' else (_lib.BF16, torch.bfloat16)
     g = gen(91)
     M = F * N
@@ -482,11 +484,20 @@ def test_qkv_projection_fused_into_attention_is_bitwise_the_two_kernels(F, N, D,
     W = (torch.randn(3 * D, D, generator=g) * 0.06).to(DEV).to(tdt)
     b = torch.randn(3 * D, generator=g).to(DEV)
     qkv = torch.empty(M, 3 * D, device=DEV, dtype=tdt)
-    mr = c = None
-    if fold:
+    mr = c = part = None
+    ns = 0
+    if fold == 'part':
+        ns = D // 64
+        xs = A.float().view(M, ns, 64)
+        part = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).permute(1, 0, 2).contiguous()      # [ns][M][2]
+        mr = torch.empty(M, 2, device=DEV)
+        _lib.call('mvf_ln_stats_finalize', part.data_ptr(), ns, mr.data_ptr(), M, D, 1e-6, S())
+        mean, rstd = mr[:, 0], mr[:, 1]
+    elif fold:
         mean = A.float().mean(-1)
         rstd = 1.0 / torch.sqrt(A.float().var(-1, unbiased=False) + 1e-6)
         mr = torch.stack([mean, rstd], 1).contiguous()
+    if fold:
         c = W.float().sum(1).contiguous()
         _lib.call('mvf_gemm_tc_ln', code, 0, A.data_ptr(), D, W.data_ptr(), D, b.data_ptr(), qkv.data_ptr(), 3 * D, None, 0, None, 0,
                   None, N, None, 0, None, mr.data_ptr(), c.data_ptr(), M, 3 * D, D, S())
@@ -495,10 +506,10 @@ def test_qkv_projection_fused_into_attention_is_bitwise_the_two_kernels(F, N, D,
                   None, None, N, M, 3 * D, D, S())
     ref = torch.full((M, D), 7.0, device=DEV, dtype=tdt)
     _lib.call('mvf_vit_attn_fwd', code, qkv.data_ptr(), ref.data_ptr(), F, N, H, D, 0, S())
-    for rep in range(3):
+    for rep in range(2):           # (twice: a second launch over warm caches)
         out = torch.full((M, D), 7.0, device=DEV, dtype=tdt)
-        _lib.call('mvf_vit_qkv_attn_fwd', code, A.data_ptr(), D, W.data_ptr(), b.data_ptr(), _lib.ptr(c), _lib.ptr(mr), out.data_ptr(),
-                  F, N, H, D, S())
+        _lib.call('mvf_vit_qkv_attn_fwd', code, A.data_ptr(), D, W.data_ptr(), b.data_ptr(), _lib.ptr(c),
+                  None if part is not None else _lib.ptr(mr), _lib.ptr(part), ns, 1e-6, out.data_ptr(), F, N, H, D, S())
         torch.cuda.synchronize()
         bad = (out != ref)
         assert not bad.any(), (rep, int(bad.sum()), bad.nonzero()[:5].tolist(), (out.float() - ref.float()).abs().max().item())
@@ -509,8 +520,12 @@ def test_qkv_projection_fused_into_attention_is_bitwise_the_two_kernels(F, N, D,
             q = rstd.double().cpu()[:, None] * (q - mean.double().cpu()[:, None] * c.double().cpu())
         q = (q + b.double().cpu()).to(tdt).double()
         check(out, _attn_ref(q.to(tdt), F, N, H), 2e-2 if dtype == 'bf16' else 4e-3, 'fused qkv + attention vs fp64')
-    assert not _lib.try_call('mvf_vit_qkv_attn_fwd', code, A.data_ptr(), D, W.data_ptr(), b.data_ptr(), _lib.ptr(c), _lib.ptr(mr),
-                             out.data_ptr(), 1, 257, H, D, S())
+    assert not _lib.try_call('mvf_vit_qkv_attn_fwd', code, A.data_ptr(), D, W.data_ptr(), b.data_ptr(), _lib.ptr(c),
+                             None if part is not None else _lib.ptr(mr), _lib.ptr(part), ns, 1e-6, out.data_ptr(), 1, 257, H, D, S())
+    if part is not None:           # statistics in both forms at once: a bad argument
+        with pytest.raises(_lib.MvfError):
+            _lib.call('mvf_vit_qkv_attn_fwd', code, A.data_ptr(), D, W.data_ptr(), b.data_ptr(), _lib.ptr(c), _lib.ptr(mr),
+                      _lib.ptr(part), ns, 1e-6, out.data_ptr(), F, N, H, D, S())
 
 
 @pytest.mark.parametrize('dim,depth,heads,patch,img,F', [(128, 2, 2, 16, 32, 3), (768, 12, 12, 16, 224, 2),

@@ -152,8 +152,8 @@ def main():
         call('mvf_vit_attn_fwd', _lib.BF16, qkv.data_ptr(), h.data_ptr(), F, N, H, D, 6, st)
 
     def k_qkv_attn():      # qkv projection fused into the attention kernel (folded-LayerNorm form, as blocks 1.. run it)
-        call('mvf_vit_qkv_attn_fwd', _lib.BF16, xb.data_ptr(), D, Wqkv.data_ptr(), b3.data_ptr(), c3.data_ptr(), mr.data_ptr(), h.data_ptr(),
-             F, N, H, D, st)
+        call('mvf_vit_qkv_attn_fwd', _lib.BF16, xb.data_ptr(), D, Wqkv.data_ptr(), b3.data_ptr(), c3.data_ptr(), mr.data_ptr(), None, 0, 0.0,
+             h.data_ptr(), F, N, H, D, st)
 
     def k_ln():
         call('mvf_layernorm_fwd', _lib.BF16, x.data_ptr(), D, g.data_ptr(), be.data_ptr(), h.data_ptr(), D, M, D, 1e-6, st)

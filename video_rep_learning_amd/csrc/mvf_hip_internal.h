@@ -46,8 +46,9 @@ int mvf_layernorm_impl(int out_dtype, const float* x, size_t in_stride, const fl
 int mvf_cast_bf16_impl(const float* in, void* out, size_t n, hipStream_t st);
 int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t st);
 // vit_qkv_attn.hip: the qkv projection fused into the attention kernel (N = 193 .. 208); MVF_ERR_UNSUPPORTED outside its shapes
+// (folded form: the rows' statistics as ln_mr pairs, or as the producer's partial sums ln_part [ln_ns][F*N][2] finalized in the kernel)
 int mvf_qkv_attn_impl(int dtype, const void* A, int lda, const void* W, const float* bias, const float* ln_c, const float* ln_mr,
-                      void* out, int F, int N, int H, int D, hipStream_t st);
+                      const float* ln_part, int ln_ns, float ln_eps, void* out, int F, int N, int H, int D, hipStream_t st);
 // shapes the fused kernel takes (and MVF_FUSE_QKV != 0: the variable keeps the GEMM + attention launches for A/B measurements)
 bool mvf_qkv_attn_supported(int dtype, int F, int N, int H, int D, int lda);
 

@@ -196,13 +196,18 @@ int run_blocks(const MvfVitWeights* w, int dtype, bool fp8, const Ws& ws, int fc
     if (fused_attn) {
       if (folded(w->qkv_c, l)) {
         if (l == l0) return MVF_ERR_ARG;   // nothing in this call produced the layer's statistics
-        RUN(mvf_ln_stats_finalize_impl(ws.stats, ns, ws.mr, Mc, D, w->ln_eps, st));
-        RUN(mvf_qkv_attn_impl(dtype, ws.xb, D, w->qkv_w[l], w->qkv_b[l], w->qkv_c[l], ws.mr, ws.h, fc, N, H, D, st));
+        // (the kernel turns the producer's partial sums into (mean, rstd) itself: no finalize launch between fc2 and this one)
+        if (g_ln_inkernel) {
+          RUN(mvf_qkv_attn_impl(dtype, ws.xb, D, w->qkv_w[l], w->qkv_b[l], w->qkv_c[l], nullptr, ws.stats, ns, w->ln_eps, ws.h, fc, N, H, D, st));
+        } else {
+          RUN(mvf_ln_stats_finalize_impl(ws.stats, ns, ws.mr, Mc, D, w->ln_eps, st));
+          RUN(mvf_qkv_attn_impl(dtype, ws.xb, D, w->qkv_w[l], w->qkv_b[l], w->qkv_c[l], ws.mr, nullptr, 0, 0.f, ws.h, fc, N, H, D, st));
+        }
       } else {
         // the LayerNorm output is parked in the (otherwise unused) qkv buffer: the kernel's output goes to ws.h, and a unit's
         // output columns must not land in rows another (frame, head) unit of the same launch still reads as its operand
         RUN(mvf_layernorm_impl(dtype, ws.x, D, w->ln1_w[l], w->ln1_b[l], ws.qkv, D, Mc, D, w->ln_eps, st));
-        RUN(mvf_qkv_attn_impl(dtype, ws.qkv, D, w->qkv_w[l], w->qkv_b[l], nullptr, nullptr, ws.h, fc, N, H, D, st));
+        RUN(mvf_qkv_attn_impl(dtype, ws.qkv, D, w->qkv_w[l], w->qkv_b[l], nullptr, nullptr, nullptr, 0, 0.f, ws.h, fc, N, H, D, st));
       }
     }
     if (fused_attn) {

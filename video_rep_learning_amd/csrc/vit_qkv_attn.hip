@@ -8,27 +8,32 @@
 // what ~175 bf16 FLOPs cost.  The qkv tensor is 232 MB written by the GEMM and 232 MB read back by the attention kernel per ViT
 // block, 464 MB of the block's 2.24 GB.  Here a workgroup computes one head's Q, K, V for one frame (a 208 x 192 x 768 GEMM,
 // 61 MFLOP) into LDS images and runs the attention on them; HBM sees A (shared by the frame's 12 heads through L2) and the output.
+// Measured at BASELINE configs[1] (256 frames, profiles/r04/qkv_attn_fused.txt): 218 us / 296 mJ per launch against 175 + 74 us /
+// 225 + 98 mJ for the qkv GEMM + attention kernel on the same box.
 //
 // gfx950 design:
-//  * 512 threads = 8 waves as 2 (token rows: 7 | 6 tiles of 16) x 4 (48 of the 192 q|k|v columns each); v_mfma_f32_16x16x32 with the
-//    W fragment as the A operand, so a lane owns 4 consecutive channels of one token (8-byte LDS stores of the results)
+//  * ONE (frame, head) unit per 256-thread workgroup, TWO workgroups per CU: a unit's GEMM phase (~35 k cycles, matrix pipe) and
+//    attention phase (~20 k cycles, VALU / latency) are complementary, and the CU's second workgroup drifts half a unit out of phase
+//    by itself.  (The first form built -- one persistent 8-wave workgroup per CU with the next unit's K tiles prefetched under the
+//    attention phase -- ran the two phases back to back: 264 us per launch at the full 2.39 GHz, below the power cap, i.e.
+//    schedule-bound; it is gone, its numbers are in the profile file.)
+//  * 4 waves as 1 (all 13 token tiles of 16) x 4 (48 of the 192 q|k|v columns each): 156 accumulator registers per lane;
+//    v_mfma_f32_16x16x32 with the W fragment as the A operand, so a lane owns 4 consecutive channels of one token (8-byte LDS
+//    stores of the results).  The token fragments stream through three registers sets two tiles ahead of their MFMAs, read and
+//    waited for by hand (comment at the loop).
 //  * K tile = 32 channels (64-byte LDS rows, one MFMA k-step), a ring of THREE operand buffers filled by LDS-DMA
 //    (global_load_lds_dwordx4; 16 rows per 1-KiB piece; chunk index XOR-ed with (-(row >> 2)) & 3 on the source address and on the
-//    ds_read_b128 address: the four rows that share a 256-byte bank row of the LDS get four different 16-byte slots);
-//        per K tile t:  [L: fragments of tile t, issue tile t+2]  s_barrier  [C: MFMAs of tile t]  s_barrier
-//    with wave row 1 one barrier behind wave row 0, so each SIMD has one wave in its matrix segment while its partner loads (the
-//    first form -- one barrier per K tile, all eight waves in step -- took 1.7 k cycles per K tile against 0.62 k of MFMA work:
-//    264 us per launch at the full 2.38 GHz, i.e. not even power-bound).  Hazards: the comment at the loop.  24 K tiles per unit
-//    and a ring of 3: the ring runs straight through unit boundaries -- tiles 0 / 1 of the NEXT (frame, head) are in flight while
-//    this one's attention runs.
-//  * epilogue: LayerNorm fold + bias (the tile's bias / c / (mean, rstd) slices arrive by LDS-DMA at the unit's first K tile: a
-//    VGPR load here would make hipcc drain the next unit's DMAs), bf16 (fp16) rounding, 8-byte stores into the Q / K / V images in
-//    the layouts vit_attn_tiles.h reads (K, Q: 16-byte chunks XOR (row & 7); V: 32-byte chunks rotated by (row >> 1) & 3)
-//  * attention: 13 query tiles on 8 waves -- waves 0-4 a pair (w, w + 8), waves 5-7 one -- with the two-tile body of the unfused
-//    kernel (attn_tiles): the same arithmetic in the same order, so the output is BIT-IDENTICAL to qkv GEMM + attention kernel
-//  * persistent: one workgroup per CU; XCD x (blockIdx & 7, speed only) walks the (frame, head) units of frames f = x mod 8,
-//    frame-major, so the 12 heads of a frame meet their A rows in that XCD's L2.
-// LDS: ring 3 x 25 600 + images 3 x 26 624 + bias / c / (mean, rstd) 3 200 = 159 872 bytes (one workgroup per CU).
+//    ds_read_b128 address: the four rows that share a 256-byte bank row of the LDS get four different 16-byte slots); one counted
+//    vmcnt wait + one s_barrier per K tile.  No look-ahead into another unit: the other workgroup covers the cold start.
+//  * epilogue: LayerNorm fold + bias, bf16 (fp16) rounding, 8-byte stores into the Q / K / V images in the layouts
+//    vit_attn_tiles.h reads (K, Q: 16-byte chunks XOR (row & 7); V: 32-byte chunks rotated by (row >> 1) & 3).  The images go ON TOP
+//    of the operand ring once its last K tile has been read; the unit's (mean, rstd) pairs arrive by LDS-DMA at kernel start behind
+//    them (a plain load per token tile here cost 13 exposed L2 round trips per unit).
+//  * attention: the stand-alone kernel's split -- query tiles {w, w + 4} then {w + 8, w + 12} -- with its two-tile body
+//    (attn_tiles): the same arithmetic in the same order, so the output is BIT-IDENTICAL to qkv GEMM + attention kernel.
+//  * grid 8 x ceil(F / 8) x H; XCD x (blockIdx & 7, speed only) gets the frames f = x mod 8, head-minor, so the 12 heads of a
+//    frame meet their A rows in that XCD's L2.
+// LDS: images 3 x 26 624 (>= ring 3 x 25 600) + (mean, rstd) 1 664 = 81 536 bytes, two workgroups per CU.
 #include "common.h"
 #include "mvf_hip_internal.h"
 #include "gemm_tc_epi.h"
@@ -45,12 +50,8 @@ constexpr int NCOL = 192;                    // q | k | v columns of one head
 constexpr int KE = 32;                       // K tile, elements (64-byte rows)
 constexpr int A_BYTES = NTOK * 64, B_BYTES = NCOL * 64, BUF_BYTES = A_BYTES + B_BYTES;
 constexpr int RING = 3;
+constexpr int NPA = NTOK / 16;                // 1-KiB pieces per K tile: 13 of A, then 12 of W
 constexpr int IMG = NTOK * 128;              // one of the Q / K / V images: [token][64] 16-bit, 128-byte rows
-constexpr int OFF_Q = RING * BUF_BYTES, OFF_K = OFF_Q + IMG, OFF_V = OFF_K + IMG;
-constexpr int OFF_BIAS = OFF_V + IMG, OFF_C = OFF_BIAS + NCOL * 4, OFF_MR = OFF_C + NCOL * 4;
-constexpr int LDS_TOTAL = OFF_MR + NTOK * 8;
-static_assert(LDS_TOTAL <= 160 * 1024, "LDS");
-constexpr int NPA = NTOK / 16, NPB = NCOL / 16, NPIECE = NPA + NPB;     // 1-KiB pieces per K tile: 13 + 12
 
 struct QkvAttnArgs {
   const char* A;       // [F*N, lda] 16-bit
@@ -58,222 +59,199 @@ struct QkvAttnArgs {
   const float* bias;   // [3*D] (b, or d = b + W beta when folded)
   const float* ln_c;   // [3*D] or NULL
   const float* ln_mr;  // [F*N][2] (mean, rstd) or NULL
+  const float* ln_part;  // folded, ln_mr NULL: the producer's partial sums [ln_ns][F*N][2] (sum, sum of squares per 64-column slice)
+  int ln_ns;
+  float ln_inv_d, ln_eps;
   char* out;           // [F*N, D] 16-bit
   int lda, F, N, H, D;
   float scale_log2;
 };
 
 #define WAIT_VMCNT_IMM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define LDS_RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+constexpr int OFF_MR = 3 * IMG;  // the unit's (mean, rstd) pairs behind the images (79 872 >= RING * BUF_BYTES = 76 800)
+constexpr int LDS_TOTAL = OFF_MR + NTOK * 8;
+static_assert(3 * IMG >= RING * BUF_BYTES && 2 * LDS_TOTAL <= 160 * 1024, "LDS");
 
 template <bool F16>
-__global__ __launch_bounds__(512, 2) void vit_qkv_attn_kernel(QkvAttnArgs a) {
+__global__ __launch_bounds__(256, 2) void vit_qkv_attn_kernel(QkvAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
   const int li = lane & 15, g = lane >> 4;
-  const int nmt = wr ? 6 : 7;                        // this wave row's token tiles (wave-uniform)
-  const int mt0 = wr * 7;
+  const int xcd = blockIdx.x & 7, ui = blockIdx.x >> 3;
+  const int f = xcd + 8 * (ui / a.H), h = ui % a.H;
+  if (f >= a.F) return;                                // (whole workgroup: the grid is 8 x ceil(F / 8) x H)
 
-  // ---- unit walk: XCD x owns frames x, x + 8, ...; its workgroups take (frame, head) units slot, slot + nslots, ...
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int nslots = (gridDim.x - xcd + 7) >> 3;
-  const int nfx = a.F > xcd ? (a.F - xcd + 7) >> 3 : 0;
-  const int nunits = nfx * a.H;
-  int u = slot;
-  if (u >= nunits) return;
-
-  // ---- LDS-DMA sources: piece p = wave, wave + 8, ... (< 25) of a K tile = 16 rows x 64 B; lane -> (row 16 p' + lane / 4, physical
-  // chunk lane % 4); logical chunk = physical ^ ((-(row >> 2)) & 3)
+  // piece p = wave + 4 i of a K tile (25 = 13 A + 12 W pieces of 16 rows x 64 B): i = 0..2 A; i = 3 A for wave 0, W else; i = 4, 5 W;
+  // i = 6 W, wave 0 only
   const int prow = lane >> 2, pch = lane & 3;
-  unsigned src[4];                                   // byte offsets from a.A (A pieces) / a.W (W pieces), K tile 0
-  auto set_sources = [&](int unit) {
-    const int f = xcd + 8 * (unit / a.H), h = unit % a.H;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int p = wave + 8 * i;
-      if (p < NPA) {
-        const int r = p * 16 + prow;
-        const int lc = pch ^ ((-(r >> 2)) & 3);
-        src[i] = (unsigned)(f * a.N + min(r, a.N - 1)) * (unsigned)(a.lda * 2) + lc * 16;
-      } else if (p < NPIECE) {
-        const int n = (p - NPA) * 16 + prow;            // 0 .. 191: q | k | v row of W for head h
-        const int lc = pch ^ ((-(n >> 2)) & 3);
-        src[i] = (unsigned)((n >> 6) * a.D + h * HD + (n & 63)) * (unsigned)(a.D * 2) + lc * 16;
-      } else {
-        src[i] = 0;
-      }
-    }
+  unsigned src[7];
+  auto a_src = [&](int p) {
+    const int r = p * 16 + prow;
+    return (unsigned)(f * a.N + min(r, a.N - 1)) * (unsigned)(a.lda * 2) + (unsigned)((pch ^ ((-(r >> 2)) & 3)) * 16);
   };
+  auto w_src = [&](int p) {
+    const int n = (p - NPA) * 16 + prow;
+    return (unsigned)((n >> 6) * a.D + h * HD + (n & 63)) * (unsigned)(a.D * 2) + (unsigned)((pch ^ ((-(n >> 2)) & 3)) * 16);
+  };
+#pragma unroll
+  for (int i = 0; i < 3; ++i) src[i] = a_src(wave + 4 * i);
+  src[3] = wave == 0 ? a_src(12) : w_src(wave + 12);
+  src[4] = w_src(wave + 16);
+  src[5] = w_src(wave + 20);
+  src[6] = w_src(24);
+  const char* const g3 = wave == 0 ? a.A : a.W;
+  const int d3 = wave == 0 ? 12 * 1024 : A_BYTES + (wave + 12 - NPA) * 1024;
   auto issue = [&](int buf, int kt) {
     char* base = smem + buf * BUF_BYTES;
     const unsigned koff = (unsigned)kt * (KE * 2);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int p = wave + 8 * i;
-      if (p < NPA)
-        __builtin_amdgcn_global_load_lds(GLB_PTR(a.A + (size_t)(src[i] + koff)), LDS_PTR(base + p * 1024), 16, 0, 0);
-      else if (p < NPIECE)
-        __builtin_amdgcn_global_load_lds(GLB_PTR(a.W + (size_t)(src[i] + koff)), LDS_PTR(base + A_BYTES + (p - NPA) * 1024), 16, 0, 0);
-    }
+    for (int i = 0; i < 3; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(a.A + (size_t)(src[i] + koff)), LDS_PTR(base + (wave + 4 * i) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(g3 + (size_t)(src[3] + koff)), LDS_PTR(base + d3), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(a.W + (size_t)(src[4] + koff)), LDS_PTR(base + A_BYTES + (wave + 16 - NPA) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(a.W + (size_t)(src[5] + koff)), LDS_PTR(base + A_BYTES + (wave + 20 - NPA) * 1024), 16, 0, 0);
+    if (wave == 0)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(a.W + (size_t)(src[6] + koff)), LDS_PTR(base + A_BYTES + (24 - NPA) * 1024), 16, 0, 0);
   };
-  // the unit's bias / c / (mean, rstd) slices, 4 bytes per lane: waves 0-2 bias, 3-5 c, 0-6 the 416 floats of (mean, rstd)
-  auto issue_small = [&](int unit) {
-    const int f = xcd + 8 * (unit / a.H), h = unit % a.H;
-    if (wave < 3) {
-      const int n = wave * 64 + lane;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(a.bias + (n >> 6) * a.D + h * HD + (n & 63)), LDS_PTR(smem + OFF_BIAS + wave * 256), 4, 0, 0);
-    } else if (wave < 6 && a.ln_c != nullptr) {
-      const int n = (wave - 3) * 64 + lane;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(a.ln_c + (n >> 6) * a.D + h * HD + (n & 63)), LDS_PTR(smem + OFF_C + (wave - 3) * 256), 4, 0, 0);
-    }
-    if (wave < 7 && a.ln_mr != nullptr) {
-      const int fi = wave * 64 + lane;                  // float index into [208][2]
-      const int row = min(fi >> 1, a.N - 1);
-      if (fi < NTOK * 2)
-        __builtin_amdgcn_global_load_lds(GLB_PTR(a.ln_mr + ((size_t)f * a.N + row) * 2 + (fi & 1)), LDS_PTR(smem + OFF_MR + wave * 256), 4, 0, 0);
-    }
-  };
-
-  // fragment read offsets inside a buffer: lane (row li of a 16-row tile, k chunk g)
   const int frag = li * 64 + ((g ^ ((-(li >> 2)) & 3)) << 4);
-  const int nk = a.D / KE;                            // 24 at D = 768 (a multiple of RING: checked by the launch)
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(smem);
+  const int nk = a.D / KE;
 
-  set_sources(u);
+  f32x4_t acc[13][3];
+#pragma unroll
+  for (int i = 0; i < 13; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   issue(0, 0);
   issue(1, 1);
-  if (wave == 0) WAIT_VMCNT_IMM(4); else WAIT_VMCNT_IMM(3);     // tile 0 landed (this wave's pieces; tile 1 stays in flight)
-  __builtin_amdgcn_s_barrier();
-  for (;;) {
-    const int unext = u + nslots;
-    const bool have_next = unext < nunits;
-    f32x4_t acc[7][3];
-#pragma unroll
-    for (int i = 0; i < 7; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    // Two slots per K tile, [L: fragment reads of tile t + DMA issue of tile t + 2] barrier [C: the MFMAs of tile t] barrier, with wave
-    // row 1 running ONE barrier behind wave row 0: the two waves of a SIMD alternate, one in its matrix segment while its partner
-    // loads.  Every wave waits for its own pieces of tile t + 1 before the barrier that opens wave row 0's L(t + 1) -- wave row 0 at
-    // the end of C(t), wave row 1 at the end of L(t) -- so that tile is complete for both rows' reads; tile t + 2 stays in flight.
-    // The buffer tile t + 2 lands in held tile t - 1, whose last reads (wave row 1's L(t - 1)) are retired (lgkmcnt(0)) before the
-    // barrier in front of wave row 0's L(t), the first slot that issues into it.
-    if (wr == 1) __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < nk; ++t) {
-      // ---- L(t)
-      const char* ab = smem + (t % RING) * BUF_BYTES;
-      const char* bb = ab + A_BYTES;
-      bf16x8_t bf[3], af[7];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(bb + (wc * 3 + j) * 1024 + frag);
-#pragma unroll
-      for (int i = 0; i < 7; ++i)
-        if (i < nmt) af[i] = *reinterpret_cast<const bf16x8_t*>(ab + (mt0 + i) * 1024 + frag);
-      if (t == 0) issue_small(u);                     // (every wave is past the previous unit's epilogue, the regions' last reader)
-      const bool more = t + 2 < nk || have_next;      // a tile t + 2 exists (this unit's, or tile t + 2 - nk of the next one)
-      if (t + 2 < nk) {
-        issue((t + 2) % RING, t + 2);
-      } else if (have_next) {
-        if (t + 2 == nk) set_sources(unext);          // this unit's last tile was issued two iterations ago
-        issue((t + 2) % RING, t + 2 - nk);
+  // the unit's (mean, rstd) pairs into LDS behind the images: by LDS-DMA, or finalized here from the producer's partial sums (one
+  // thread per token, the slices in order: ln_stats_finalize_kernel's arithmetic spelled the same way, so the pairs are the bits that
+  // kernel would have written) -- the finalize launch between fc2 and this kernel is gone.  Every K tile's wait + barrier lies between
+  // these writes and the epilogue's reads.  (A plain load per token tile in the epilogue cost 13 exposed L2 round trips per unit.)
+  if (a.ln_part != nullptr) {
+    if (tid < NTOK) {
+      const float2* p = reinterpret_cast<const float2*>(a.ln_part) + (size_t)f * a.N + min(tid, a.N - 1);
+      const size_t rows = (size_t)a.F * a.N;
+      float s1 = 0.f, s2 = 0.f;
+      for (int sl = 0; sl < a.ln_ns; ++sl) {
+        const float2 v = p[sl * rows];
+        s1 += v.x;
+        s2 += v.y;
       }
+      const float mean = s1 * a.ln_inv_d;
+      const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * a.ln_inv_d), 0.f);
+      *reinterpret_cast<float2*>(smem + OFF_MR + tid * 8) = make_float2(mean, 1.0f / sqrtf(var + a.ln_eps));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (wr == 1) {                                  // tile t + 1 (if any) landed; tile t + 2 may stay in flight
-        if (more) WAIT_VMCNT_IMM(3); else WAIT_VMCNT_IMM(0);     // (waves 4-7 issue three pieces per K tile)
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- C(t)
-      __builtin_amdgcn_s_setprio(1);
+    }
+  } else if (a.ln_mr != nullptr) {
 #pragma unroll
-      for (int i = 0; i < 7; ++i)
-        if (i < nmt) {
+    for (int q = 0; q < 2; ++q) {
+      const int fi = (wave * 2 + q) * 64 + lane;          // float index into [208][2]; 7 x 64 = 448 >= 416
+      if (fi < NTOK * 2)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(a.ln_mr + ((size_t)f * a.N + min(fi >> 1, a.N - 1)) * 2 + (fi & 1)),
+                                         LDS_PTR(smem + OFF_MR + (wave * 2 + q) * 256), 4, 0, 0);
+    }
+  }
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk) { if (wave == 0) WAIT_VMCNT_IMM(7); else WAIT_VMCNT_IMM(6); }   // tile t landed, tile t + 1 may be in flight
+    else WAIT_VMCNT_IMM(0);
+    __builtin_amdgcn_s_barrier();        // every wave's pieces of tile t; and every wave is done reading tile t - 1 (buffer of t + 2)
+    if (t + 2 < nk) issue((t + 2) % RING, t + 2);
+    // Fragment reads and their waits by hand: A fragments run two token tiles ahead of their MFMAs and each tile waits with a COUNTED
+    // lgkmcnt for its own fragment only.  (Left to itself hipcc reads a pair, waits lgkmcnt(0), issues six MFMAs -- every pair's LDS
+    // latency exposed, ~900 cycles per K tile beside 624 of matrix work; with plain loads hoisted in the source it still drains the
+    // queue with lgkmcnt(0) every third tile.)  The reads are asm so that the compiler's own wait insertion does not count them.
+    const unsigned a_rd = lds0 + (t % RING) * BUF_BYTES + frag;
+    const unsigned b_rd = a_rd + A_BYTES + wave * 3072;
+    bf16x8_t bf[3], af[3];
+    LDS_RD128(bf[0], b_rd, 0); LDS_RD128(bf[1], b_rd, 1024); LDS_RD128(bf[2], b_rd, 2048);
+    LDS_RD128(af[0], a_rd, 0); LDS_RD128(af[1], a_rd, 1024);
 #pragma unroll
-          for (int j = 0; j < 3; ++j) acc[i][j] = mfma16x16x32<F16>(bf[j], af[i], acc[i][j]);
+    for (int i = 0; i < 13; ++i) {
+      if (i + 2 < 13) LDS_RD128(af[(i + 2) % 3], a_rd, (i + 2) * 1024);
+      if (i == 0) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(af[0]));
+      else if (i < 11) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(af[i % 3]));
+      else if (i == 11) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(af[i % 3]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[i % 3]));
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[i][j] = mfma16x16x32<F16>(bf[j], af[i % 3], acc[i][j]);
+    }
+  }
+  __builtin_amdgcn_s_barrier();          // the ring is dead: the images go on top of it
+
+  {
+    const bool fold = a.ln_c != nullptr;
+    // the (mean, rstd) pairs of this lane's 13 tokens out of LDS BEFORE the images overwrite anything (they sit behind the images,
+    // but a wave may run ahead into the image stores); bias / c of the wave's three column tiles in one batch of loads
+    float2 mrv[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i)
+      mrv[i] = *reinterpret_cast<const float2*>(smem + OFF_MR + (i * 16 + li) * 8);      // unused garbage when not folded
+    float4 bvj[3], cvj[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int n0 = (wave * 3 + j) * 16;
+      const int col = (n0 >> 6) * a.D + h * HD + (n0 & 63) + 4 * g;      // column of the [3D] bias / c vectors
+      bvj[j] = *reinterpret_cast<const float4*>(a.bias + col);
+      cvj[j] = fold ? *reinterpret_cast<const float4*>(a.ln_c + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int n0 = (wave * 3 + j) * 16;
+      const int sel = n0 >> 6, d0 = (n0 & 63) + 4 * g;
+      const float4 bv = bvj[j], cv = cvj[j];
+      char* img = smem + sel * IMG;
+#pragma unroll
+      for (int i = 0; i < 13; ++i) {
+        const int tok = i * 16 + li;
+        float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+        if (fold) {
+          const float2 mr = mrv[i];
+          const float nm = -mr.x;
+          v0 = mul_rounded(mr.y, fmaf(nm, cv.x, v0)); v1 = mul_rounded(mr.y, fmaf(nm, cv.y, v1));
+          v2 = mul_rounded(mr.y, fmaf(nm, cv.z, v2)); v3 = mul_rounded(mr.y, fmaf(nm, cv.w, v3));
         }
-      __builtin_amdgcn_s_setprio(0);
-      if (wr == 0) {
-        if (more) { if (wave == 0) WAIT_VMCNT_IMM(4); else WAIT_VMCNT_IMM(3); } else WAIT_VMCNT_IMM(0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (wr == 0) __builtin_amdgcn_s_barrier();        // re-align the wave rows: both write the images in the same slot
-
-    // ---- epilogue: LN fold + bias, rounding, Q / K / V images ----
-    {
-      const float* sbias = reinterpret_cast<const float*>(smem + OFF_BIAS);
-      const float* sc = reinterpret_cast<const float*>(smem + OFF_C);
-      const float* smr = reinterpret_cast<const float*>(smem + OFF_MR);
-      const bool fold = a.ln_c != nullptr;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int n0 = (wc * 3 + j) * 16;               // 0 .. 176: which of q | k | v, and the channel inside it
-        const int sel = n0 >> 6, d0 = (n0 & 63) + 4 * g;
-        const float4 bv = *reinterpret_cast<const float4*>(sbias + n0 + 4 * g);
-        float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (fold) cv = *reinterpret_cast<const float4*>(sc + n0 + 4 * g);
-        char* img = smem + (sel == 0 ? OFF_Q : (sel == 1 ? OFF_K : OFF_V));
-#pragma unroll
-        for (int i = 0; i < 7; ++i)
-          if (i < nmt) {
-            const int tok = (mt0 + i) * 16 + li;
-            float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-            if (fold) {
-              const float2 mr = *reinterpret_cast<const float2*>(smr + tok * 2);
-              const float nm = -mr.x;
-              v0 = mul_rounded(mr.y, fmaf(nm, cv.x, v0)); v1 = mul_rounded(mr.y, fmaf(nm, cv.y, v1));
-              v2 = mul_rounded(mr.y, fmaf(nm, cv.z, v2)); v3 = mul_rounded(mr.y, fmaf(nm, cv.w, v3));
-            }
-            v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
-            const int chunk = d0 >> 3;
-            const int sw = sel == 2 ? (((tok >> 1) & 3) << 1) : (tok & 7);
-            *reinterpret_cast<uint2*>(img + tok * 128 + ((chunk ^ sw) << 4) + (d0 & 7) * 2) =
-                make_uint2(pack16x2<F16>(v0, v1), pack16x2<F16>(v2, v3));
-          }
+        v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
+        const int chunk = d0 >> 3;
+        const int sw = sel == 2 ? (((tok >> 1) & 3) << 1) : (tok & 7);
+        *reinterpret_cast<uint2*>(img + tok * 128 + ((chunk ^ sw) << 4) + (d0 & 7) * 2) = make_uint2(pack16x2<F16>(v0, v1), pack16x2<F16>(v2, v3));
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                     // images complete
+  }
+  __syncthreads();                       // images complete (no LDS-DMA in flight: a plain barrier)
 
-    // ---- attention on the images: waves 0-4 query tiles (w, w + 8), waves 5-7 tile w ----
-    {
-      AttnArgs aa;
-      aa.N = a.N; aa.H = a.H; aa.D = a.D; aa.scale_log2 = a.scale_log2; aa.lse = nullptr; aa.npad = 0; aa.rounds = 0; aa.nblk = 1;
-      aa.qkv = nullptr; aa.out = nullptr;
-      const int f = xcd + 8 * (u / a.H), h = u % a.H;
-      bf16_t* obase = reinterpret_cast<bf16_t*>(a.out) + (size_t)f * a.N * a.D + h * HD;
-      const char* sq = smem + OFF_Q;
-      const int vsw = ((2 * g + (li >> 3)) & 3) << 5;
-      const int qt[2] = {wave, wave + 8};
-      bf16x8_t qf[2][2];
+  {
+    AttnArgs aa;
+    aa.N = a.N; aa.H = a.H; aa.D = a.D; aa.scale_log2 = a.scale_log2; aa.lse = nullptr; aa.npad = 0; aa.rounds = 0; aa.nblk = 1;
+    aa.qkv = nullptr; aa.out = nullptr;
+    bf16_t* obase = reinterpret_cast<bf16_t*>(a.out) + (size_t)f * a.N * a.D + h * HD;
+    const char* sq = smem;
+    const int vsw = ((2 * g + (li >> 3)) & 3) << 5;
+    auto load_q = [&](bf16x8_t (&qf)[2][2], const int (&qt)[2]) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int qrow = min(qt[i], 12) * 16 + li;      // (waves 5-7 have no second tile: any valid row)
+        const int qrow = min(qt[i], 12) * 16 + li;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
           qf[i][ks] = *reinterpret_cast<const bf16x8_t*>(sq + qrow * 128 + (((ks * 4 + g) ^ (qrow & 7)) << 4));
       }
-      if (wave < 5) attn_tiles<13, 2, F16, true>(aa, smem + OFF_K, smem + OFF_V, obase, qf, qt, li, g, vsw, false);
-      else attn_tiles<13, 1, F16, true>(aa, smem + OFF_K, smem + OFF_V, obase, qf, qt, li, g, vsw, false);
-    }
-    if (!have_next) break;
-    u = unext;
+    };
+    bf16x8_t qf[2][2];
+    int qt[2] = {wave, wave + 4};
+    load_q(qf, qt);
+    attn_tiles<13, 2, F16, true>(aa, smem + IMG, smem + 2 * IMG, obase, qf, qt, li, g, vsw, false);
+    qt[0] = wave + 8; qt[1] = wave + 12;
+    load_q(qf, qt);
+    if (wave == 0) attn_tiles<13, 2, F16, true>(aa, smem + IMG, smem + 2 * IMG, obase, qf, qt, li, g, vsw, false);
+    else attn_tiles<13, 1, F16, true>(aa, smem + IMG, smem + 2 * IMG, obase, qf, qt, li, g, vsw, false);
   }
 }
 
-// OFF by default (MVF_FUSE_QKV=1 routes the backbone through it): measured sustained at BASELINE configs[1] (256 frames, profiles/r04/
-// qkv_attn_fused.txt) the launch takes 264 us (one barrier per K tile, eight waves in step) / 286 us (this staggered form) against
-// 171 + 72 us for the qkv GEMM + attention kernel on the same box, and the training step 11.46 against 11.13 ms.  It is correct (bit for
-// bit, tests/test_gpu_kernels.py) and moves 464 MB less per block, but it runs at the full 2.39 GHz BELOW the power cap, i.e. it is
-// schedule-bound: a unit's GEMM phase (~35 k cycles, matrix pipe) and attention phase (~20 k cycles, VALU / latency at two waves per
-// SIMD) run one after the other in the CU's only workgroup, where the stand-alone attention kernel overlaps three workgroups per CU
-// (13 k CU-cycles per unit).  The two phases are complementary -- what would pay is a second co-resident workgroup half a unit out of
-// phase, which the 78 KB of Q / K / V images per workgroup do not leave room for.
-const bool g_fuse = [] { const char* e = getenv("MVF_FUSE_QKV"); return e != nullptr && e[0] == '1'; }();
+// ON unless MVF_FUSE_QKV=0 (which keeps the qkv GEMM + attention launches, for A/B measurements)
+const bool g_fuse = [] { const char* e = getenv("MVF_FUSE_QKV"); return e == nullptr || atoi(e) != 0; }();
 
 }  // namespace
 
@@ -285,26 +263,27 @@ bool mvf_qkv_attn_supported(int dtype, int F, int N, int H, int D, int lda) {
 // A [F*N, lda] . W_h^T (+ LN fold / bias) -> attention -> out [F*N, D].  MVF_ERR_UNSUPPORTED outside the kernel's shape:
 // N = 193 .. 208, D = H * 64, D % 96 == 0 (24 K tiles at D = 768: the ring of three runs through unit boundaries), bf16 / fp16.
 int mvf_qkv_attn_impl(int dtype, const void* A, int lda, const void* W, const float* bias, const float* ln_c, const float* ln_mr,
-                      void* out, int F, int N, int H, int D, hipStream_t st) {
+                      const float* ln_part, int ln_ns, float ln_eps, void* out, int F, int N, int H, int D, hipStream_t st) {
   if (!(dtype == MVF_BF16 || dtype == MVF_F16) || N < 193 || N > 208 || D != H * HD || D % (KE * RING) != 0 || F < 1 || lda < D ||
       (lda * 2) % 16 != 0 || (size_t)F * N * lda * 2 >= (1ull << 32) || (size_t)3 * D * D * 2 >= (1ull << 32))      // (32-bit offsets)
     return MVF_ERR_UNSUPPORTED;
-  MVF_CHECK_ARG(A && W && bias && out && A != out && (ln_c == nullptr) == (ln_mr == nullptr));
+  // folded (ln_c): the rows' statistics as (mean, rstd) pairs OR as the producer's partial sums, never both; plain: neither
+  MVF_CHECK_ARG(A && W && bias && out && A != out && (ln_c != nullptr) == ((ln_mr != nullptr) != (ln_part != nullptr)) &&
+                !(ln_mr != nullptr && ln_part != nullptr) && (ln_part == nullptr || (ln_ns >= 1 && ln_ns <= 64)));
   MVF_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0);
   QkvAttnArgs a;
   a.A = (const char*)A; a.W = (const char*)W; a.bias = bias; a.ln_c = ln_c; a.ln_mr = ln_mr; a.out = (char*)out;
+  a.ln_part = ln_part; a.ln_ns = ln_ns; a.ln_inv_d = 1.0f / (float)D; a.ln_eps = ln_eps;
   a.lda = lda; a.F = F; a.N = N; a.H = H; a.D = D;
   a.scale_log2 = LOG2E / 8.0f;
-  int wgs = 256;
-  (void)mvf_gemm_tc_get_wgs(&wgs);                     // one workgroup per CU of the persistent kernels' budget (RCCL reserve, CU-masked streams)
-  const int grid = std::max(8, std::min(wgs & ~7, ((F * H + 7) / 8) * 8));
+  const int grid = 8 * ((F + 7) / 8) * H;
   static bool attr[2] = {false, false};
   if (dtype == MVF_F16) {
     if (!attr[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vit_qkv_attn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL); attr[1] = true; }
-    hipLaunchKernelGGL(vit_qkv_attn_kernel<true>, dim3(grid), dim3(512), LDS_TOTAL, st, a);
+    hipLaunchKernelGGL(vit_qkv_attn_kernel<true>, dim3(grid), dim3(256), LDS_TOTAL, st, a);
   } else {
     if (!attr[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vit_qkv_attn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL); attr[0] = true; }
-    hipLaunchKernelGGL(vit_qkv_attn_kernel<false>, dim3(grid), dim3(512), LDS_TOTAL, st, a);
+    hipLaunchKernelGGL(vit_qkv_attn_kernel<false>, dim3(grid), dim3(256), LDS_TOTAL, st, a);
   }
   MVF_LAUNCH_CHECK();
   return MVF_OK;
@@ -312,6 +291,7 @@ int mvf_qkv_attn_impl(int dtype, const void* A, int lda, const void* W, const fl
 
 // exported for the unit parity test: the fused kernel against mvf_gemm_tc(_ln) + mvf_vit_attn_fwd on the same operands
 extern "C" int mvf_vit_qkv_attn_fwd(int dtype, const void* A, int lda, const void* W, const float* bias, const float* ln_c,
-                                    const float* ln_mr, void* out, int F, int N, int H, int D, hipStream_t st) {
-  return mvf_qkv_attn_impl(dtype, A, lda, W, bias, ln_c, ln_mr, out, F, N, H, D, st);
+                                    const float* ln_mr, const float* ln_part, int ln_ns, float ln_eps, void* out, int F, int N, int H,
+                                    int D, hipStream_t st) {
+  return mvf_qkv_attn_impl(dtype, A, lda, W, bias, ln_c, ln_mr, ln_part, ln_ns, ln_eps, out, F, N, H, D, st);
 }

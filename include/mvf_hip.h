@@ -239,6 +239,13 @@ int mvf_hgemm_ex(const float* A, long sam, long sak, const float* B, long sbk, l
  * instead of overwriting.  (ReLU / dropout backward of dy: mvf_relu_bwd / mvf_dropout_add first.) */
 int mvf_hlinear_bwd(const float* dy, long ldy, const float* x, long ldx, const float* W, long ldw, float* dx, long lddx,
                     float* dW, long lddw, float* db, int M, int N, int K, int accumulate_params, hipStream_t stream);
+/* LSTPCrossAtt's static queries folded through linear_K2d (models/mvformer.py:383, `Q = self.Q_s + self.Q_s_b`; the pooling rewrite
+ * of mvf_lstp_fused_fwd takes wq = Q W_K): wq [nq, C] = (qs [nq, d] + qb [d]) . wk [d, C]; backward: gqs, gqb, gwk ACCUMULATE
+ * (flat gradient buffer) from dv [nq, C].  nq <= 8.  One launch each way (plain fp32 FMAs, fixed order). */
+int mvf_static_query_fwd(const float* qs, const float* qb, const float* wk, long ldw, float* wq, int nq, int d, int C,
+                         hipStream_t stream);
+int mvf_static_query_bwd(const float* dv, long ldv, const float* qs, const float* qb, const float* wk, long ldw, float* gqs,
+                         float* gqb, float* gwk, long ldgw, int nq, int d, int C, hipStream_t stream);
 int mvf_colsum(const float* x, long ld, int rows, int cols, float* out, int accumulate, hipStream_t stream);
 /* stage 1 of a column sum over very many rows: part[s][c] = sum of row slice s (splits slices); stage 2: mvf_sum_batches */
 int mvf_colsum_split(const float* x, long ld, int rows, int cols, int splits, float* part, hipStream_t stream);

@@ -1423,3 +1423,30 @@ def test_fused_clip_adam_vs_torch():
         check(norm[:1], tn.view(1), 1e-5, 'grad norm')
         ops.adam_step(pd, gd, m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-5, calls, clip=10.0, norm=norm)
         check(pd, pr.detach(), 1e-5, 'adam step %d' % step)
+
+
+@pytest.mark.parametrize('nq,d,C', [(3, 384, 2304), (8, 96, 200), (1, 64, 64)])
+def test_static_query_kernels_vs_fp64(nq, d, C):
+    """mvf_static_query_fwd / _bwd (LSTPCrossAtt's static queries folded through W_K, one launch each way) against fp64: the product,
+    and the three ACCUMULATED parameter gradients on top of non-zero slot contents; a strided W_K / gradient (row stride > C)."""
+    g = gen(17)
+    qs, qb = torch.randn(nq, d, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
+    wk_buf = torch.randn(d, C + 8, generator=g).to(DEV)
+    wk = wk_buf[:, :C]
+    dv = torch.randn(nq, C, generator=g).to(DEV)
+    out = torch.empty(nq, C, device=DEV)
+    _lib.call('mvf_static_query_fwd', qs.data_ptr(), qb.data_ptr(), wk.data_ptr(), wk.stride(0), out.data_ptr(), nq, d, C, S())
+    q64 = (qs.double() + qb.double())
+    check(out, q64 @ wk.double(), 2e-6, 'static query forward')
+    gqs0, gqb0 = torch.randn(nq, d, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
+    gwk_buf0 = torch.randn(d, C + 8, generator=g).to(DEV)
+    gqs, gqb, gwk_buf = gqs0.clone(), gqb0.clone(), gwk_buf0.clone()
+    gwk = gwk_buf[:, :C]
+    _lib.call('mvf_static_query_bwd', dv.data_ptr(), C, qs.data_ptr(), qb.data_ptr(), wk.data_ptr(), wk.stride(0), gqs.data_ptr(),
+              gqb.data_ptr(), gwk.data_ptr(), gwk.stride(0), nq, d, C, S())
+    dq = dv.double() @ wk.double().t()
+    check(gqs, gqs0.double() + dq, 2e-6, 'static query d Q_s')
+    check(gqb, gqb0.double() + dq.sum(0), 2e-6, 'static query d Q_s_b')
+    check(gwk, gwk_buf0[:, :C].double() + q64.t() @ dv.double(), 2e-6, 'static query d W_K')
+    assert torch.equal(gwk_buf[:, C:], gwk_buf0[:, C:])          # the padding columns of the strided gradient are untouched
+

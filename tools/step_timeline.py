@@ -27,6 +27,7 @@ def main():
     p = argparse.ArgumentParser()
     p.add_argument('--steps', type=int, default=300)
     p.add_argument('--no-head', action='store_true', help='backbone forwards only (the floor)')
+    p.add_argument('--fwd-only', action='store_true', help='head forward + loss only (no backward, no optimizer)')
     p.add_argument('--dummy', default='', help="instead of the head: 'tiny:N' = N one-workgroup elementwise launches per step, "
                                                "'gemm:N' = N head-sized fp32 GEMM launches (768 x 512 x 512) per step")
     a = p.parse_args()
@@ -102,6 +103,9 @@ def main():
                     ops.linear(dummy_x, dummy_w, None)
         elif a.no_head:
             model._stash.pop(0)
+        elif a.fwd_only:
+            with torch.no_grad():
+                algo.compute_loss(wrapped, videos, seq_lens, steps, masks)
         else:
             opt.zero_grad()
             loss = algo.compute_loss(wrapped, videos, seq_lens, steps, masks)['loss']

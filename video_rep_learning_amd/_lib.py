@@ -56,6 +56,8 @@ SIGNATURES = {
     'mvf_cast_bf16_f32': 'ppzp',
     'mvf_vit_attn_fwd_lse': 'pppiiiip',
     'mvf_vit_attn_bwd': 'ppppppiiiiip',
+    'mvf_static_query_fwd': 'ppplpiiip',
+    'mvf_static_query_bwd': 'plppplppplIIIp'.replace('I', 'i'),
     'mvf_hgemm': 'pllpllplppllii' + 'iiifiip',
     'mvf_hgemm_ex': 'pllpllplppllii' + 'iiifii' + 'plfuup',
     'mvf_hlinear_bwd': 'plplplplplpiiiip',

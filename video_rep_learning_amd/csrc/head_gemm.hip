@@ -25,6 +25,7 @@
 // swapped in the MFMA so a lane owns 4 consecutive n (16-byte stores).
 #include "common.h"
 #include "mvf_hip_internal.h"
+#include <type_traits>
 
 namespace {
 
@@ -146,21 +147,30 @@ __device__ __forceinline__ void hgemm_tile(const HGemmArgs& a, int bx, int by, f
   float rs[2] = {0.f, 0.f};
   const bool want_rs = a.rowsum != nullptr && bx == 0 && (wave & 1) == 0;
 
-  f32x4_t ra[NPASS], rb[NPASS];
+  // Two register sets: tile j travels global -> registers set j & 1 -> LDS buffer j & 1.  While tile t is multiplied, tile t + 1 sits
+  // in (or is on its way to) its registers and tile t + 2 is in flight: a request has TWO k steps to come back (one in the first
+  // form, which asked for tile t + 1 at the top of step t and needed it at the bottom: 1.17 us per 64-deep step of 32-row tiles
+  // against 0.5 us of MFMAs -- the K = 2 304 first-layer GEMM took 42 us, and under the backbone's memory traffic several times that)
+  f32x4_t ra[2][NPASS], rb[2][NPASS];
   const int nt = (a.K + TK - 1) / TK;
-  tile_load<AKM, GUARD, TM>(a.A, a.sam, a.sak, m0, a.M, 0, a.K, avec, ra);
-  tile_load<BKM, GUARD>(a.B, a.sbn, a.sbk, n0, a.N, 0, a.K, bvec, rb);
-  tile_store<AKM, TM>(lds, ra);
-  tile_store<BKM>(lds + TILE_F, rb);
+  tile_load<AKM, GUARD, TM>(a.A, a.sam, a.sak, m0, a.M, 0, a.K, avec, ra[0]);
+  tile_load<BKM, GUARD>(a.B, a.sbn, a.sbk, n0, a.N, 0, a.K, bvec, rb[0]);
+  if (nt > 1) {
+    tile_load<AKM, GUARD, TM>(a.A, a.sam, a.sak, m0, a.M, TK, a.K, avec, ra[1]);
+    tile_load<BKM, GUARD>(a.B, a.sbn, a.sbk, n0, a.N, TK, a.K, bvec, rb[1]);
+  }
+  tile_store<AKM, TM>(lds, ra[0]);
+  tile_store<BKM>(lds + TILE_F, rb[0]);
+  if (nt > 2) {
+    tile_load<AKM, GUARD, TM>(a.A, a.sam, a.sak, m0, a.M, 2 * TK, a.K, avec, ra[0]);
+    tile_load<BKM, GUARD>(a.B, a.sbn, a.sbk, n0, a.N, 2 * TK, a.K, bvec, rb[0]);
+  }
   __syncthreads();
-  for (int t = 0; t < nt; ++t) {
+  // k step t; S = (t + 1) & 1 = the register set of tile t + 1 (a compile-time index: the sets must stay in registers)
+  auto kstep = [&](int t, auto set_c) {
+    constexpr int S = decltype(set_c)::value;
     const float* As = lds + (t & 1) * 2 * TILE_F;
     const float* Bs = As + TILE_F;
-    if (t + 1 < nt) {   // request the next tile before this tile's MFMAs
-      tile_load<AKM, GUARD, TM>(a.A, a.sam, a.sak, m0, a.M, (t + 1) * TK, a.K, avec, ra);
-      tile_load<BKM, GUARD>(a.B, a.sbn, a.sbk, n0, a.N, (t + 1) * TK, a.K, bvec, rb);
-      __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the MFMAs (the scheduler would sink them)
-    }
 #pragma unroll
     for (int q = 0; q < TK / 4; ++q) {
       float af[2] = {0.f, 0.f}, bf[2];
@@ -176,10 +186,18 @@ __device__ __forceinline__ void hgemm_tile(const HGemmArgs& a, int bx, int by, f
     }
     if (t + 1 < nt) {
       float* An = lds + ((t + 1) & 1) * 2 * TILE_F;
-      tile_store<AKM, TM>(An, ra);
-      tile_store<BKM>(An + TILE_F, rb);
+      tile_store<AKM, TM>(An, ra[S]);
+      tile_store<BKM>(An + TILE_F, rb[S]);
+    }
+    if (t + 3 < nt) {   // the set just emptied takes tile t + 3
+      tile_load<AKM, GUARD, TM>(a.A, a.sam, a.sak, m0, a.M, (t + 3) * TK, a.K, avec, ra[S]);
+      tile_load<BKM, GUARD>(a.B, a.sbn, a.sbk, n0, a.N, (t + 3) * TK, a.K, bvec, rb[S]);
     }
     __syncthreads();
+  };
+  for (int t = 0; t < nt; t += 2) {
+    kstep(t, std::integral_constant<int, 1>{});
+    if (t + 1 < nt) kstep(t + 1, std::integral_constant<int, 0>{});
   }
 
   const int m_base = m0 + wm, n_base = n0 + wn;

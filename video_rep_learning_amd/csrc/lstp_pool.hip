@@ -781,3 +781,104 @@ extern "C" int mvf_lstp_fused_bwd(const void* const* taps, int n_taps, int dtype
   a.G = G;
   return dtype == MVF_BF16 ? fused_pick<true, bf16_t>(a, n_taps, nq, F, st) : fused_pick<true, float>(a, n_taps, nq, F, st);
 }
+
+// ---- static queries folded through W_K (LSTPCrossAtt with num_dynamic = 0, mvformer.py:383: Q = Q_s + Q_s_b) ----
+//     wq[j, c] = sum_k (qs[j, k] + qb[k]) wk[k, c]            qs [nq, d], qb [d], wk [d, C] (row stride ldw), wq [nq, C]
+// and its backward, every parameter gradient ACCUMULATED in place (flat gradient buffer):
+//     gqs[j, k] += sum_c dv[j, c] wk[k, c];   gqb[k] += sum_j (that);   gwk[k, c] += sum_j (qs[j, k] + qb[k]) dv[j, c]
+// nq = 3 rows against a 384 x 2 304 matrix: through the 64-row MFMA GEMM these were six launches with K-long serial chains in a
+// handful of workgroups (49 us each for the two [nq | 1] x 2 304 -> 384 products); here one launch each way, a few microseconds,
+// plain fp32 FMAs in a fixed order (deterministic; no atomics).
+//   forward : workgroup = 64 columns x 4 slices of k (k = s, s + 4, ..): 96 independent coalesced loads per thread, LDS combine
+//   backward: workgroup = one row k of wk: threads stride over c; gwk's row updated in place, the nq dot products block-reduced
+namespace {
+
+__global__ __launch_bounds__(256) void static_query_fwd_kernel(const float* __restrict__ qs, const float* __restrict__ qb,
+                                                               const float* __restrict__ wk, long ldw, float* __restrict__ wq,
+                                                               int nq, int d, int C) {
+  __shared__ float red[4][MAXQ][64];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float acc[MAXQ];
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j) acc[j] = 0.f;
+  if (c < C) {
+    for (int k = sl; k < d; k += 4) {
+      const float w = wk[(long)k * ldw + c];
+      const float b = qb[k];
+#pragma unroll
+      for (int j = 0; j < MAXQ; ++j)
+        if (j < nq) acc[j] = fmaf(qs[(long)j * d + k] + b, w, acc[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j) red[sl][j][cl] = acc[j];
+  __syncthreads();
+  if (sl == 0 && c < C) {
+#pragma unroll
+    for (int j = 0; j < MAXQ; ++j)
+      if (j < nq) wq[(long)j * C + c] = (red[0][j][cl] + red[1][j][cl]) + (red[2][j][cl] + red[3][j][cl]);
+  }
+}
+
+__global__ __launch_bounds__(256) void static_query_bwd_kernel(const float* __restrict__ dv, long ldv, const float* __restrict__ qs,
+                                                               const float* __restrict__ qb, const float* __restrict__ wk, long ldw,
+                                                               float* __restrict__ gqs, float* __restrict__ gqb,
+                                                               float* __restrict__ gwk, long ldgw, int nq, int d, int C) {
+  __shared__ float red[4][MAXQ];
+  const int k = blockIdx.x;
+  float a[MAXQ], s[MAXQ];
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j) {
+    a[j] = j < nq ? qs[(long)j * d + k] + qb[k] : 0.f;
+    s[j] = 0.f;
+  }
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float w = wk[(long)k * ldw + c];
+    float g = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXQ; ++j)
+      if (j < nq) {
+        const float v = dv[(long)j * ldv + c];
+        s[j] = fmaf(v, w, s[j]);
+        g = fmaf(a[j], v, g);
+      }
+    gwk[(long)k * ldgw + c] += g;
+  }
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j) {
+    float v = s[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int j = 0; j < nq; ++j) {
+      const float v = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+      gqs[(long)j * d + k] += v;
+      tot += v;
+    }
+    gqb[k] += tot;
+  }
+}
+
+}  // namespace
+
+extern "C" int mvf_static_query_fwd(const float* qs, const float* qb, const float* wk, long ldw, float* wq, int nq, int d, int C,
+                                    hipStream_t st) {
+  MVF_CHECK_ARG(qs && qb && wk && wq && nq >= 1 && nq <= MAXQ && d >= 1 && C >= 1 && ldw >= C);
+  hipLaunchKernelGGL(static_query_fwd_kernel, dim3((C + 63) / 64), dim3(256), 0, st, qs, qb, wk, ldw, wq, nq, d, C);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
+extern "C" int mvf_static_query_bwd(const float* dv, long ldv, const float* qs, const float* qb, const float* wk, long ldw,
+                                    float* gqs, float* gqb, float* gwk, long ldgw, int nq, int d, int C, hipStream_t st) {
+  MVF_CHECK_ARG(dv && qs && qb && wk && gqs && gqb && gwk && nq >= 1 && nq <= MAXQ && d >= 1 && C >= 1 && ldw >= C && ldgw >= C &&
+                ldv >= C);
+  hipLaunchKernelGGL(static_query_bwd_kernel, dim3(d), dim3(256), 0, st, dv, ldv, qs, qb, wk, ldw, gqs, gqb, gwk, ldgw, nq, d, C);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}

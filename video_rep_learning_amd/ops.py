@@ -281,10 +281,10 @@ def matmul(a, b):
 
 class _StaticQuery(torch.autograd.Function):
     """wq = (Q_s + Q_s_b) W_K  [nq, C]: the query side of the pooling rewrite for static queries (LSTPCrossAtt,
-    mvformer.py:383 `Q = self.Q_s + self.Q_s_b`, folded through linear_K2d as csrc/lstp_pool.hip describes).  By linearity
-    (Q_s + 1 b^T) W = Q_s W + 1 (b^T W): two small GEMM launches forward, the second one's result entering the first as its
-    bias; the backward accumulates all three parameter gradients straight into their flat-gradient slots -- no broadcast add,
-    no select / sum / AccumulateGrad kernels of the autograd engine."""
+    mvformer.py:383 `Q = self.Q_s + self.Q_s_b`, folded through linear_K2d as csrc/lstp_pool.hip describes).
+    One launch each way (csrc/lstp_pool.hip: mvf_static_query_fwd / _bwd); the backward accumulates all three parameter
+    gradients straight into their flat-gradient slots -- no broadcast add, no select / sum / AccumulateGrad kernels of the
+    autograd engine."""
 
     @staticmethod
     def forward(ctx, qs, qb, wk, slots):
@@ -292,10 +292,8 @@ class _StaticQuery(torch.autograd.Function):
         nq, d = qs.shape[-2], qs.shape[-1]
         C = wk.shape[1]
         dev = wk.device
-        bw = torch.empty(1, C, device=dev, dtype=torch.float32)
-        _hgemm(qb.data_ptr(), d, 1, wk.data_ptr(), wk.stride(0), 1, bw.data_ptr(), C, 1, C, d)               # b^T W_K
         out = torch.empty(nq, C, device=dev, dtype=torch.float32)
-        _hgemm(qs.data_ptr(), d, 1, wk.data_ptr(), wk.stride(0), 1, out.data_ptr(), C, nq, C, d, bias=bw)    # Q_s W_K + 1 (b^T W_K)
+        call('mvf_static_query_fwd', qs.data_ptr(), qb.data_ptr(), wk.data_ptr(), wk.stride(0), out.data_ptr(), nq, d, C, stream())
         ctx.save_for_backward(qs, qb, wk)
         ctx.slots = slots
         return out
@@ -307,12 +305,8 @@ class _StaticQuery(torch.autograd.Function):
         nq, d = qs.shape[-2], qs.shape[-1]
         C = wk.shape[1]
         dv, dvp, ldv = _mat(dv)
-        cs = torch.empty(C, device=dv.device, dtype=torch.float32)
-        call('mvf_colsum', dvp, ldv, nq, C, ptr(cs), 0, stream())                                           # 1^T dv
-        _hgemm(dvp, ldv, 1, wk.data_ptr(), 1, wk.stride(0), gqs.data_ptr(), d, nq, d, C, accumulate=True)    # dQ_s += dv W_K^T
-        _hgemm(cs.data_ptr(), C, 1, wk.data_ptr(), 1, wk.stride(0), gqb.data_ptr(), d, 1, d, C, accumulate=True)   # dQ_s_b += (1^T dv) W_K^T
-        _hgemm(qs.data_ptr(), 1, d, dvp, ldv, 1, gwk.data_ptr(), gwk.stride(0), d, C, nq, accumulate=True)   # dW_K += Q_s^T dv
-        _hgemm(qb.data_ptr(), 1, d, cs.data_ptr(), C, 1, gwk.data_ptr(), gwk.stride(0), d, C, 1, accumulate=True)  # dW_K += b (1^T dv)
+        call('mvf_static_query_bwd', dvp, ldv, qs.data_ptr(), qb.data_ptr(), wk.data_ptr(), wk.stride(0), gqs.data_ptr(), gqb.data_ptr(),
+             gwk.data_ptr(), gwk.stride(0), nq, d, C, stream())
         grad_ready(*ctx.owners)
         return None, None, None, None
 
@@ -322,7 +316,7 @@ def static_query(q_s, q_s_b, w_k):
     parameters live in the flat buffers (training under FusedAdam), the plain composition otherwise."""
     slots = (grad_slot(q_s), grad_slot(q_s_b), grad_slot(w_k))
     if any(s is None for s in slots) or not (q_s.requires_grad and q_s_b.requires_grad and w_k.requires_grad) or \
-            not (q_s.is_contiguous() and q_s_b.is_contiguous() and w_k.stride(1) == 1):
+            not (q_s.is_contiguous() and q_s_b.is_contiguous() and w_k.stride(1) == 1) or q_s.shape[-2] > 8:
         return matmul((q_s + q_s_b)[0], w_k)
     out = _StaticQuery.apply(q_s, q_s_b, w_k, slots)
     return out

@@ -45,7 +45,8 @@ PEAK_F32_TFLOPS = 157.3       # fp32-input MFMA (= vector) peak, parity mode
 GEMM_NAMES = {(0, 2304, 768): 'qkv [M,768]x[2304,768]^T', (2, 768, 768): 'proj+resid [M,768]x[768,768]^T',
               (0, 768, 768): 'proj (bf16 branch output, residual add deferred) [M,768]x[768,768]^T',
               (1, 3072, 768): 'fc1+gelu [M,768]x[3072,768]^T', (2, 768, 3072): 'fc2+resid [M,3072]x[768,3072]^T',
-              (3, 768, 768): 'patch-embed+pos [M,768]x[768,768]^T'}
+              (3, 768, 768): 'patch-embed+pos [M,768]x[768,768]^T',
+              (5, 2304, 768): 'qkv + attention fused [M,768]x[2304,768]^T, softmax(QK^T)V (vit_qkv_attn_kernel)'}
 # bf16 mode against the bf16-emulating oracle, (loss, embeddings): about 3x what the driver-style runs measure
 # measured over this round's runs: loss 1.5e-4 .. 1.0e-3 (relative, on a loss that the resident batch drives down to 0.09),
 # embeddings 5.7e-4 .. 1.5e-3.  The loss gate is relative to max(|loss|, 0.25): a longer run over-fits the resident batch further
@@ -86,7 +87,9 @@ def rocprof_names(groups, dtype, ln_fold, defer=True, frames=256, tokens=197, nw
     by = {}
     for r in groups:
         e = r['epi']
-        if dtype not in ('bf16', 'fp16'):
+        if e == 5:        # the fused qkv + attention launch (csrc/vit_qkv_attn.hip), not a gemm_tc256 instantiation
+            parts = [('vit_qkv_attn_kernel<%s>' % ('true' if dtype == 'fp16' else 'false'), 1.0)]
+        elif dtype not in ('bf16', 'fp16'):
             parts = [('gemm_tc_kernel<float, %d, false>' % e, 1.0)]
         else:
             qkv, fc1 = e == 0 and r['n'] > r['k'], e == 1        # (epi 0 with N == K: the proj GEMM of the deferred residual)
@@ -518,7 +521,8 @@ def main():
         peak = PEAK_BF16_TFLOPS if a.dtype in ('bf16', 'fp16') else PEAK_F32_TFLOPS     # (fp16 MFMA: the bf16 rate)
         ach = dom['flop'] / (dom['ms'] * 1e-3) / 1e12
         tot_ms, tot_fl = sum(r['ms'] for r in groups), sum(r['flop'] for r in groups)
-        kern = ('gemm_tc256_kernel' if a.dtype in ('bf16', 'fp16') else 'gemm_tc_kernel<float>') + ' / ' + dom['name']
+        kern = ('vit_qkv_attn_kernel' if dom['epi'] == 5 else 'gemm_tc256_kernel' if a.dtype in ('bf16', 'fp16') else 'gemm_tc_kernel<float>') + \
+            ' / ' + dom['name']
         roof = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                 'traffic': pmc_traffic(dom['name']), 'kernel': kern, 'launches': dom['launches'],
                 'timing': 'HIP events around each launch on its stream, kernels serialized (1 backbone lane, no lookahead)',

@@ -88,6 +88,39 @@ int timed_gemm(int dtype, int epi, const void* A, int lda, const void* W, int ld
   return rc;
 }
 
+// the fused qkv + attention launch under the same profile (mvf_prof_collect group: epi 5, n = 3 D, k = D; FLOPs = the projection's
+// 2 M 3D D + the attention's 4 F H N^2 64)
+constexpr int PROF_QKV_ATTN = 5;
+int timed_qkv_attn(int dtype, const void* A, const void* W, const float* bias, const float* ln_c, const float* ln_mr,
+                   const float* ln_part, int ln_ns, float ln_eps, void* out, int F, int N, int H, int D, hipStream_t st) {
+  const bool rec = g_prof.on && g_prof.used < 4096;
+  size_t slot = 0;
+  if (rec) {
+    slot = g_prof.used++;
+    if (g_prof.ev.size() < 2 * (slot + 1)) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return MVF_ERR_ARG;
+      g_prof.ev.push_back(a);
+      g_prof.ev.push_back(b);
+      g_prof.epi.push_back(0);
+      g_prof.n.push_back(0);
+      g_prof.k.push_back(0);
+      g_prof.flops.push_back(0.0);
+    }
+    g_prof.epi[slot] = PROF_QKV_ATTN;
+    g_prof.n[slot] = 3 * D;
+    g_prof.k[slot] = D;
+    g_prof.flops[slot] = 2.0 * F * N * 3.0 * D * D + 4.0 * F * H * (double)N * N * 64.0;
+    (void)hipEventRecord(g_prof.ev[2 * slot], st);
+  }
+  const int rc = mvf_qkv_attn_impl(dtype, A, D, W, bias, ln_c, ln_mr, ln_part, ln_ns, ln_eps, out, F, N, H, D, st);
+  if (rec) {
+    if (rc == MVF_ERR_UNSUPPORTED) --g_prof.used;
+    else (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
+  }
+  return rc;
+}
+
 size_t carve(int dtype, int fc, int N, int D, int P, Ws* w, char* base) {
   const size_t esz = dtype == MVF_F32 ? 4 : 2;     // MX-fp8 mode keeps bf16 activations between its quantisers
   const size_t Mc = (size_t)fc * N;
@@ -198,16 +231,16 @@ int run_blocks(const MvfVitWeights* w, int dtype, bool fp8, const Ws& ws, int fc
         if (l == l0) return MVF_ERR_ARG;   // nothing in this call produced the layer's statistics
         // (the kernel turns the producer's partial sums into (mean, rstd) itself: no finalize launch between fc2 and this one)
         if (g_ln_inkernel) {
-          RUN(mvf_qkv_attn_impl(dtype, ws.xb, D, w->qkv_w[l], w->qkv_b[l], w->qkv_c[l], nullptr, ws.stats, ns, w->ln_eps, ws.h, fc, N, H, D, st));
+          RUN(timed_qkv_attn(dtype, ws.xb, w->qkv_w[l], w->qkv_b[l], w->qkv_c[l], nullptr, ws.stats, ns, w->ln_eps, ws.h, fc, N, H, D, st));
         } else {
           RUN(mvf_ln_stats_finalize_impl(ws.stats, ns, ws.mr, Mc, D, w->ln_eps, st));
-          RUN(mvf_qkv_attn_impl(dtype, ws.xb, D, w->qkv_w[l], w->qkv_b[l], w->qkv_c[l], ws.mr, nullptr, 0, 0.f, ws.h, fc, N, H, D, st));
+          RUN(timed_qkv_attn(dtype, ws.xb, w->qkv_w[l], w->qkv_b[l], w->qkv_c[l], ws.mr, nullptr, 0, 0.f, ws.h, fc, N, H, D, st));
         }
       } else {
         // the LayerNorm output is parked in the (otherwise unused) qkv buffer: the kernel's output goes to ws.h, and a unit's
         // output columns must not land in rows another (frame, head) unit of the same launch still reads as its operand
         RUN(mvf_layernorm_impl(dtype, ws.x, D, w->ln1_w[l], w->ln1_b[l], ws.qkv, D, Mc, D, w->ln_eps, st));
-        RUN(mvf_qkv_attn_impl(dtype, ws.qkv, D, w->qkv_w[l], w->qkv_b[l], nullptr, nullptr, nullptr, 0, 0.f, ws.h, fc, N, H, D, st));
+        RUN(timed_qkv_attn(dtype, ws.qkv, w->qkv_w[l], w->qkv_b[l], nullptr, nullptr, nullptr, 0, 0.f, ws.h, fc, N, H, D, st));
       }
     }
     if (fused_attn) {

@@ -1450,3 +1450,38 @@ def test_static_query_kernels_vs_fp64(nq, d, C):
     check(gwk, gwk_buf0[:, :C].double() + q64.t() @ dv.double(), 2e-6, 'static query d W_K')
     assert torch.equal(gwk_buf[:, C:], gwk_buf0[:, C:])          # the padding columns of the strided gradient are untouched
 
+
+def test_qkv_attention_fused_kernel_repeats_bitwise_beside_other_work():
+    """Race screen for the fused kernel's LDS hand-overs (operand ring -> Q / K / V images on top of it, (mean, rstd) slots, hand-written
+    lgkmcnt / vmcnt waits): 150 launches at BASELINE configs[1] size while a second stream keeps other kernels in flight (workgroups start
+    at staggered times, the CU's two workgroups drift against each other) -- every output must be the first launch's, bit for bit."""
+    F, N, D, H = 256, 197, 768, 12
+    M = F * N
+    g = gen(5)
+    A = (torch.randn(M, D, generator=g) * 1.3 + 0.2).to(DEV).to(torch.bfloat16)
+    W = (torch.randn(3 * D, D, generator=g) * 0.06).to(DEV).to(torch.bfloat16)
+    b = torch.randn(3 * D, generator=g).to(DEV)
+    ns = D // 64
+    xs = A.float().view(M, ns, 64)
+    part = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).permute(1, 0, 2).contiguous()
+    c = W.float().sum(1).contiguous()
+
+    def run(out):
+        _lib.call('mvf_vit_qkv_attn_fwd', _lib.BF16, A.data_ptr(), D, W.data_ptr(), b.data_ptr(), c.data_ptr(), None, part.data_ptr(), ns,
+                  1e-6, out.data_ptr(), F, N, H, D, S())
+    ref = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    run(ref)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    X = torch.randn(2048, 2048, device=DEV)
+    bad = 0
+    for it in range(150):
+        out = torch.full((M, D), 7.0, device=DEV, dtype=torch.bfloat16)
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                X.mul_(1.0)                     # (an elementwise pass over 16 MB: a few hundred workgroups competing for CUs)
+        run(out)
+        bad += 0 if torch.equal(out, ref) else 1
+    torch.cuda.synchronize()
+    assert bad == 0, bad
+

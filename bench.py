@@ -30,6 +30,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# the host driver only supports dmabuf IPC: without this RCCL's buffer exchange fails with `hipIpcGetMemHandle: invalid argument`
+# (exported on the GPU boxes already; set here too so that a bare launcher environment cannot lose it)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

@@ -23,9 +23,12 @@ import random
 import shutil
 import time
 
-import numpy as np
-import torch
-import torch.nn as nn
+# (the host driver of the MI355X boxes only supports dmabuf IPC: RCCL's buffer exchange needs this before the runtime loads)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
 
 from . import ops
 from .utils import distributed as du

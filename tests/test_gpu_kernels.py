@@ -548,21 +548,21 @@ def test_vit_forward_fp32_vs_oracle(dim, depth, heads, patch, img, F):
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_vit_forward_lanes_bitwise(dtype):
-    """The forward split into concurrent lanes (one HIP stream + workspace each) returns the same bits as one call,
-    call after call (the second round reuses the lanes' workspaces while the first round's outputs are compared)."""
+    """The forward split into concurrent lanes (one HIP stream + workspace each; the lanes need not be equal) returns the same
+    bits as one call, call after call (the second round reuses the lanes' workspaces while the first round's outputs are compared)."""
     dim, depth, heads, patch, img, F = 128, 2, 2, 16, 64, 8
     w = OV.init_vit_weights(dim, depth, patch, img, seed=5)
     pk = _pack(w, depth, dim, heads, patch, img, (0, 1), dtype)
     xs = [torch.randn(F, 3, img, img, generator=gen(20 + i)).to(DEV) for i in range(3)]
     one = [ops.vit_forward(x, pk, lanes=1) for x in xs]
-    for lanes in (2, 4):
+    for lanes in (2, 4, 3, 5):         # 3, 5: unequal lanes (3 + 3 + 2 frames, 2 + 2 + 2 + 1 + 1)
         many = [ops.vit_forward(x, pk, lanes=lanes) for x in xs]
         torch.cuda.synchronize()
         for (t1, c1), (t2, c2) in zip(one, many):
             assert all(torch.equal(a, b) for a, b in zip(t1, t2)), lanes
             assert torch.equal(c1, c2), lanes
     with pytest.raises(ops._lib.MvfError):
-        ops.vit_forward(xs[0], pk, lanes=3)
+        ops.vit_forward(xs[0], pk, lanes=9)                 # more lanes than frames
 
 
 def test_vit_forward_bf16_error():

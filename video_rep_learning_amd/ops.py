@@ -1455,8 +1455,8 @@ VIT_LANES = 2
 def vit_forward(frames, packed, frames_per_chunk=0, want_cls=True, attn_variant=0, lanes=None):
     """frames [F,3,H,W] fp32 -> (taps: list of [F*(N-1), dim] tensors in packed.tdtype, cls [F, dim] fp32 | None).
 
-    `lanes`: the F frames are forwarded as `lanes` independent slices on as many HIP streams (lane 0 = the caller's
-    stream), each with its own workspace and writing its slice of the outputs.  The persistent GEMM leaves most CUs idle
+    `lanes`: the F frames are forwarded as `lanes` independent slices (of F // lanes frames, the first F % lanes one more) on as
+    many HIP streams (lane 0 = the caller's stream), each with its own workspace and writing its slice of the outputs.  The persistent GEMM leaves most CUs idle
     in the last, partially filled round of 256 x 256 tiles (N = 768: 591 tiles on 256 CUs); with two forwards in flight
     the other lane's kernels fill those CUs (ViT-B/16, 256 frames: 12.09 -> 11.31 ms, outputs bitwise identical).
     None = 2 lanes when each still fills the chip, else 1."""
@@ -1468,10 +1468,11 @@ def vit_forward(frames, packed, frames_per_chunk=0, want_cls=True, attn_variant=
     np_ = (packed.img // packed.patch) ** 2
     if lanes is None:
         lanes = VIT_LANES if (F % VIT_LANES == 0 and (F // VIT_LANES) * (np_ + 1) >= VIT_LANE_MIN_ROWS) else 1
-    if lanes < 1 or F % lanes != 0:
+    if lanes < 1 or lanes > F:
         raise _lib.MvfError('vit_forward: %d frames do not split into %d lanes' % (F, lanes))
-    fl = F // lanes
-    fc = fl if frames_per_chunk <= 0 else min(frames_per_chunk, fl)
+    sizes = [F // lanes + (1 if s < F % lanes else 0) for s in range(lanes)]       # (the first F % lanes lanes take one frame more)
+    starts = [sum(sizes[:s]) for s in range(lanes)]
+    fc_max = sizes[0] if frames_per_chunk <= 0 else min(frames_per_chunk, sizes[0])
     dev = frames.device
     taps = [torch.empty(F * np_, packed.dim, device=dev, dtype=packed.tdtype) for _ in packed.taps]
     cls = torch.empty(F, packed.dim, device=dev, dtype=torch.float32) if want_cls else None
@@ -1486,11 +1487,13 @@ def vit_forward(frames, packed, frames_per_chunk=0, want_cls=True, attn_variant=
         st = cur if s == 0 else packed.lane_stream(s, dev)
         if s > 0:
             st.wait_event(ready)
-        ws = packed.workspace(fc, dev, s)
-        tab = (ctypes.c_void_p * max(len(taps), 1))(*[t.data_ptr() + s * fl * np_ * packed.dim * esz for t in taps])
+        fl, f0 = sizes[s], starts[s]
+        fc = fl if frames_per_chunk <= 0 else min(frames_per_chunk, fl)
+        ws = packed.workspace(fc_max, dev, s)      # (one size for every lane: the cache is keyed by it)
+        tab = (ctypes.c_void_p * max(len(taps), 1))(*[t.data_ptr() + f0 * np_ * packed.dim * esz for t in taps])
         call('mvf_vit_fwd', ctypes.byref(packed.struct), packed.code,
-             frames.data_ptr() + s * fl * 3 * packed.img * packed.img * 4, fl, tab,
-             None if cls is None else cls.data_ptr() + s * fl * packed.dim * 4, ptr(ws), ws.numel(), fc, attn_variant,
+             frames.data_ptr() + f0 * 3 * packed.img * packed.img * 4, fl, tab,
+             None if cls is None else cls.data_ptr() + f0 * packed.dim * 4, ptr(ws), ws.numel(), fc, attn_variant,
              ctypes.c_void_p(st.cuda_stream))
         if s > 0:
             ev = torch.cuda.Event()

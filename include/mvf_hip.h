@@ -363,6 +363,106 @@ int mvf_lstp_fused_bwd(const void* const* taps, int n_taps, int dtype, int D, in
 int mvf_lstp_select(int form);
 
 /* ------------------------------------------------------------------------------------------------
+ * Row-chain kernels of the trainable head on the 16-bit matrix cores (csrc/head_chain.hip): one launch walks a chain of
+ * row-wise operators over 32-row panels (activations in LDS, bf16 weights streamed from L2).  Used when the head runs in
+ * bf16 (MI355X.HEAD_DTYPE, default = bf16 unless COMPUTE_DTYPE is fp32 -- the reference's head runs under fp16 autocast,
+ * train.py:113-117); GEMM operands bf16, accumulation / LayerNorm / dropout / residual stream fp32.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct MvfDrop {       /* counter-based dropout of mvf_dropout_add (element index = row * width + column); p == 0: identity */
+  float p;
+  uint64_t seed, offset;
+} MvfDrop;
+
+/* FRAGMENT-MAJOR ("FM") image of a bf16 matrix X[rows][red] (red = the reduction index of the GEMM it feeds):
+ *     FM[rows / 16][red / 32][64][8]     lane = row % 16 + 16 * ((red % 32) / 8), element = red % 8
+ * -- each 16 x 32 block stored as the 64 lanes of v_mfma_f32_16x16x32_bf16 hold it, so a wave fetches a fragment with one coalesced
+ * 1 KB load; rows padded to a multiple of 64, red to a multiple of 128 (zeros).
+ * bf16 operand copies of nn.Linear weights: w fp32 [N, K] (row stride ld) -> w16 = FM image of W (rows n, reduction k: the forward
+ * operand) and w16t = FM image of W^T (rows k, reduction n: the input-gradient operand); either may be NULL.  n <= 32 entries, one
+ * launch.  mvf_head_pack_elems: elements of the two images. */
+typedef struct MvfPackEntry {
+  const float* w;
+  long ld;
+  int N, K;
+  void* w16;
+  void* w16t;
+} MvfPackEntry;
+int mvf_head_pack_weights(const MvfPackEntry* entries_host, int n, hipStream_t stream);
+/* measurement knob of tools/chain_probe.py (0 = product behaviour): see csrc/head_chain.hip g_chain_dbg */
+int mvf_head_chain_debug(int bits);
+/* diagnostic: pull `bytes` of read-only data into every XCD's L2 (256 workgroups, slice b / 8 each) */
+int mvf_head_l2_warm(const void* p, size_t bytes, hipStream_t stream);
+int mvf_head_chain_debug_stamps(long long* stamps16);   /* device buffer of 16 int64, or NULL (default): stage time stamps of workgroup 0 */
+size_t mvf_head_pack_elems(int N, int K, int transposed);
+
+/* One temporal EncoderLayer minus its attention core (models/utils.py:196-226; ResidualConnection :147-159,
+ * MultiheadedAttention :75-108, PositionwiseFeedForward :176-194), rows m of x [M, D]:
+ *   segment A (o != NULL):     x1 = x_in + drop_attn(o Wo^T + bo);  h1 = LN1(x1);  a = relu(h1 W1^T + b1);
+ *                              x2 = x1 + drop_ffn(a W2^T + b2)                       [o = attention output of this layer]
+ *   segment B (wqkv != NULL):  h0 = LN0(x2, or x_in without segment A);  qkv = h0 Wqkv^T + bqkv   [the NEXT layer's Q|K|V]
+ * w*: bf16 copies from mvf_head_pack_weights (w16).  Saved for the backward (each may be NULL): x1, mean1 / rstd1, a
+ * (bf16 [M, DFF]), mean0 / rstd0, and the operands of the weight gradients oT, h1T, h0T, aT: FM images of the TRANSPOSED
+ * activations [D or DFF (padded to 64), Mp] (rows = features, reduction = the row index m; Mp multiple of 128, >= M; m >= M zero).  D % 256 == 0, DFF % 256 == 0, D <= 512; MVF_ERR_UNSUPPORTED when the
+ * panels do not fit 160 KB of LDS. */
+typedef struct MvfEncFwd {
+  int M, D, DFF, Mp;
+  float ln_eps;
+  const float* o;
+  const float* x_in;
+  const void *wo, *w1, *w2;
+  const float *bo, *b1, *b2, *ln1_g, *ln1_b;
+  MvfDrop drop_attn, drop_ffn;
+  float *x1, *mean1, *rstd1;
+  void* a;
+  float* x2;
+  void *oT, *h1T, *aT;
+  const void* wqkv;
+  const float *bqkv, *ln0_g, *ln0_b;
+  float *qkv, *mean0, *rstd0;
+  void* h0T;
+} MvfEncFwd;
+int mvf_enc_layer_fwd(const MvfEncFwd* args_host, hipStream_t stream);
+
+/* The same chain backwards.  dres [M, D]: the gradient arriving on the residual stream (of the layer's output when only
+ * segment A' runs; dx1 of the layer whose Q|K|V gradient dqkv is consumed when segment B' runs).
+ *   segment B' (dqkv != NULL):  dh0 = dqkv Wqkv;  dx = dres + LN0'(dh0)   -> dx_out (may be NULL when A' follows)
+ *   segment A' (w2T != NULL):   on dy = dx (or dres):  g2 = mask_ffn(dy);  du = (g2 W2) [a > 0];  dh1 = du W1;
+ *                               dx1 = dy + LN1'(dh1) -> dx1_out;  go = mask_attn(dx1);  d_o = go Wo
+ * w*T: the transposed images (w16t).  dqkvT, g2T / goT, duT: FM images of the transposed output gradients [3D | D | DFF, Mp]
+ * for mvf_head_dw (may be NULL).  dln*_g / dln*_b: LayerNorm parameter gradients, ACCUMULATED with float atomics. */
+typedef struct MvfEncBwd {
+  int M, D, DFF, Mp;
+  const float* dqkv;
+  const void* wqkvT;
+  const float *x_in, *mean0, *rstd0, *ln0_g;
+  float *dln0_g, *dln0_b;
+  void* dqkvT;
+  const float* dres;
+  float* dx_out;
+  MvfDrop drop_ffn, drop_attn;
+  const void *w2T, *w1T, *woT;
+  const void* a;
+  const float *x1, *mean1, *rstd1, *ln1_g;
+  float *dln1_g, *dln1_b;
+  void *g2T, *duT, *goT;
+  float *dx1_out, *d_o;
+} MvfEncBwd;
+int mvf_enc_layer_bwd(const MvfEncBwd* args_host, hipStream_t stream);
+
+/* Weight / bias gradients of n <= 16 Linears in one launch: dw[n][k] (+)= sum_m gT[n][m] xT[k][m], db[n] (+)= sum_m gT[n][m]
+ * (db may be NULL); gT, xT: FM images of [N, Mp] and [K, Mp] (the transposed saves above; Mp % 128 == 0).  accumulate != 0: add into dw / db (the flat
+ * gradient buffer).  Fixed summation order (no atomics). */
+typedef struct MvfDwProblem {
+  const void* gT;
+  const void* xT;
+  float* dw;
+  long lddw;
+  float* db;
+  int N, K;
+} MvfDwProblem;
+int mvf_head_dw(const MvfDwProblem* probs_host, int n, int Mp, int accumulate, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Sequence-contrastive loss (algos/scl.py:52-105), fused forward / backward
  *   negative_flags: bit0 'single' in NEGATIVE_TYPE, bit1 'noself' in NEGATIVE_TYPE
  * ---------------------------------------------------------------------------------------------- */

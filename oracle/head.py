@@ -82,7 +82,43 @@ class HeadCfg:
 # ----------------------------------------------------------------------------
 # primitives
 # ----------------------------------------------------------------------------
+# Emulation of the 16-bit head (csrc/head_chain.hip; MI355X.HEAD_DTYPE bf16): the SAME restatement with a round-to-nearest-even
+# bf16 rounding of both GEMM operands of the Linears the device runs on the bf16 matrix cores -- forward (x, W), input gradient
+# (dy, W) and weight gradient (dy, x); the bias gradient sums the rounded dy (the device sums the operand it has).  Everything
+# else (accumulation, bias, LayerNorm, BatchNorm, softmax, residual stream) stays in the oracle's precision.  `prefixes`: the
+# parameter-name prefixes of the Linears concerned (None: all).  Off by default: plain matmul.
+EMU = {'mode': None, 'prefixes': None}
+
+
+def emulate_head(mode=None, prefixes=None):
+    assert mode in (None, 'bf16'), mode
+    EMU.update(mode=mode, prefixes=None if prefixes is None else tuple(prefixes))
+
+
+def bf16r(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _EmuLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xr, wr = bf16r(x), bf16r(w)
+        ctx.save_for_backward(xr, wr)
+        ctx.has_b = b is not None
+        y = xr @ wr.t()
+        return y + b if b is not None else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, wr = ctx.saved_tensors
+        g = bf16r(dy)
+        g2, x2 = g.reshape(-1, g.shape[-1]), xr.reshape(-1, xr.shape[-1])
+        return g @ wr, g2.t() @ x2, (g2.sum(0) if ctx.has_b else None)
+
+
 def linear(x, p, name):
+    if EMU['mode'] is not None and (EMU['prefixes'] is None or name.startswith(EMU['prefixes'])):
+        return _EmuLinear.apply(x, p[name + '.weight'], p.get(name + '.bias'))
     y = x @ p[name + '.weight'].t()
     if name + '.bias' in p:
         y = y + p[name + '.bias']

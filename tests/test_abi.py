@@ -64,7 +64,12 @@ def test_struct_layouts_match_the_header(tmp_path):
     if shutil.which('gcc') is None or not os.path.exists('/opt/rocm/include/hip/hip_runtime_api.h'):
         pytest.skip('needs gcc and the HIP headers')
     probes = [('MvfVitWeights', ['depth', 'taps', 'ln_eps', 'cls_token', 'patch_w', 'ln1_w', 'fc2_b', 'ls2']),
-              ('MvfAugmentParams', ['crop_top', 'flip', 'color_op', 'color_factor', 'blur_kx', 'blur_sigma', 'gray', 'mean', 'std'])]
+              ('MvfAugmentParams', ['crop_top', 'flip', 'color_op', 'color_factor', 'blur_kx', 'blur_sigma', 'gray', 'mean', 'std']),
+              ('MvfDrop', ['p', 'seed', 'offset']),
+              ('MvfPackEntry', ['w', 'ld', 'N', 'K', 'w16', 'w16t']),
+              ('MvfEncFwd', ['M', 'Mp', 'ln_eps', 'o', 'wo', 'ln1_b', 'drop_attn', 'drop_ffn', 'x1', 'a', 'x2', 'aT', 'wqkv', 'qkv', 'h0T']),
+              ('MvfEncBwd', ['M', 'Mp', 'dqkv', 'dqkvT', 'dres', 'dx_out', 'drop_ffn', 'drop_attn', 'w2T', 'a', 'dln1_b', 'goT', 'd_o']),
+              ('MvfDwProblem', ['gT', 'xT', 'dw', 'lddw', 'db', 'N', 'K'])]
     body = ''.join('printf("%s %%zu", sizeof(%s));%sprintf("\\n");\n' % (
         st, st, ''.join('printf(" %%zu", offsetof(%s, %s));' % (st, f) for f in fs)) for st, fs in probes)
     src = tmp_path / 'layout.c'

@@ -96,6 +96,14 @@ SIGNATURES = {
     'mvf_lstp_reduce_frames': 'ppiiiip',
     'mvf_token_pool': 'piiiiiipp',
     'mvf_lstp_dx': 'piiiiiippppip',
+    'mvf_head_pack_weights': 'pip',
+    'mvf_head_chain_debug': 'i',
+    'mvf_head_l2_warm': 'pzp',
+    'mvf_head_chain_debug_stamps': 'p',
+    'mvf_head_pack_elems': 'iii',
+    'mvf_enc_layer_fwd': 'pp',
+    'mvf_enc_layer_bwd': 'pp',
+    'mvf_head_dw': 'piiip',
     'mvf_scl_rows': 'ppppiip',
     'mvf_scl_fwd': 'pppppppppiiiiffp',
     'mvf_scl_bwd': 'pppppppppiiiiiiffp',
@@ -125,6 +133,40 @@ class MvfAugmentParams(ctypes.Structure):
                 ('gray', _I), ('mean', _F * 3), ('std', _F * 3)]
 
 
+class MvfDrop(ctypes.Structure):
+    """Mirror of `struct MvfDrop` (include/mvf_hip.h)."""
+    _fields_ = [('p', _F), ('seed', ctypes.c_uint64), ('offset', ctypes.c_uint64)]
+
+
+class MvfPackEntry(ctypes.Structure):
+    """Mirror of `struct MvfPackEntry`."""
+    _fields_ = [('w', _P), ('ld', _L), ('N', _I), ('K', _I), ('w16', _P), ('w16t', _P)]
+
+
+class MvfEncFwd(ctypes.Structure):
+    """Mirror of `struct MvfEncFwd`."""
+    _fields_ = ([('M', _I), ('D', _I), ('DFF', _I), ('Mp', _I), ('ln_eps', _F)]
+                + [(n, _P) for n in ('o', 'x_in', 'wo', 'w1', 'w2', 'bo', 'b1', 'b2', 'ln1_g', 'ln1_b')]
+                + [('drop_attn', MvfDrop), ('drop_ffn', MvfDrop)]
+                + [(n, _P) for n in ('x1', 'mean1', 'rstd1', 'a', 'x2', 'oT', 'h1T', 'aT', 'wqkv', 'bqkv', 'ln0_g', 'ln0_b',
+                                     'qkv', 'mean0', 'rstd0', 'h0T')])
+
+
+class MvfEncBwd(ctypes.Structure):
+    """Mirror of `struct MvfEncBwd`."""
+    _fields_ = ([('M', _I), ('D', _I), ('DFF', _I), ('Mp', _I)]
+                + [(n, _P) for n in ('dqkv', 'wqkvT', 'x_in', 'mean0', 'rstd0', 'ln0_g', 'dln0_g', 'dln0_b', 'dqkvT', 'dres',
+                                     'dx_out')]
+                + [('drop_ffn', MvfDrop), ('drop_attn', MvfDrop)]
+                + [(n, _P) for n in ('w2T', 'w1T', 'woT', 'a', 'x1', 'mean1', 'rstd1', 'ln1_g', 'dln1_g', 'dln1_b', 'g2T', 'duT',
+                                     'goT', 'dx1_out', 'd_o')])
+
+
+class MvfDwProblem(ctypes.Structure):
+    """Mirror of `struct MvfDwProblem`."""
+    _fields_ = [('gT', _P), ('xT', _P), ('dw', _P), ('lddw', _L), ('db', _P), ('N', _I), ('K', _I)]
+
+
 class MvfError(RuntimeError):
     pass
 
@@ -147,7 +189,8 @@ def load():
     for name, sig in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.argtypes = [_KIND[k] for k in sig]
-        fn.restype = _Z if name in ('mvf_vit_workspace_bytes', 'mvf_bn_workspace_floats', 'mvf_augment_workspace_bytes') else _I
+        fn.restype = _Z if name in ('mvf_vit_workspace_bytes', 'mvf_bn_workspace_floats', 'mvf_augment_workspace_bytes',
+                                    'mvf_head_pack_elems') else _I
     _lib = lib
     return lib
 

@@ -221,6 +221,7 @@ class MultiEntityTransformerEmbModel(nn.Module):
         if cfg.MODEL.EMBEDDER_MODEL.NUM_LAYERS > 0:
             self.video_encoder = Encoder(hidden_channels, drop_rate, cfg.MODEL.EMBEDDER_MODEL.NUM_HEADS,
                                          cfg.MODEL.EMBEDDER_MODEL.D_FF, cfg.MODEL.EMBEDDER_MODEL.NUM_LAYERS)
+            self.video_encoder.head_dtype = ops.head_dtype_of(cfg)
         self.embedding_layer = nn.Linear(hidden_channels, self.embedding_size)
         self.smart_final = _em(cfg, 'SMART_FINAL', 'max')
         assert self.smart_final in ['max', 'one', 'avg', 'lin']

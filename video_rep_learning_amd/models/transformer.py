@@ -62,6 +62,7 @@ class TransformerEmbModel(nn.Module):
         self.video_pos_enc = PositionalEncoder(cfg, hidden_channels, drop_rate, seq_len=cfg.TRAIN.NUM_FRAMES)
         if em.NUM_LAYERS > 0:
             self.video_encoder = Encoder(hidden_channels, drop_rate, em.NUM_HEADS, em.D_FF, em.NUM_LAYERS)
+            self.video_encoder.head_dtype = ops.head_dtype_of(cfg)
         self.embedding_layer = nn.Linear(hidden_channels, self.embedding_size)
         self.drop_state = ops.DropoutState(seed=int(cfg.RNG_SEED) if 'RNG_SEED' in cfg else 0)
         self.sync_group = None

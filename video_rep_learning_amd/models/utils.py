@@ -138,7 +138,43 @@ class Encoder(nn.Module):
         layer = EncoderLayer(d_model, dout_p, H, d_ff, d_hidden)
         self.enc_layers = nn.ModuleList([deepcopy(layer) for _ in range(N)])
 
+        # 'bf16': run on the row-chain kernels (csrc/head_chain.hip) where the shapes allow it; set from cfg by the owning model
+        # (ops.head_dtype_of); 'fp32' = one kernel per operator on the fp32 matrix cores (parity mode)
+        self.head_dtype = 'fp32'
+        self._pack = ops.HeadPack()
+
+    def invalidate_packed(self):
+        """The fused optimizer updated the parameters through raw pointers: the bf16 operand copies are stale."""
+        self._pack.invalidate()
+
+    def _chain_layers(self):
+        layers = []
+        for ly in self.enc_layers:
+            att, ff = ly.self_att, ly.feed_forward
+            if att.d_model != att.linear_Q2d.weight.shape[1] or att.d_out != att.d_model:
+                return None
+            w, b, fused = att._qkv_operands()
+            plist = [ly.res_layer0.norm.weight, ly.res_layer0.norm.bias, w, b, att.linear_d2Q.weight, att.linear_d2Q.bias,
+                     ly.res_layer1.norm.weight, ly.res_layer1.norm.bias, ff.fc1.weight, ff.fc1.bias, ff.fc2.weight, ff.fc2.bias]
+            slots = [ops.grad_slot(q) for q in plist]
+            owners = [q for i, q in enumerate(plist) if i not in (2, 3)]
+            if fused is not None:
+                slots[2], slots[3] = fused[0], fused[1]
+                owners += list(fused[2])
+            layers.append({'params': plist, 'slots': slots if all(s_ is not None for s_ in slots) else None, 'owners': owners})
+        return layers
+
     def forward(self, x, src_mask=None, drop_state=None):
+        l0 = self.enc_layers[0] if len(self.enc_layers) > 0 else None
+        if self.head_dtype == 'bf16' and l0 is not None and x.is_cuda and \
+                ops.encoder_chain_supported(x.shape[-1], l0.feed_forward.fc1.weight.shape[0], l0.self_att.H):
+            layers = self._chain_layers()
+            if layers is not None:
+                drops = []
+                for ly in self.enc_layers:
+                    drops.append(ops.drop_args(ly.res_layer0.dout_p, self.training, drop_state, x.numel()))
+                    drops.append(ops.drop_args(ly.res_layer1.dout_p, self.training, drop_state, x.numel()))
+                return ops.encoder_chain(x, src_mask, layers, l0.self_att.H, l0.res_layer0.norm.eps, drops, self._pack)
         for layer in self.enc_layers:
             x = layer(x, src_mask, drop_state)
         return x

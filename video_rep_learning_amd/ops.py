@@ -845,6 +845,260 @@ def temporal_attention(qkv, mask, B, S, H):
 
 
 # ------------------------------------------------------------------------------------------------
+# Row-chain kernels of the head on the 16-bit matrix cores (csrc/head_chain.hip)
+# ------------------------------------------------------------------------------------------------
+# MVF_HEAD_CHAIN=0: keep the one-kernel-per-operator fp32 head everywhere (A/B measurements, tests)
+HEAD_CHAIN = os.environ.get('MVF_HEAD_CHAIN', '1') != '0'
+
+
+def head_dtype_of(cfg):
+    """'bf16' | 'fp32': the trainable head's GEMM operand dtype.  cfg.MI355X.HEAD_DTYPE when given; else bf16 whenever the
+    backbone runs in a reduced precision (bf16 / fp16 / fp8, or USE_AMP without a COMPUTE_DTYPE) -- the reference's head runs
+    under fp16 autocast then (train.py:113-117) -- and fp32 in parity mode (COMPUTE_DTYPE fp32)."""
+    mi = cfg.MI355X if 'MI355X' in cfg else {}
+    if 'HEAD_DTYPE' in mi:
+        hd = str(mi['HEAD_DTYPE']).lower()
+        if hd not in ('bf16', 'fp32'):
+            raise ValueError("MI355X.HEAD_DTYPE must be 'bf16' or 'fp32' (got %r)" % (mi['HEAD_DTYPE'],))
+        return hd
+    cd = mi['COMPUTE_DTYPE'] if 'COMPUTE_DTYPE' in mi else ('bf16' if ('USE_AMP' in cfg and cfg.USE_AMP) else 'fp32')
+    return 'fp32' if str(cd).lower() in ('fp32', 'f32') else 'bf16'
+
+
+class HeadPack:
+    """bf16 operand copies (fragment-major images of W and of W^T) of a set of nn.Linear weights, refreshed by ONE launch when any source
+    changed: torch's version counters catch in-place writes (load_state_dict, torch optimizers), `invalidate()` is what the
+    fused optimizer calls after it updated the parameters through raw pointers (FusedAdam.packed_owners)."""
+
+    def __init__(self):
+        self.key = None
+        self.buf = None
+        self.views = {}
+        self.stale = True
+
+    def invalidate(self):
+        self.stale = True
+
+    def get(self, named):
+        """named: [(name, weight [N, K] fp32 with unit inner stride)] -> {name: (w16 ptr, w16t ptr)}"""
+        key = tuple((n, w.data_ptr(), w._version, tuple(w.shape), w.stride(0)) for n, w in named)
+        if not self.stale and key == self.key:
+            return self.views
+        lib = _lib.load()
+        dev = named[0][1].device
+        sizes = [(lib.mvf_head_pack_elems(w.shape[0], w.shape[1], 0), lib.mvf_head_pack_elems(w.shape[0], w.shape[1], 1))
+                 for _n, w in named]
+        total = sum((a + 63) // 64 * 64 + (b + 63) // 64 * 64 for a, b in sizes)
+        if self.buf is None or self.buf.numel() < total or self.buf.device != dev:
+            self.buf = torch.empty(total, device=dev, dtype=torch.bfloat16)
+        ents = (_lib.MvfPackEntry * len(named))()
+        views, off, base = {}, 0, self.buf.data_ptr()
+        for i, ((n, w), (a, b)) in enumerate(zip(named, sizes)):
+            if not w.is_cuda:
+                raise _lib.MvfError('HIP op received a %s tensor (no CPU fallback)' % w.device)
+            assert w.dim() == 2 and w.dtype == torch.float32 and w.stride(1) == 1
+            p16, off = base + 2 * off, off + (a + 63) // 64 * 64
+            p16t, off = base + 2 * off, off + (b + 63) // 64 * 64
+            e = ents[i]
+            e.w, e.ld, e.N, e.K, e.w16, e.w16t = w.data_ptr(), w.stride(0), w.shape[0], w.shape[1], p16, p16t
+            views[n] = (p16, p16t)
+        for i0 in range(0, len(named), 32):
+            n = min(32, len(named) - i0)
+            call('mvf_head_pack_weights', ctypes.byref(ents, i0 * ctypes.sizeof(_lib.MvfPackEntry)), n, stream())
+        self.key, self.views, self.stale = key, views, False
+        return views
+
+
+def _drop_c(d):
+    """(p, seed, offset) | None -> MvfDrop"""
+    m = _lib.MvfDrop()
+    if d is not None:
+        m.p, m.seed, m.offset = float(d[0]), int(d[1]), int(d[2])
+    return m
+
+
+def encoder_chain_supported(D, DFF, H):
+    return HEAD_CHAIN and D % 256 == 0 and DFF % 256 == 0 and D <= 512 and D % H == 0 and (D // H) in (16, 32, 64) and \
+        32 * ((D + 4) * 8 + (D + 8) * 2 + (max(DFF, 3 * D) + 8) * 2) <= 160 * 1024
+
+
+class _EncoderChain(torch.autograd.Function):
+    """The temporal Encoder (models/utils.py:228-242: N pre-LN EncoderLayers, no final norm) as ONE autograd node on the
+    row-chain kernels: per layer one attention launch + one chain launch forward; one chain launch + the two attention-backward
+    launches backward; all weight / bias gradients of the encoder in one launch at the end.
+    params per layer (12): ln0.w, ln0.b, Wqkv [3D, D], bqkv, Wo, bo, ln1.w, ln1.b, W1, b1, W2, b2."""
+
+    NP = 12
+
+    @staticmethod
+    def forward(ctx, x, mask, B, S, H, eps, drops, pack, slots, owners, *params):
+        L = len(params) // _EncoderChain.NP
+        x = x.contiguous()
+        M, D = x.shape
+        DFF = params[8].shape[0]
+        dev = x.device
+        Mp = (M + 127) // 128 * 128
+        need = any(ctx.needs_input_grad)
+        named = []
+        for l in range(L):
+            P = params[l * 12:(l + 1) * 12]
+            named += [('qkv%d' % l, P[2]), ('o%d' % l, P[4]), ('f1%d' % l, P[8]), ('f2%d' % l, P[10])]
+        W = pack.get(named)
+        mlen, mk = S, None
+        if mask is not None:
+            mk = mask.reshape(B, -1)
+            mlen = mk.shape[1]
+            assert S % mlen == 0, (S, mlen)
+            if mk.dtype != torch.float32 or not mk.is_contiguous():
+                mk = mk.contiguous().float()
+
+        def f32(*shape):
+            return torch.empty(*shape, device=dev, dtype=torch.float32)
+
+        def b16(rows, cols):
+            """bf16 [rows, cols] (the row save of `a`), or -- cols == Mp -- the fragment-major image of a transposed operand
+            (rows padded to 64: include/mvf_hip.h, "FM")"""
+            return torch.empty((rows + 63) // 64 * 64, cols, device=dev, dtype=torch.bfloat16) if need else None
+
+        saved = []
+        xs = [x]
+        a = _lib.MvfEncFwd()
+        a.M, a.D, a.DFF, a.Mp, a.ln_eps = M, D, DFF, Mp, eps
+        P0 = params[0:12]
+        qkv, mean0, rstd0, h0T = f32(M, 3 * D), f32(M), f32(M), b16(D, Mp)
+        a.x_in, a.wqkv, a.bqkv, a.ln0_g, a.ln0_b = ptr(x), W['qkv0'][0], ptr(P0[3]), ptr(P0[0]), ptr(P0[1])
+        a.qkv, a.mean0, a.rstd0, a.h0T = ptr(qkv), ptr(mean0), ptr(rstd0), ptr(h0T)
+        call('mvf_enc_layer_fwd', ctypes.byref(a), stream())
+        for l in range(L):
+            P = params[l * 12:(l + 1) * 12]
+            o, lse = f32(M, D), f32(B, H, S)
+            call('mvf_tattn_fwd', ptr(qkv), ptr(mk), mlen, ptr(o), ptr(lse), B, S, H, D, stream())
+            x1, mean1, rstd1, x2 = f32(M, D), f32(M), f32(M), f32(M, D)
+            act, oT, h1T, aT = b16(M, DFF), b16(D, Mp), b16(D, Mp), b16(DFF, Mp)
+            a = _lib.MvfEncFwd()
+            a.M, a.D, a.DFF, a.Mp, a.ln_eps = M, D, DFF, Mp, eps
+            a.o, a.x_in = ptr(o), ptr(xs[-1])
+            a.wo, a.w1, a.w2 = W['o%d' % l][0], W['f1%d' % l][0], W['f2%d' % l][0]
+            a.bo, a.b1, a.b2, a.ln1_g, a.ln1_b = ptr(P[5]), ptr(P[9]), ptr(P[11]), ptr(P[6]), ptr(P[7])
+            a.drop_attn, a.drop_ffn = _drop_c(drops[2 * l]), _drop_c(drops[2 * l + 1])
+            a.x1, a.mean1, a.rstd1, a.a, a.x2 = ptr(x1), ptr(mean1), ptr(rstd1), ptr(act), ptr(x2)
+            a.oT, a.h1T, a.aT = ptr(oT), ptr(h1T), ptr(aT)
+            rec = dict(qkv=qkv, o=o, lse=lse, x1=x1, mean1=mean1, rstd1=rstd1, a=act, oT=oT, h1T=h1T, aT=aT, mean0=mean0, rstd0=rstd0,
+                       h0T=h0T)
+            if l + 1 < L:
+                Pn = params[(l + 1) * 12:(l + 2) * 12]
+                qkv, mean0, rstd0, h0T = f32(M, 3 * D), f32(M), f32(M), b16(D, Mp)
+                a.wqkv, a.bqkv, a.ln0_g, a.ln0_b = W['qkv%d' % (l + 1)][0], ptr(Pn[3]), ptr(Pn[0]), ptr(Pn[1])
+                a.qkv, a.mean0, a.rstd0, a.h0T = ptr(qkv), ptr(mean0), ptr(rstd0), ptr(h0T)
+            call('mvf_enc_layer_fwd', ctypes.byref(a), stream())
+            saved.append(rec)
+            xs.append(x2)
+        if need:
+            ctx.saved = saved
+            ctx.xs = xs
+            ctx.params = params
+            ctx.cfg = (B, S, H, M, D, DFF, Mp, L, mk, mlen, drops, W, slots, owners)
+            ctx.keep = pack.buf         # the bf16 copies the backward reads (a later refresh allocates a new buffer only if it grows)
+        return xs[-1]
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, S, H, M, D, DFF, Mp, L, mk, mlen, drops, W, slots, owners = ctx.cfg
+        params, saved, xs = ctx.params, ctx.saved, ctx.xs
+        dev = dy.device
+        dy = dy.contiguous().view(M, D)
+
+        def f32(*shape):
+            return torch.empty(*shape, device=dev, dtype=torch.float32)
+
+        def b16(rows, cols):
+            return torch.empty((rows + 63) // 64 * 64, cols, device=dev, dtype=torch.bfloat16)
+
+        use_slots = slots is not None
+        grads = [None] * len(params)
+
+        def gbuf(i, zero):
+            """gradient buffer of params[i]: its flat-gradient slot, or a fresh tensor"""
+            if use_slots:
+                return slots[i]
+            g = (torch.zeros_like if zero else torch.empty_like)(params[i])
+            grads[i] = g
+            return g
+
+        probs = []
+        keep = []
+        dres, dqkv = dy, None
+        for l in range(L - 1, -2, -1):
+            a = _lib.MvfEncBwd()
+            a.M, a.D, a.DFF, a.Mp = M, D, DFF, Mp
+            a.dres = ptr(dres)
+            if dqkv is not None:        # segment B' of layer l + 1
+                lb = l + 1
+                R = saved[lb]
+                dqkvT = b16(3 * D, Mp)
+                a.dqkv, a.wqkvT, a.x_in = ptr(dqkv), W['qkv%d' % lb][1], ptr(xs[lb])
+                a.mean0, a.rstd0, a.ln0_g = ptr(R['mean0']), ptr(R['rstd0']), ptr(params[lb * 12 + 0])
+                a.dln0_g, a.dln0_b = gbuf(lb * 12 + 0, True).data_ptr(), gbuf(lb * 12 + 1, True).data_ptr()
+                a.dqkvT = ptr(dqkvT)
+                probs.append((dqkvT, R['h0T'], lb * 12 + 2, lb * 12 + 3, 3 * D, D))
+                keep.append(dqkvT)
+            dx_out = None
+            if l < 0:
+                dx_out = f32(M, D)
+                a.dx_out = ptr(dx_out)
+            else:                        # segment A' of layer l
+                R = saved[l]
+                g2T, duT, goT, dx1, d_o = b16(D, Mp), b16(DFF, Mp), b16(D, Mp), f32(M, D), f32(M, D)
+                a.drop_attn, a.drop_ffn = _drop_c(drops[2 * l]), _drop_c(drops[2 * l + 1])
+                a.w2T, a.w1T, a.woT = W['f2%d' % l][1], W['f1%d' % l][1], W['o%d' % l][1]
+                a.a, a.x1, a.mean1, a.rstd1, a.ln1_g = ptr(R['a']), ptr(R['x1']), ptr(R['mean1']), ptr(R['rstd1']), ptr(params[l * 12 + 6])
+                a.dln1_g, a.dln1_b = gbuf(l * 12 + 6, True).data_ptr(), gbuf(l * 12 + 7, True).data_ptr()
+                a.g2T, a.duT, a.goT, a.dx1_out, a.d_o = ptr(g2T), ptr(duT), ptr(goT), ptr(dx1), ptr(d_o)
+                probs += [(g2T, R['aT'], l * 12 + 10, l * 12 + 11, D, DFF), (duT, R['h1T'], l * 12 + 8, l * 12 + 9, DFF, D),
+                          (goT, R['oT'], l * 12 + 4, l * 12 + 5, D, D)]
+                keep += [g2T, duT, goT]
+            call('mvf_enc_layer_bwd', ctypes.byref(a), stream())
+            if l < 0:
+                break
+            dqkv = f32(M, 3 * D)
+            call('mvf_tattn_bwd', ptr(R['qkv']), ptr(mk), mlen, ptr(R['o']), ptr(R['lse']), ptr(d_o), ptr(dqkv), B, S, H, D, stream())
+            dres = dx1
+        # every weight / bias gradient of the encoder: one launch per 16 Linears
+        for i0 in range(0, len(probs), 16):
+            chunk = probs[i0:i0 + 16]
+            arr = (_lib.MvfDwProblem * len(chunk))()
+            for e, (gT, xT, iw, ib, N, K) in zip(arr, chunk):
+                gw, gb = gbuf(iw, False), gbuf(ib, False)
+                e.gT, e.xT, e.dw, e.lddw, e.db, e.N, e.K = ptr(gT), ptr(xT), gw.data_ptr(), gw.stride(0) if gw.dim() == 2 else K, gb.data_ptr(), N, K
+            call('mvf_head_dw', arr, len(chunk), Mp, 1 if use_slots else 0, stream())
+        if use_slots:
+            grad_ready(*owners)
+        ctx.saved = ctx.xs = None
+        return (dx_out if ctx.needs_input_grad[0] else None, None, None, None, None, None, None, None, None, None) + tuple(grads)
+
+
+def encoder_chain(x, mask, layers, H, eps, drops, pack):
+    """x [B, S, D] -> [B, S, D].  layers: per EncoderLayer a dict with the 12 parameter tensors in _EncoderChain's order
+    ('params'), and for parameters that live in the flat gradient buffer 'slots' (12 gradient views, the Q|K|V one over the
+    three projections) + 'owners' (the nn.Parameters to report ready); drops: (p, seed, offset) | None per sub-layer
+    (attention, feed-forward) in layer order."""
+    B, S, D = x.shape
+    params, slots, owners = [], [], []
+    use_slots = x.requires_grad and all(ly.get('slots') is not None for ly in layers)
+    for ly in layers:
+        params += list(ly['params'])
+        if use_slots:
+            slots += list(ly['slots'])
+            owners += list(ly['owners'])
+    if use_slots:
+        for o in owners:
+            grad_slot(o)        # marks the flat gradient buffer as written
+    y = _EncoderChain.apply(x.reshape(B * S, D), mask, B, S, H, float(eps), tuple(drops), pack, tuple(slots) if use_slots else None,
+                            tuple(owners), *params)
+    return y.view(B, S, D)
+
+
+# ------------------------------------------------------------------------------------------------
 # small row ops
 # ------------------------------------------------------------------------------------------------
 class _ConcatOneHot(torch.autograd.Function):

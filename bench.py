@@ -245,6 +245,10 @@ def cpu_baseline(cfg, model):
                       'timed, %.1f s per step' % (nv, 2 * nv, t, iters, dt)}
 
 
+def m0_prefixes(pre):
+    return sorted({q[len('embed.'):] if q.startswith('embed.') else q for q in pre})
+
+
 def parity_block(model, batch, nv, dev, reduced='bf16'):
     """The HIP path vs the oracle on `nv` videos of the resident benchmark batch (real size: ViT-B/16, 32 frames), dropout 0
     (its masks cannot be replayed on the CPU), training-mode loss (BatchNorm batch statistics) and eval-mode per-frame
@@ -264,16 +268,25 @@ def parity_block(model, batch, nv, dev, reduced='bf16'):
     params = T.cpu_params(m0)
     t0 = time.time()
     ref = {}
+    # the benchmarked run's head dtype (MI355X.HEAD_DTYPE, bf16 beside a bf16 backbone): the reduced mode of this block runs the
+    # same head, and the oracle rounds the operands of the Linears the device runs on the bf16 matrix cores (oracle/head.py)
+    head_red = model.head_dtype if reduced != 'fp16' else 'fp32'
+    m0.set_head_dtype(head_red)
+    head_pre = m0.head_bf16_linears()
+    head_pre = tuple('embed.' + q for q in head_pre) + head_pre
+    m0.set_head_dtype('fp32')
     with torch.no_grad():
         for mode in ('fp32', reduced):
             vcfg = dict(vit_cfg, emulate=reduced) if mode == reduced else vit_cfg
             feat, cls = OM.backbone_features(vc.reshape(b * v * t, *vc.shape[3:]), params, vcfg)
-            ref[mode] = (OM.forward_from_backbone(feat, cls, b * v, t, params, vcfg, head_cfg, mc.reshape(b * v, 1, t),
-                                                  project=False, training=False),
-                         OM.loss_from_backbone(feat, cls, sc, stc, mc, params, vcfg, head_cfg, scl_cfg, training=True))
+            with T.OH.emulating(head_pre if mode == reduced else ()):
+                ref[mode] = (OM.forward_from_backbone(feat, cls, b * v, t, params, vcfg, head_cfg, mc.reshape(b * v, 1, t),
+                                                      project=False, training=False),
+                             OM.loss_from_backbone(feat, cls, sc, stc, mc, params, vcfg, head_cfg, scl_cfg, training=True))
     algo = get_algo(cfg0)
     out = {'sample': '%d videos = %d clips x %d frames of the resident batch, dropout 0; oracle %.0f s'
                      % (nv, b * v, t, time.time() - t0),
+           'head_dtype': head_red, 'head_bf16_linears': list(m0_prefixes(head_pre)),
            'oracle_loss_fp32': round(float(ref['fp32'][1]), 6), 'oracle_loss_%s_emulating' % reduced: round(float(ref[reduced][1]), 6)}
     # Every device pass sees the parameters AND BatchNorm running statistics the oracle's `params` snapshot holds: the
     # train-mode loss pass updates running_mean / running_var even under no_grad, so the eval-mode embeddings of both modes
@@ -282,11 +295,13 @@ def parity_block(model, batch, nv, dev, reduced='bf16'):
     buffers = {k: b_.clone() for k, b_ in m0.named_buffers()}
     for mode in ('fp32', reduced):
         m0.compute_dtype = mode
+        m0.set_head_dtype(head_red if mode == reduced else 'fp32')
         m0.eval()
         with torch.no_grad():
             embs[mode] = m0(videos.reshape(b * v, t, *videos.shape[3:]), t, video_masks=masks.reshape(b * v, 1, t).to(dev))
     for mode in ('fp32', reduced):
         m0.compute_dtype = mode
+        m0.set_head_dtype(head_red if mode == reduced else 'fp32')
         m0.train()
         with torch.no_grad():
             losses[mode] = algo.compute_loss(m0, videos, seq_lens, steps, masks)['loss']
@@ -408,6 +423,16 @@ def main():
             raise SystemExit('bench.py: process group has %d ranks, WORLD_SIZE=%d' % (dist.get_world_size(), world))
     backend_seen = dist.get_backend() if dist.is_initialized() else None
     world_seen = dist.get_world_size() if dist.is_initialized() else 1
+    # which physical GPU every rank really sits on (device index + PCI address as the runtime reports them): a scaling run has
+    # to show N DISTINCT devices, not N ranks on one
+    prop = torch.cuda.get_device_properties(local)
+    me = {'rank': rank, 'device': local, 'name': prop.name,
+          'pci': '%04x:%02x:%02x' % (getattr(prop, 'pci_domain_id', 0), getattr(prop, 'pci_bus_id', 0), getattr(prop, 'pci_device_id', 0)),
+          'uuid': str(getattr(prop, 'uuid', ''))}
+    ranks_seen = [me]
+    if dist.is_initialized() and world_seen > 1:
+        ranks_seen = [None] * world_seen
+        dist.all_gather_object(ranks_seen, me)
 
     from video_rep_learning_amd import _lib
     from video_rep_learning_amd.utils import presets
@@ -556,10 +581,14 @@ def main():
                                    'batch 4/GPU = 8 clips/GPU/step, full train step (frozen backbone fwd, head fwd+bwd, SCL, '
                                    'grad all-reduce, clip+Adam), dropout 0.1', 'global_batch': 4 * world_seen, 'frames': 32,
                        'parallelism': 'dp%d' % world_seen, 'frames_per_sec': round(value * 32, 1), 'samples_per_sec': round(value / 2, 2),
-                       'step_tflops_algorithmic': round(value / world_seen * TFLOP_PER_CLIP, 1), 'last_loss': round(last_loss, 4),
+                       # algorithmic work (1.1925 TFLOP per clip = 9.54 TFLOP per step and GPU) over the measured time
+                       'tflops_algorithmic_per_gpu': round(value / world_seen * TFLOP_PER_CLIP, 1),
+                       'tflop_per_step_per_gpu': round(cfg.TRAIN.BATCH_SIZE * 2 * TFLOP_PER_CLIP, 2),
+                       'head_dtype': model.head_dtype, 'last_loss': round(last_loss, 4),
                        'gemm_cu_budget': gemm_cus or 'all',
                        # the process group as it actually ran (None / 1: no group): never the environment's word for it
-                       'backend': backend_seen, 'world_size_seen': world_seen,
+                       'backend': backend_seen, 'world_size_seen': world_seen, 'ranks': ranks_seen,
+                       'distinct_gpus': len({(r['pci'], r['uuid']) for r in ranks_seen}),
                        **({'comm': comm} if comm is not None else {})},
             'roofline': roof,
         }

@@ -95,6 +95,24 @@ def emulate_head(mode=None, prefixes=None):
     EMU.update(mode=mode, prefixes=None if prefixes is None else tuple(prefixes))
 
 
+class emulating:
+    """with emulating(prefixes): ...  -- bf16 emulation of the Linears under these name prefixes (empty / None: plain oracle)."""
+
+    def __init__(self, prefixes):
+        self.prefixes = tuple(prefixes) if prefixes else None
+
+    def __enter__(self):
+        self.saved = dict(EMU)
+        if self.prefixes:
+            emulate_head('bf16', self.prefixes)
+        else:
+            emulate_head(None)
+
+    def __exit__(self, *exc):
+        EMU.update(self.saved)
+        return False
+
+
 def bf16r(t):
     return t.to(torch.bfloat16).to(t.dtype)
 

@@ -116,6 +116,81 @@ def test_gathered_scl_loss_and_local_gradient_equal_concatenated_reference():
         assert e_loss < 1e-6 and e_grad < 1e-6
 
 
+class _OracleSclOp(torch.autograd.Function):
+    """Stands in for ops.scl_loss (a HIP kernel pair) with ITS contract on the CPU: per-row float vectors in, the loss over ALL rows
+    out, and in the backward only rows [row0, row0 + rows) of dE, multiplied by grad_scale."""
+
+    @staticmethod
+    def forward(ctx, e, st, ln, mk, t, neg, tau, var, row0, rows, grad_scale):
+        m, c = e.shape
+        b = m // (2 * t)
+        with torch.enable_grad():
+            leaf = e.detach().clone().requires_grad_(True)
+            loss = OS.scl_loss(leaf.reshape(b, 2, t, c), ln.reshape(b, 2, t)[:, :, 0].long(), st.reshape(b, 2, t).long(),
+                               mk.reshape(b * 2, 1, t), negative_type=neg, temperature=tau, label_variance=var)
+            (g,) = torch.autograd.grad(loss, leaf)
+        rows = m if rows is None else rows
+        d = torch.zeros_like(g)
+        d[row0:row0 + rows] = g[row0:row0 + rows] * grad_scale
+        ctx.save_for_backward(d)
+        return loss.detach()
+
+    @staticmethod
+    def backward(ctx, gout):
+        (d,) = ctx.saved_tensors
+        return (d * gout,) + (None,) * 10
+
+
+def _gather_mode_parameter_gradient(rank, world):
+    """The PRODUCT's SCL.compute_sequence_loss in gather mode (algos/scl.py: gather_rows + grad_scale = W) behind a small trainable
+    map, gradients averaged by the flat-buffer reducer as in training: the PARAMETER gradient must equal the single-process gradient
+    of the loss on the rank-concatenated batch.  (An Adam-update comparison cannot see a wrong scale -- Adam is scale invariant.)"""
+    from video_rep_learning_amd import ops
+    from video_rep_learning_amd.algos.scl import SCL
+    from video_rep_learning_amd.utils import presets
+    cfg = presets.make_cfg(num_frames=6, batch_size=2)
+    cfg.SCL.NEGATIVE_TYPE = 'batch_noself'
+    cfg.MI355X = {'GATHER_EMBEDDINGS': True}
+    algo = SCL(cfg)
+    assert algo.gather and du.collectives_active()
+    real = ops.scl_loss
+    ops.scl_loss = lambda e, st, ln, mk, t, neg, tau, var, row0=0, rows=None, grad_scale=1.0: \
+        _OracleSclOp.apply(e, st, ln, mk, t, neg, tau, var, row0, rows, grad_scale)
+    try:
+        g = torch.Generator().manual_seed(5)
+        b, t, cin, e = 2, 6, 5, 8
+        x = torch.randn(world, b, 2, t, cin, generator=g)
+        steps = torch.sort(torch.randint(0, 40, (world, b, 2, t), generator=g), dim=-1)[0]
+        lens = torch.full((world, b, 2), 40)
+        masks = torch.ones(world, b * 2, 1, t)
+        torch.manual_seed(7)
+        lin = torch.nn.Linear(cin, e, bias=False)
+        w0 = lin.weight.detach().clone()
+        flat = du.FlatBuffers(list(lin.parameters()))
+        red = du.GradReducer(flat, bucket_bytes=1 << 20)
+        flat.zero_grad()
+        emb = torch.nn.functional.normalize(lin(x[rank]), dim=-1)
+        loss = algo.compute_sequence_loss(emb, lens[rank], steps[rank], masks[rank])['loss']
+        loss.backward()
+        scale = red.finish()
+        got = (flat.flat_g * scale)[:w0.numel()].view_as(w0).clone()
+    finally:
+        ops.scl_loss = real
+    # single process, rank-concatenated batch
+    wr = w0.clone().requires_grad_(True)
+    embr = torch.nn.functional.normalize(x.reshape(world * b, 2, t, cin) @ wr.t(), dim=-1)
+    ref = OS.scl_loss(embr, lens.reshape(world * b, 2), steps.reshape(world * b, 2, t), masks.reshape(world * b * 2, 1, t),
+                      negative_type='batch_noself', temperature=cfg.SCL.SOFTMAX_TEMPERATURE, label_variance=cfg.SCL.LABEL_VARIENCE)
+    (gref,) = torch.autograd.grad(ref, wr)
+    return abs(loss.item() - ref.item()), ((got - gref).abs().max() / gref.abs().max()).item(), (got.norm() / gref.norm()).item()
+
+
+def test_gather_mode_parameter_gradient_equals_concatenated_reference():
+    for e_loss, e_grad, ratio in spawn(_gather_mode_parameter_gradient):
+        assert e_loss < 1e-6 and e_grad < 1e-5, (e_loss, e_grad, ratio)
+        assert abs(ratio - 1.0) < 1e-5          # a missing x W (or a double one) shows up here as 1 / W (or W)
+
+
 # ---------------------------------------------------------------------------------------------- C4
 def _loss_allreduce(rank, world):
     v = torch.tensor(float(rank + 1))

@@ -59,6 +59,9 @@ def oracle_cfgs(cfg):
 
 
 def make(seed=0, layer=None, edit=None, **kw):
+    # the gates of this file's and test_gpu_configs' reduced-precision cases are those of the fp32 head (pooling kernels on bf16
+    # taps, everything behind them in fp32); the bf16 head has its own tests with its own gates (head_dtype='bf16')
+    kw.setdefault('head_dtype', 'fp32')
     cfg = presets.make_cfg(**kw)
     if layer is not None:
         cfg.MODEL.BASE_MODEL.LAYER = layer
@@ -391,6 +394,68 @@ def bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, ref_emb_fp32=No
                          '(ReLU flips), the largest %.3e (%s), every other element <= %.3e (%s)' % (
                              loss.item(), out['loss_head'], flips, nelem, flip_rows, gate, worst_raw[0], worst_raw[1], worst[0], worst[1]))
     out['text'] += '; top-3 ' + ', '.join('%s %.2e (%d of %d elements above the gate)' % (n, e, k, tot) for e, k, tot, n in det)
+    return out
+
+
+def bf16_head_report(cfg, model, videos, seq_lens, steps, masks):
+    """MI355X.HEAD_DTYPE bf16 (row-chain kernels, csrc/head_chain.hip) on one batch, dropout 0: the oracle HEAD fed with the device's
+    own taps, once with the bf16 emulation of the Linears the device runs in bf16 (oracle/head.py emulating) and once plain.
+    Returns loss deviations and, per parameter tensor, the rel-L2 of the gradients: device vs emulating oracle, and emulating vs
+    plain oracle (= what the dtype itself costs: the device must sit inside that)."""
+    vit_cfg, head_cfg, scl_cfg = oracle_cfgs(cfg)
+    b, t = cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.NUM_FRAMES
+    x = videos.view(b * 2, t, *videos.shape[3:])
+    params = cpu_params(model)
+    model.set_head_dtype('bf16')
+    prefixes = model.head_bf16_linears()
+    assert prefixes, 'the bf16 head does not cover this configuration'
+    model.eval()
+    with torch.no_grad():
+        taps, cls_dev = model.features(x.to(DEV))
+    feat_dev = torch.cat([tt.float().cpu().view(b * 2 * t, taps.n_tokens, -1) for tt in taps.tensors], dim=2)
+    cls_c = cls_dev.float().cpu() if cls_dev is not None else None
+
+    def oracle(pre):
+        leaves = {k: params[k].clone().requires_grad_(True) for k in OM.trainable_names(params)}
+        p = dict(params)
+        p.update(leaves)
+        with OH.emulating(pre):
+            loss = OM.loss_from_backbone(feat_dev, cls_c, seq_lens, steps, masks, p, dict(vit_cfg, emulate=model.compute_dtype),
+                                         head_cfg, scl_cfg, training=True)
+            loss.backward()
+        return loss.detach(), {k: v.grad for k, v in leaves.items() if v.grad is not None}
+    l_emu, g_emu = oracle(tuple('embed.' + q for q in prefixes) + prefixes)
+    l_fp, g_fp = oracle(())
+    model.train()
+    model.zero_grad()
+    loss = get_algo(cfg).compute_loss(model, videos.to(DEV), seq_lens, steps, masks)['loss']
+    loss.backward()
+    got = {n: p.grad.detach().double().cpu() for n, p in model.named_parameters() if p.grad is not None}
+    names = sorted(n for n in g_emu if n in got)
+    # Scale of a tensor's error: its own gradient norm, but not less than 3e-3 of the whole gradient's.  Several parameters have an
+    # IDENTICALLY zero true gradient (a bias in front of a BatchNorm -- fc_layers.*.bias, ssl_projection.net.0.bias, and through
+    # them linear_V2d.bias, the last layer's fc2.bias and embedding_layer.bias; linear_K2d.bias under the softmax): what any
+    # implementation reports for them is rounding noise (2^-9 of the summed rows with bf16 operands), which a relative measure
+    # would turn into errors of 1e3.
+    gall = torch.cat([g_fp[n].double().flatten() for n in names]).norm().item()
+
+    def l2(a, bb, ref):
+        return ((a.double() - bb.double()).norm() / max(ref.double().norm().item(), 3e-3 * gall)).item()
+    dev = max((l2(got[n], g_emu[n], g_fp[n]), n) for n in names)
+    dt = max((l2(g_emu[n], g_fp[n], g_fp[n]), n) for n in names)
+    va = torch.cat([got[n].flatten() for n in names])
+    vb = torch.cat([g_emu[n].double().flatten() for n in names])
+    vc = torch.cat([g_fp[n].double().flatten() for n in names])
+    cos = torch.nn.functional.cosine_similarity(va, vb, dim=0).item()
+    cos_dt = torch.nn.functional.cosine_similarity(vb, vc, dim=0).item()
+    out = dict(loss_emu=relerr(loss, l_emu), loss_fp=relerr(loss, l_fp), grad_dev=dev[0], grad_dev_name=dev[1], grad_dtype=dt[0],
+               grad_dtype_name=dt[1], grad_cos=cos, grad_cos_dtype=cos_dt, grad_all=((va - vb).norm() / vb.norm()).item(),
+               grad_all_dtype=((vb - vc).norm() / vc.norm()).item(), prefixes=prefixes)
+    out['text'] = ('bf16 head (%s) on the DEVICE taps: loss %.6f, rel %.3e vs emulating oracle head, %.3e vs plain oracle head; head gradient '
+                   '(all tensors) rel-L2 %.3e / cosine %.5f vs emulating oracle -- the dtype itself (emulating vs plain oracle): %.3e / '
+                   '%.5f; worst tensor (error over max(own norm, 3e-3 of the whole gradient)): device vs emulating %.3e (%s), emulating '
+                   'vs plain %.3e (%s)' % (', '.join(prefixes), loss.item(), out['loss_emu'], out['loss_fp'], out['grad_all'], cos,
+                                           out['grad_all_dtype'], cos_dt, dev[0], dev[1], dt[0], dt[1]))
     return out
 
 

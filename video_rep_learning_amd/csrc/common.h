@@ -118,5 +118,32 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t offset, uint64
   return mix32(seed * 0x2545F4914F6CDD1Dull + offset + i) >= thresh;
 }
 
+// ---- two-stage reductions in ONE launch: the workgroup that arrives last finishes the job ----
+// Every workgroup stores its partial result, then calls last_arriver() (all threads); it returns true -- in every thread -- in exactly
+// one workgroup of the grid, the one whose arrival was the n-th, and that workgroup may then read all n partials with plain loads.
+// Nobody waits for anybody (no co-residency assumption).  Agent-scope release on the way in, acquire in the last arriver (per-XCD L2s
+// are not coherent and a CU's L1 is never refreshed by other CUs' stores: /opt/skills/guides/MI355X_MICROARCH.md, "Valid forms"); the
+// explicit s_waitcnt keeps the ticket from overtaking the write-back.  `ticket` is a zero-initialised device word that the last
+// arriver resets, so launches that share it must be ordered on one stream.
+__device__ __forceinline__ bool last_arriver(unsigned* ticket, unsigned n) {
+  __shared__ int s_last_arriver;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = t == n - 1u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_last_arriver = last;
+  }
+  __syncthreads();
+  return s_last_arriver != 0;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

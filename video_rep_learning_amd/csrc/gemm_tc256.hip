@@ -770,13 +770,11 @@ int launch_bm(const GemmTcArgs& a0, bool persistent, hipStream_t st) {
   }
   static const bool force_static = getenv("MVF_GEMM_STATIC") != nullptr;   // A/B measurements only
   a.sched = persistent && !force_static ? sched_slot() : nullptr;
-  static bool attr_set = false;
+  static uint64_t attr_set = 0;      // per device
   constexpr bool lncons = LN && (EPI == EPI_STORE || EPI == EPI_GELU);
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2, BMT, F16>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lncons ? LDS_MAX : LDS_BYTES);
-    attr_set = true;
-  }
+  if (mvf_ensure_lds(reinterpret_cast<const void*>(gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2, BMT, F16>),
+                     lncons ? LDS_MAX : LDS_BYTES, attr_set) != MVF_OK)
+    return MVF_ERR_UNSUPPORTED;      // the ln_part form: run_blocks falls back to the ln_stats_finalize launch
   int lds_bytes = LDS_BYTES;
   if (a.ln_part != nullptr) {   // in-kernel finalize: the partial sums of a tile's 256 rows behind the single (mean, rstd) slot
     if (!lncons || !persistent || a.ln_ns < 1 || LNP_OFF + a.ln_ns * 2048 > LDS_MAX || (a.M & 1) || (FP8 ? a.K >> 7 : a.K >> 6) < 4)

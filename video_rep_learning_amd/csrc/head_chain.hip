@@ -711,15 +711,6 @@ __global__ __launch_bounds__(256) void l2_warm_kernel(const u32x4_t* __restrict_
   if (acc == 0x9e3779b9u && sink != nullptr) *sink = acc;     // keeps the loads alive; practically never true
 }
 
-int ensure_lds(const void* fn, size_t bytes, uint64_t& done_mask) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return MVF_ERR_UNSUPPORTED;
-  if (dev < 64 && (done_mask >> dev) & 1) return MVF_OK;
-  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return MVF_ERR_UNSUPPORTED;
-  if (dev < 64) done_mask |= 1ull << dev;
-  return MVF_OK;
-}
-
 bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
@@ -782,7 +773,7 @@ extern "C" int mvf_enc_layer_fwd(const MvfEncFwd* s, hipStream_t st) {
   k.x1 = s->x1; k.mean1 = s->mean1; k.rstd1 = s->rstd1; k.x2 = s->x2; k.qkv = s->qkv; k.mean0 = s->mean0; k.rstd0 = s->rstd0;
   k.a = (bf16_t*)s->a; k.oT = (bf16_t*)s->oT; k.h1T = (bf16_t*)s->h1T; k.aT = (bf16_t*)s->aT; k.h0T = (bf16_t*)s->h0T;
   static uint64_t attr = 0;
-  if (ensure_lds(reinterpret_cast<const void*>(enc_fwd_kernel), 160 * 1024, attr) != MVF_OK) return MVF_ERR_UNSUPPORTED;
+  if (mvf_ensure_lds(reinterpret_cast<const void*>(enc_fwd_kernel), 160 * 1024, attr) != MVF_OK) return MVF_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(enc_fwd_kernel, dim3(ceil_div(s->M, TM)), dim3(NTH), L.total, st, k);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
@@ -809,7 +800,7 @@ extern "C" int mvf_enc_layer_bwd(const MvfEncBwd* s, hipStream_t st) {
   k.x1 = s->x1; k.mean1 = s->mean1; k.rstd1 = s->rstd1; k.g1 = s->ln1_g; k.dg1 = s->dln1_g; k.db1 = s->dln1_b;
   k.dx1_out = s->dx1_out; k.d_o = s->d_o;
   static uint64_t attr = 0;
-  if (ensure_lds(reinterpret_cast<const void*>(enc_bwd_kernel), 160 * 1024, attr) != MVF_OK) return MVF_ERR_UNSUPPORTED;
+  if (mvf_ensure_lds(reinterpret_cast<const void*>(enc_bwd_kernel), 160 * 1024, attr) != MVF_OK) return MVF_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(enc_bwd_kernel, dim3(ceil_div(s->M, TM)), dim3(NTH), L.total, st, k);
   MVF_LAUNCH_CHECK();
   return MVF_OK;

@@ -789,35 +789,53 @@ extern "C" int mvf_lstp_fused_bwd(const void* const* taps, int n_taps, int dtype
 // nq = 3 rows against a 384 x 2 304 matrix: through the 64-row MFMA GEMM these were six launches with K-long serial chains in a
 // handful of workgroups (49 us each for the two [nq | 1] x 2 304 -> 384 products); here one launch each way, a few microseconds,
 // plain fp32 FMAs in a fixed order (deterministic; no atomics).
-//   forward : workgroup = 64 columns x 4 slices of k (k = s, s + 4, ..): 96 independent coalesced loads per thread, LDS combine
-//   backward: workgroup = one row k of wk: threads stride over c; gwk's row updated in place, the nq dot products block-reduced
+//   forward : workgroup = 64 columns x 16 slices of k (k = s, s + 16, ..), 1 024 threads; q + b staged in LDS once; a thread's
+//             weight loads are issued in batches of 8 before the first is used (as a run-time loop of load -> fma the 96 loads per
+//             thread were 96 dependent round trips: 71 us for a 3 x 384 x 2 304 product), LDS combine in a fixed order
+//   backward: workgroup = one row k of wk: threads stride over c in batches of 4 columns (loads first); gwk's row updated in
+//             place, the nq dot products block-reduced
 namespace {
 
-__global__ __launch_bounds__(256) void static_query_fwd_kernel(const float* __restrict__ qs, const float* __restrict__ qb,
-                                                               const float* __restrict__ wk, long ldw, float* __restrict__ wq,
-                                                               int nq, int d, int C) {
-  __shared__ float red[4][MAXQ][64];
+constexpr int SQ_SL = 16;        // k slices per workgroup (forward)
+
+__global__ __launch_bounds__(1024) void static_query_fwd_kernel(const float* __restrict__ qs, const float* __restrict__ qb,
+                                                                const float* __restrict__ wk, long ldw, float* __restrict__ wq,
+                                                                int nq, int d, int C) {
+  extern __shared__ float sq_lds[];
+  float* aq = sq_lds;                          // [nq][d]: q + b
+  float* red = sq_lds + (size_t)nq * d;        // [SQ_SL][MAXQ][64]
+  for (int i = threadIdx.x; i < nq * d; i += 1024) aq[i] = qs[i] + qb[i % d];
+  __syncthreads();
   const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
+  const int cc = min(c, C - 1);
   float acc[MAXQ];
 #pragma unroll
   for (int j = 0; j < MAXQ; ++j) acc[j] = 0.f;
-  if (c < C) {
-    for (int k = sl; k < d; k += 4) {
-      const float w = wk[(long)k * ldw + c];
-      const float b = qb[k];
+  constexpr int U = 8;
+  for (int k0 = sl; k0 < d; k0 += SQ_SL * U) {
+    float w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + SQ_SL * u;
+      w[u] = k < d ? wk[(long)k * ldw + cc] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = min(k0 + SQ_SL * u, d - 1);
 #pragma unroll
       for (int j = 0; j < MAXQ; ++j)
-        if (j < nq) acc[j] = fmaf(qs[(long)j * d + k] + b, w, acc[j]);
+        if (j < nq) acc[j] = fmaf(aq[j * d + k], w[u], acc[j]);
     }
   }
 #pragma unroll
-  for (int j = 0; j < MAXQ; ++j) red[sl][j][cl] = acc[j];
+  for (int j = 0; j < MAXQ; ++j) red[(sl * MAXQ + j) * 64 + cl] = acc[j];
   __syncthreads();
-  if (sl == 0 && c < C) {
+  if (sl < nq && c < C) {       // wave j combines query j
+    float v = 0.f;
 #pragma unroll
-    for (int j = 0; j < MAXQ; ++j)
-      if (j < nq) wq[(long)j * C + c] = (red[0][j][cl] + red[1][j][cl]) + (red[2][j][cl] + red[3][j][cl]);
+    for (int s2 = 0; s2 < SQ_SL; ++s2) v += red[(s2 * MAXQ + sl) * 64 + cl];
+    wq[(long)sl * C + c] = v;
   }
 }
 
@@ -833,17 +851,30 @@ __global__ __launch_bounds__(256) void static_query_bwd_kernel(const float* __re
     a[j] = j < nq ? qs[(long)j * d + k] + qb[k] : 0.f;
     s[j] = 0.f;
   }
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float w = wk[(long)k * ldw + c];
-    float g = 0.f;
+  constexpr int U = 4;
+  for (int c0 = threadIdx.x; c0 < C; c0 += 256 * U) {
+    float w[U], go[U], v[U][MAXQ];
 #pragma unroll
-    for (int j = 0; j < MAXQ; ++j)
-      if (j < nq) {
-        const float v = dv[(long)j * ldv + c];
-        s[j] = fmaf(v, w, s[j]);
-        g = fmaf(a[j], v, g);
-      }
-    gwk[(long)k * ldgw + c] += g;
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + 256 * u;
+      const bool in = c < C;
+      w[u] = in ? wk[(long)k * ldw + c] : 0.f;
+      go[u] = in ? gwk[(long)k * ldgw + c] : 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXQ; ++j) v[u][j] = (in && j < nq) ? dv[(long)j * ldv + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + 256 * u;
+      float g = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXQ; ++j)
+        if (j < nq) {
+          s[j] = fmaf(v[u][j], w[u], s[j]);
+          g = fmaf(a[j], v[u][j], g);
+        }
+      if (c < C) gwk[(long)k * ldgw + c] = go[u] + g;
+    }
   }
 #pragma unroll
   for (int j = 0; j < MAXQ; ++j) {
@@ -869,7 +900,9 @@ __global__ __launch_bounds__(256) void static_query_bwd_kernel(const float* __re
 extern "C" int mvf_static_query_fwd(const float* qs, const float* qb, const float* wk, long ldw, float* wq, int nq, int d, int C,
                                     hipStream_t st) {
   MVF_CHECK_ARG(qs && qb && wk && wq && nq >= 1 && nq <= MAXQ && d >= 1 && C >= 1 && ldw >= C);
-  hipLaunchKernelGGL(static_query_fwd_kernel, dim3((C + 63) / 64), dim3(256), 0, st, qs, qb, wk, ldw, wq, nq, d, C);
+  const size_t lds = ((size_t)nq * d + (size_t)SQ_SL * MAXQ * 64) * 4;
+  if (lds > 64 * 1024) return MVF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(static_query_fwd_kernel, dim3((C + 63) / 64), dim3(1024), lds, st, qs, qb, wk, ldw, wq, nq, d, C);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

@@ -4,6 +4,19 @@
 #include <stdint.h>
 #include <algorithm>
 #include "../../include/mvf_hip.h"
+#include "common.h"
+
+// Raises a kernel's dynamic-LDS limit once per DEVICE (the attribute is per device: a process-wide "done" flag would leave a
+// second device at the 64 KB default); a failure is reported so that the caller can decline (MVF_ERR_UNSUPPORTED) instead of
+// launching into a generic error.  done_mask: one static uint64_t per kernel instantiation.
+static inline int mvf_ensure_lds(const void* fn, size_t bytes, uint64_t& done_mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return MVF_ERR_UNSUPPORTED;
+  if (dev < 64 && ((done_mask >> dev) & 1)) return MVF_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return MVF_ERR_UNSUPPORTED;
+  if (dev < 64) done_mask |= 1ull << dev;
+  return MVF_OK;
+}
 
 // ---- backbone ----
 // LayerNorm folded into the GEMMs (bf16 256x256 kernel only): producer side (epi 2) xb / stats, consumer side (epi 0, 1)

@@ -2,14 +2,22 @@
 // Reference: torch.nn.utils.clip_grad_norm_(model.parameters(), GRAD_CLIP) followed by
 // torch.optim.Adam(lr, betas=(0.9, 0.999), weight_decay) -- CARL_MVF/train.py:124-133,147-149,
 // utils/optimizer.py:60-66.  The head's 4.8 M trainable parameters live in one contiguous buffer (the DDP
-// gradient bucket is the matching flat gradient buffer), so the whole optimizer is three launches instead
+// gradient bucket is the matching flat gradient buffer), so the whole optimizer is two launches instead
 // of ~10 per parameter tensor.  HBM-bound: 4 streams read + 3 written per element, float4 accesses.
 #include "common.h"
 #include "mvf_hip_internal.h"
 
 namespace {
 
-__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
+// ticket of the one-launch norm (zero-initialised with the code object, reset by the last arriver; one optimizer step at a time)
+__device__ unsigned g_sqnorm_ticket;
+
+// norm_out[0] = sqrt(sum g^2 + extra_sq[0]): every workgroup stores its partial sum, the last one to arrive adds them in a fixed
+// order (reproducible) -- one launch instead of a partial and a final one.
+// norm_out[1] += 1 when that norm is not finite: the count of optimizer steps adam_kernel has SKIPPED (what
+// torch.cuda.amp.GradScaler.step does for the reference's fp16 path, train.py:127-133: no update, no step count)
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part,
+                                                     const float* __restrict__ extra_sq, float* __restrict__ norm_out) {
   __shared__ float red[4];
   float s = 0.f;
   const size_t n4 = n / 4;
@@ -23,18 +31,12 @@ __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __rest
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
-
-// norm_out[0] = sqrt(sum(part) + extra_sq[0]) ; fixed summation order -> reproducible
-// norm_out[1] += 1 when that norm is not finite: the count of optimizer steps adam_kernel has SKIPPED (what
-// torch.cuda.amp.GradScaler.step does for the reference's fp16 path, train.py:127-133: no update, no step count)
-__global__ void sqnorm_final_kernel(const float* __restrict__ part, int nparts, const float* __restrict__ extra_sq,
-                                    float* __restrict__ norm_out) {
-  __shared__ float red[4];
-  float s = 0.f;
-  for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  if (!last_arriver(&g_sqnorm_ticket, gridDim.x)) return;
+  float t = 0.f;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += part[i];
+  t = wave_sum(t);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
   __syncthreads();
   if (threadIdx.x == 0) {
     const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3] + (extra_sq ? extra_sq[0] : 0.f));
@@ -85,8 +87,7 @@ extern "C" int mvf_grad_norm(const float* g, size_t n, const float* extra_sq, fl
                              hipStream_t st) {
   MVF_CHECK_ARG(g && scratch && norm_out && n > 0 && ((uintptr_t)g & 15) == 0);
   const int nblk = (int)std::min<size_t>(1024, (n / 4 + 255) / 256 + 1);
-  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nblk), dim3(256), 0, st, g, n, scratch);
-  hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, st, scratch, nblk, extra_sq, norm_out);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(nblk), dim3(256), 0, st, g, n, scratch, extra_sq, norm_out);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

@@ -31,7 +31,25 @@ struct SclArgs {
   int single, noself;
   float inv_tau, inv_2var;
   int row0, rows;
+  float* loss;          // forward: the scalar, written by the workgroup that arrives last (common.h last_arriver)
 };
+
+// loss = sum(lossrow) / sum(mask), in the launch that produced lossrow: the last workgroup to arrive adds the rows in a fixed order
+__device__ unsigned g_scl_ticket;
+__device__ __forceinline__ void scl_finalize(const SclArgs& a) {
+  if (a.loss == nullptr || !last_arriver(&g_scl_ticket, gridDim.x)) return;
+  __shared__ float s1[16], s2[16];
+  float x = 0.f, y = 0.f;
+  for (int i = threadIdx.x; i < a.M; i += blockDim.x) { x += a.lossrow[i]; y += a.mask[i]; }
+  x = wave_sum(x); y = wave_sum(y);
+  if ((threadIdx.x & 63) == 0) { s1[threadIdx.x >> 6] = x; s2[threadIdx.x >> 6] = y; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float u = 0.f, v = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { u += s1[w]; v += s2[w]; }
+    a.loss[0] = u / v;
+  }
+}
 
 struct Meta { float step, len, mask; int vid, view; };
 
@@ -156,18 +174,7 @@ __global__ __launch_bounds__(256) void scl_stats_kernel(SclArgs a) {
   csum = sum16(csum);
   lsum = sum16(lsum);
   if (cl == 0 && gi < a.M) { a.S[gi] = Ssum; a.R[gi] = Rsum; a.c[gi] = csum; a.lossrow[gi] = lsum; }
-}
-
-// loss = sum(lossrow) / sum(mask)
-__global__ __launch_bounds__(256) void scl_finalize_kernel(const float* __restrict__ lossrow, const float* __restrict__ mask,
-                                                           int M, float* __restrict__ loss) {
-  __shared__ float s1[4], s2[4];
-  float a = 0.f, b = 0.f;
-  for (int i = threadIdx.x; i < M; i += 256) { a += lossrow[i]; b += mask[i]; }
-  a = wave_sum(a); b = wave_sum(b);
-  if ((threadIdx.x & 63) == 0) { s1[threadIdx.x >> 6] = a; s2[threadIdx.x >> 6] = b; }
-  __syncthreads();
-  if (threadIdx.x == 0) loss[0] = (s1[0] + s1[1] + s1[2] + s1[3]) / (s2[0] + s2[1] + s2[2] + s2[3]);
+  scl_finalize(a);
 }
 
 __global__ __launch_bounds__(256) void scl_grad_kernel(SclArgs a) {
@@ -269,11 +276,11 @@ __device__ __forceinline__ void load_chunk(const float* __restrict__ p, float (&
 }
 
 // per-column scalars of the four columns kb .. kb + 3 a lane handles in one step, fetched together at the top of the step (one
-// 16-byte load per array where all four are in range: kb is a multiple of 4 and the arrays are 16-byte aligned)
+// 16-byte load per array where all four are in range and the address is 16-byte aligned; element loads otherwise)
 struct Col4 { float step[4], len[4], mask[4]; };
 __device__ __forceinline__ void load4(const float* __restrict__ p, int kb, int M, float (&v)[4]) {
-  if (kb + 4 <= M) {
-    const float4 x = *reinterpret_cast<const float4*>(p + kb);
+  if (kb + 4 <= M && ((uintptr_t)(p + kb) & 15) == 0) {      // ('single' negatives with odd T, or row vectors sliced out of a
+    const float4 x = *reinterpret_cast<const float4*>(p + kb);   //  [3, M] tensor with M % 4 != 0, start columns off a 16-byte boundary)
     v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
   } else {
 #pragma unroll
@@ -406,6 +413,7 @@ __global__ __launch_bounds__(64 * NW) void scl_stats_mfma_kernel(SclArgs a) {
     a.c[r] = cs;
     a.lossrow[r] = ls;
   }
+  scl_finalize(a);
 }
 
 // LDS of the backward: NW wave-private column copies [16][E + 4] (re-used as the waves' partial gradients [16 rows][E + 4])
@@ -577,6 +585,7 @@ extern "C" int mvf_scl_fwd(const float* emb, const float* step, const float* len
   int rc = fill(a, emb, step, len, mask, S, R, c, lossrow, M, E, T, negative_flags, temperature, label_variance);
   if (rc != MVF_OK) return rc;
   MVF_CHECK_ARG(loss);
+  a.loss = loss;
   if (scl_mfma_ok(E, T)) {
     MVF_CHECK_ARG(((uintptr_t)emb % 16) == 0);
     constexpr int NW = 8;     // two waves per SIMD at up to 256 registers: room for the look-ahead copies (E = 256: without them)
@@ -590,7 +599,6 @@ extern "C" int mvf_scl_fwd(const float* emb, const float* step, const float* len
     set_lds(scl_stats_kernel, lds);
     hipLaunchKernelGGL(scl_stats_kernel, dim3(ceil_div(M, RB)), dim3(256), lds, st, a);
   }
-  hipLaunchKernelGGL(scl_finalize_kernel, dim3(1), dim3(256), 0, st, lossrow, mask, M, loss);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

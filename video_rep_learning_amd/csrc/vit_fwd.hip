@@ -430,6 +430,7 @@ extern "C" int mvf_gemm_tc_ln(int dtype, int epi, const void* A, int lda, const 
 // 256x256 kernel finalizes them itself; MVF_ERR_UNSUPPORTED where it cannot (ns > 12, odd M, K < 256, pinned 128x128 kernel)
 extern "C" int mvf_gemm_tc_ln_part(int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
                                    const float* part, int ns, float eps, const float* ln_c, int M, int N, int K, hipStream_t st) {
+  MVF_CHECK_ARG(part != nullptr && ns > 0 && ns * 64 == K);      // the partial sums cover the K = D columns in 64-column slices
   const MvfGemmLn ln = {nullptr, 0, nullptr, nullptr, ln_c, 0, nullptr, nullptr, 0, part, ns, eps};
   return mvf_gemm_tc_impl(MVF_BF16, epi, A, lda, W, ldw, bias, C, ldc, nullptr, 0, nullptr, 0, nullptr, nullptr, 1, M, N, K, st, 0, 0, &ln);
 }

@@ -269,7 +269,7 @@ int mvf_qkv_attn_impl(int dtype, const void* A, int lda, const void* W, const fl
     return MVF_ERR_UNSUPPORTED;
   // folded (ln_c): the rows' statistics as (mean, rstd) pairs OR as the producer's partial sums, never both; plain: neither
   MVF_CHECK_ARG(A && W && bias && out && A != out && (ln_c != nullptr) == ((ln_mr != nullptr) != (ln_part != nullptr)) &&
-                !(ln_mr != nullptr && ln_part != nullptr) && (ln_part == nullptr || (ln_ns >= 1 && ln_ns <= 64)));
+                !(ln_mr != nullptr && ln_part != nullptr) && (ln_part == nullptr || (ln_ns >= 1 && ln_ns <= 64 && ln_ns * 64 == D)));
   MVF_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0);
   QkvAttnArgs a;
   a.A = (const char*)A; a.W = (const char*)W; a.bias = bias; a.ln_c = ln_c; a.ln_mr = ln_mr; a.out = (char*)out;
@@ -277,12 +277,12 @@ int mvf_qkv_attn_impl(int dtype, const void* A, int lda, const void* W, const fl
   a.lda = lda; a.F = F; a.N = N; a.H = H; a.D = D;
   a.scale_log2 = LOG2E / 8.0f;
   const int grid = 8 * ((F + 7) / 8) * H;
-  static bool attr[2] = {false, false};
+  static uint64_t attr[2] = {0, 0};      // per device
   if (dtype == MVF_F16) {
-    if (!attr[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vit_qkv_attn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL); attr[1] = true; }
+    if (mvf_ensure_lds(reinterpret_cast<const void*>(vit_qkv_attn_kernel<true>), LDS_TOTAL, attr[1]) != MVF_OK) return MVF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(vit_qkv_attn_kernel<true>, dim3(grid), dim3(256), LDS_TOTAL, st, a);
   } else {
-    if (!attr[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vit_qkv_attn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL); attr[0] = true; }
+    if (mvf_ensure_lds(reinterpret_cast<const void*>(vit_qkv_attn_kernel<false>), LDS_TOTAL, attr[0]) != MVF_OK) return MVF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(vit_qkv_attn_kernel<false>, dim3(grid), dim3(256), LDS_TOTAL, st, a);
   }
   MVF_LAUNCH_CHECK();

@@ -174,6 +174,7 @@ class TransformerModel(nn.Module):
         self.compute_dtype = mi['COMPUTE_DTYPE'] if 'COMPUTE_DTYPE' in mi else \
             ('bf16' if ('USE_AMP' in cfg and cfg.USE_AMP) else 'fp32')
         self.frames_per_chunk = int(mi['FRAMES_PER_CHUNK']) if 'FRAMES_PER_CHUNK' in mi else 0
+        self.head_dtype = ops.head_dtype_of(cfg)
         if self.compute_dtype in ('fp16', 'f16') and getattr(self, 'split_layer', None) is not None:
             raise NotImplementedError('MI355X.COMPUTE_DTYPE fp16 covers the FROZEN backbone (MODEL.BASE_MODEL.LAYER >= depth); the '
                                       'trainable back-end blocks of a partially frozen one run in bf16 or fp32')
@@ -182,6 +183,24 @@ class TransformerModel(nn.Module):
         super().train(mode)
         self.backbone.eval()       # transformer.py:186: the frozen backbone always runs in eval()
         return self
+
+    def set_head_dtype(self, dt):
+        """'bf16': the trainable head's Linears on the bf16 matrix cores (row-chain kernels, csrc/head_chain.hip) where their
+        shapes allow it; 'fp32': the fp32 kernels.  (The frozen backbone's dtype is `compute_dtype`.)"""
+        assert dt in ('bf16', 'fp32'), dt
+        self.head_dtype = dt
+        for m in self.modules():
+            if m is not self and hasattr(m, 'head_dtype'):
+                m.head_dtype = dt
+
+    def head_bf16_linears(self):
+        """Name prefixes (relative to `embed.`) of the Linears that run with bf16 operands in the current mode -- what an
+        emulating checker has to round (oracle/head.py emulate_head)."""
+        pre = []
+        enc = getattr(self.embed, 'video_encoder', None)
+        if enc is not None and enc.chain_active():
+            pre.append('video_encoder.')
+        return tuple(pre)
 
     # ---- backbone pipeline: the frozen ViT runs on its own HIP stream, optionally one batch ahead of the head ----
     # The backbone has no trainable state, so the ViT forward of batch i+1 does not depend on the optimizer step of

@@ -164,10 +164,18 @@ class Encoder(nn.Module):
             layers.append({'params': plist, 'slots': slots if all(s_ is not None for s_ in slots) else None, 'owners': owners})
         return layers
 
+    def chain_active(self):
+        """True when forward() takes the row-chain kernels (bf16 operands) for this module's shapes."""
+        l0 = self.enc_layers[0] if len(self.enc_layers) > 0 else None
+        if self.head_dtype != 'bf16' or l0 is None:
+            return False
+        att = l0.self_att
+        return att.d_model == att.linear_Q2d.weight.shape[1] and att.d_out == att.d_model and \
+            ops.encoder_chain_supported(att.d_model, l0.feed_forward.fc1.weight.shape[0], att.H)
+
     def forward(self, x, src_mask=None, drop_state=None):
         l0 = self.enc_layers[0] if len(self.enc_layers) > 0 else None
-        if self.head_dtype == 'bf16' and l0 is not None and x.is_cuda and \
-                ops.encoder_chain_supported(x.shape[-1], l0.feed_forward.fc1.weight.shape[0], l0.self_att.H):
+        if x.is_cuda and self.chain_active():
             layers = self._chain_layers()
             if layers is not None:
                 drops = []

@@ -852,9 +852,9 @@ HEAD_CHAIN = os.environ.get('MVF_HEAD_CHAIN', '1') != '0'
 
 
 def head_dtype_of(cfg):
-    """'bf16' | 'fp32': the trainable head's GEMM operand dtype.  cfg.MI355X.HEAD_DTYPE when given; else bf16 whenever the
-    backbone runs in a reduced precision (bf16 / fp16 / fp8, or USE_AMP without a COMPUTE_DTYPE) -- the reference's head runs
-    under fp16 autocast then (train.py:113-117) -- and fp32 in parity mode (COMPUTE_DTYPE fp32)."""
+    """'bf16' | 'fp32': the trainable head's GEMM operand dtype.  cfg.MI355X.HEAD_DTYPE when given; else bf16 when the backbone
+    runs in bf16 or MX-fp8 (or USE_AMP without a COMPUTE_DTYPE) -- the reference's head runs under fp16 autocast then
+    (train.py:113-117) -- and fp32 in parity mode (COMPUTE_DTYPE fp32) and in fp16 mode."""
     mi = cfg.MI355X if 'MI355X' in cfg else {}
     if 'HEAD_DTYPE' in mi:
         hd = str(mi['HEAD_DTYPE']).lower()
@@ -862,7 +862,8 @@ def head_dtype_of(cfg):
             raise ValueError("MI355X.HEAD_DTYPE must be 'bf16' or 'fp32' (got %r)" % (mi['HEAD_DTYPE'],))
         return hd
     cd = mi['COMPUTE_DTYPE'] if 'COMPUTE_DTYPE' in mi else ('bf16' if ('USE_AMP' in cfg and cfg.USE_AMP) else 'fp32')
-    return 'fp32' if str(cd).lower() in ('fp32', 'f32') else 'bf16'
+    # fp16 is the accuracy mode (embeddings within 1e-3 of the fp32 oracle): its head stays on the fp32 kernels
+    return 'bf16' if str(cd).lower() in ('bf16', 'fp8', 'mxfp8') else 'fp32'
 
 
 class HeadPack:

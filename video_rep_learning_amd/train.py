@@ -155,9 +155,12 @@ def setup_distributed(args):
     else:
         rank = int(os.getenv('OMPI_COMM_WORLD_RANK')) * max(torch.cuda.device_count(), 1) + args.local_rank
     device = args.device or ('cuda' if torch.cuda.is_available() else 'cpu')
-    backend = args.backend or ('nccl' if device == 'cuda' else 'gloo')
-    if device == 'cuda':
-        torch.cuda.set_device(args.local_rank)
+    on_gpu = str(device).startswith('cuda')          # 'cuda', 'cuda:0', torch.device('cuda', 0)
+    backend = args.backend or ('nccl' if on_gpu else 'gloo')
+    if on_gpu:
+        # an explicit index ('cuda:3') names the device; the bare form takes this rank's local one
+        dev_index = torch.device(device).index
+        torch.cuda.set_device(args.local_rank if dev_index is None else dev_index)
     if world > 1 or 'MASTER_ADDR' in os.environ:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
@@ -282,7 +285,7 @@ def main(argv=None):
         t0 = time.time()
         train(cfg, train_loader, model, optimizer, scheduler, algo, cur_epoch, summary_writer, train_preproc, device,
               args.max_iters)
-        if device == 'cuda':
+        if str(device).startswith('cuda'):
             torch.cuda.synchronize()
         print('train done in (m): ' + str((time.time() - t0) / 60.0))
         if du.is_root_proc() and ((cur_epoch + 1) % cfg.CHECKPOINT.SAVE_INTERVAL == 0 or cur_epoch == cfg.TRAIN.MAX_EPOCHS - 1):

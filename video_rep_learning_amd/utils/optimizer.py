@@ -106,11 +106,20 @@ class FusedAdam(torch.optim.Optimizer):
         gscale = self.reducer.finish()
         self.step_count += 1
         norm = ops.grad_norm(self.flat.flat_g, self._scratch, self._norm)
+        # adjacent param groups with the same hyper-parameters (the reference's BN / non-BN groups always have: optimizer.py:44-52)
+        # are one launch
+        runs = []
         for g, (s, e) in zip(self.param_groups, self._ranges):
             if e <= s:
                 continue
+            hp = (float(g['lr']), g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'])
+            if runs and runs[-1][0] == hp and runs[-1][2] == s:
+                runs[-1][2] = e
+            else:
+                runs.append([hp, s, e])
+        for hp, s, e in runs:
             ops.adam_step(self.flat.flat_p[s:e], self.flat.flat_g[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e],
-                          float(g['lr']), g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], self.step_count,
+                          hp[0], hp[1], hp[2], hp[3], hp[4], self.step_count,
                           clip=float(max_norm or 0.0), norm=norm, gscale=gscale, zero_grad=True)
         self.flat.dirty = False           # every element of the gradient buffer lies in one of the ranges (asserted above)
         for m in self.packed_owners:

@@ -49,7 +49,7 @@ def penn_mvf():
 
 
 def make_cfg(base=None, network=None, num_frames=None, batch_size=None, image_size=None, compute_dtype=None,
-             dropout=None, **embedder_overrides):
+             dropout=None, head_dtype=None, **embedder_overrides):
     """Defaults <- preset (shallow update, like a YAML) <- the equivalents of `--opts` overrides."""
     cfg = get_cfg()
     cfg.update(penn_mvf() if base is None else base)
@@ -67,6 +67,10 @@ def make_cfg(base=None, network=None, num_frames=None, batch_size=None, image_si
         cfg.MODEL.EMBEDDER_MODEL[k] = v
     if compute_dtype is not None:
         cfg.MI355X = {'COMPUTE_DTYPE': compute_dtype}
+    if head_dtype is not None:          # 'bf16' | 'fp32': the trainable head's GEMM operand dtype (default: ops.head_dtype_of)
+        mi = dict(cfg.MI355X) if 'MI355X' in cfg else {}
+        mi['HEAD_DTYPE'] = head_dtype
+        cfg.MI355X = mi
     cfg.EVAL.BATCH_SIZE = cfg.TRAIN.BATCH_SIZE
     cfg.EVAL.NUM_FRAMES = cfg.TRAIN.NUM_FRAMES
     return cfg

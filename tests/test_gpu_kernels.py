@@ -1040,7 +1040,9 @@ def test_batch_norm_fwd_bwd(training, relu):
 # scalar kernels so both implementations are checked on the same cases
 @pytest.mark.parametrize('scalar', [0, 1])
 @pytest.mark.parametrize('B,S,H,Dm,pad', [(3, 96, 8, 256, 7), (2, 24, 4, 32, 0), (2, 200, 8, 256, 33), (1, 130, 2, 128, 1),
-                                           (8, 192, 8, 256, 40), (2, 70, 4, 64, 69)])
+                                           (8, 192, 8, 256, 40), (2, 70, 4, 64, 69),
+                                           # fg99_mvf.yml / pouring_mvf.yml as shipped: 240 frames x 6 / 3 entities, dk = 32
+                                           (2, 1440, 8, 256, 100), (1, 720, 8, 256, 0)])
 def test_temporal_attention_fwd_bwd(B, S, H, Dm, pad, scalar):
     g = gen(24)
     qkv = torch.randn(B * S, 3 * Dm, generator=g)

@@ -108,7 +108,8 @@ SMALL = dict(network='TIMM-vit_small_patch16_224.dino', num_frames=8, batch_size
 @pytest.mark.parametrize('variant', ['base', 'avg_enc_nst6', 'max_none', 'lin', 'dynamic', 'disjoint', 'batch_neg', 'fg99',
                                      'long64', 'dinov2', 'fwb', 'partial', 'partial_dinov2', 'late_cls',
                                      'late_spatial_max', 'late_spatial_avg', 'late_cls_partial', 'ln_keys', 'cls_res',
-                                     'warmup', 'cls_res_partial', 'ln_keys_dynamic', 'ln_keys_dynamic_partial'])
+                                     'warmup', 'cls_res_partial', 'ln_keys_dynamic', 'ln_keys_dynamic_partial', 'fg99_t240',
+                                     'pouring_t240'])
 def test_small_model_loss_and_grads(variant):
     kw = dict(SMALL)
     if variant == 'avg_enc_nst6':
@@ -125,6 +126,11 @@ def test_small_model_loss_and_grads(variant):
         kw.update(SMART_TOKENS=6, CAPACITY_SCALAR=6, EMBEDDING_SIZE=256, SMART_FEATS='9,10,11', SMART_FINAL='avg')
     elif variant == 'long64':    # 64-frame clips: temporal sequence S = 3 x 64 = 192
         kw.update(num_frames=64, batch_size=1)
+    elif variant == 'fg99_t240':     # configs_mvf/fg99_mvf.yml AS SHIPPED: 240-frame clips x 6 entities = a temporal sequence of 1 440
+        kw.update(SMART_TOKENS=6, CAPACITY_SCALAR=6, EMBEDDING_SIZE=256, SMART_FEATS='9,10,11', SMART_FINAL='avg', num_frames=240,
+                  batch_size=1)
+    elif variant == 'pouring_t240':  # configs_mvf/pouring_mvf.yml as shipped: 240 frames, one tap, S = 720
+        kw.update(SMART_FEATS='11', num_frames=240, batch_size=1)
     elif variant == 'fwb':       # fixed-width baseline: entities are slices of a linear map of the CLS embedding
         kw.update(FIXED_WIDTH_BASELINE=True)
     elif variant == 'dinov2':    # LayerScale + patch 14 backbone (DINOv2 family)
@@ -214,6 +220,17 @@ def test_small_model_loss_and_grads(variant):
     e = relerr(loss, lref)
     assert e <= 1e-3, 'loss %.3e (%.6f vs %.6f)' % (e, loss.item(), lref.item())
     rels = grad_errors(leaves)
+    if variant.endswith('_t240'):
+        # 2 880 / 1 440 head rows x up to 1 536 ReLU channels: hundreds of pre-activations sit within rounding distance of the kink
+        # (341 / 2e-5 at fg99's size) and the greedy per-unit search below would re-run the fp64 oracle a hundred times.  The flipped
+        # units move single gradient elements by their row's share (measured 9.4e-3 of the tensor's scale, tensors in front of a
+        # ReLU only); everything else is checked through the direction of the whole gradient.
+        names = [n for n, p in model.named_parameters() if n in leaves and leaves[n].grad is not None and p.grad is not None]
+        va = torch.cat([dict(model.named_parameters())[n].grad.double().cpu().flatten() for n in names])
+        vb = torch.cat([leaves[n].grad.flatten() for n in names])
+        cos = torch.nn.functional.cosine_similarity(va, vb, dim=0).item()
+        assert rels[0][0] <= 3e-2 and cos >= 0.99999, (rels[:4], cos)
+        return
     if rels[0][0] > 5e-3 and near:
         # some pre-activations sit within 2e-5 of the ReLU kink (oracle/head.py KINK): the fp32 device run may be on the
         # other side there.  The device gradient must then equal the oracle's for one assignment of those units

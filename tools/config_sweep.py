@@ -24,15 +24,25 @@ CASES = {
         network='TIMM-vit_base_patch16_224.dino', num_frames=32, batch_size=4, SMART_TOKENS=6, CAPACITY_SCALAR=6,
         EMBEDDING_SIZE=256, SMART_FEATS='9,10,11', SMART_FINAL='avg'),
     'cfg4 T=64, B=4 (S = 192)': dict(network='TIMM-vit_base_patch16_224.dino', num_frames=64, batch_size=4),
-    'cfg5 DINOv2 ViT-L/14 @336, T=32, B=2, bf16': dict(
-        network='TIMM-vit_large_patch14_dinov2.lvd142m', num_frames=32, batch_size=2, image_size=336, SMART_FEATS='7,15,23',
+    'cfg5 DINOv2 ViT-L/14 @336, T=32, B=4, bf16': dict(
+        network='TIMM-vit_large_patch14_dinov2.lvd142m', num_frames=32, batch_size=4, image_size=336, SMART_FEATS='7,15,23',
         LAYER=24),
-    'cfg5 DINOv2 ViT-L/14 @336, T=32, B=2, fp8 (MX-fp8 GEMM operands)': dict(
-        network='TIMM-vit_large_patch14_dinov2.lvd142m', num_frames=32, batch_size=2, image_size=336, SMART_FEATS='7,15,23',
+    'cfg5 DINOv2 ViT-L/14 @336, T=32, B=4, fp8 (MX-fp8 GEMM operands)': dict(
+        network='TIMM-vit_large_patch14_dinov2.lvd142m', num_frames=32, batch_size=4, image_size=336, SMART_FEATS='7,15,23',
         LAYER=24, DTYPE='fp8'),
+    'fg99_mvf.yml exactly as shipped: ViT-B/8, T=240, B=1, 6 entities (S = 1440), cap 6, E=256': dict(
+        network='TIMM-vit_base_patch8_224.dino', num_frames=240, batch_size=1, SMART_TOKENS=6, CAPACITY_SCALAR=6,
+        EMBEDDING_SIZE=256, SMART_FEATS='9,10,11', SMART_FINAL='avg'),
+    'pouring_mvf.yml exactly as shipped: ViT-B/8, T=240, B=1, one tap (S = 720)': dict(
+        network='TIMM-vit_base_patch8_224.dino', num_frames=240, batch_size=1, SMART_FEATS='11'),
     'cfg2 ViT-B/16, T=32, B=4, fp8 (NOT the headline dtype of this config: configs[1] is quoted at bf16)': dict(
         network='TIMM-vit_base_patch16_224.dino', num_frames=32, batch_size=4, DTYPE='fp8'),
 }
+
+
+# algorithmic TFLOP per step and GPU; None: not tabulated there
+TFLOP_PER_STEP = {'cfg1 penn': 2.635, 'penn_mvf.yml exactly': 26.35, 'cfg2 ViT-B/16, T=32, B=4': 9.540, 'cfg3': 9.582, 'cfg4': 19.082,
+                  'cfg5': 99.875}
 
 
 def main():
@@ -76,7 +86,14 @@ def main():
             loss = step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        print('%-75s %8.2f ms/step  %7.1f clips/s/GPU  loss %.4f' % (name, dt * 1e3, 2 * b / dt, loss.item()), flush=True)
+        tf = [v for k, v in TFLOP_PER_STEP.items() if name.startswith(k)]
+        peak = 5000.0 if cfg.MI355X['COMPUTE_DTYPE'] == 'fp8' else 2500.0
+        extra = ''
+        if tf and 'LAYER=10' not in name:
+            extra = '  %6.0f TFLOP/s algorithmic = %.3f of the dense %s peak' % (tf[0] / dt, tf[0] / dt / peak,
+                                                                            'fp8' if peak > 3000 else 'bf16')
+        print('%-92s %8.2f ms/step  %7.1f clips/s/GPU  head %s  loss %.4f%s' % (name, dt * 1e3, 2 * b / dt, model.head_dtype, loss.item(), extra),
+              flush=True)
         del model, wrapped, opt, videos
         torch.cuda.empty_cache()
 

@@ -10,7 +10,7 @@ rm -rf $out/st_$tag
 python3 - <<P
 import csv
 rows=list(csv.DictReader(open('$out/${tag}_kernel_stats.csv')))
-steps=[int(r['Calls']) for r in rows if 'scl_finalize' in r['Name']][0]
+steps=[int(r['Calls']) for r in rows if 'scl_grad' in r['Name']][0]
 tot=0; nl=0
 for r in rows:
     n=r['Name']

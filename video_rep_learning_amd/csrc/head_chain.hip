@@ -68,6 +68,15 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 // pre(m, n) -> Aux: whatever the epilogue needs from global memory for out[m][n .. n+3] (bias, residual); requested BEFORE the k loop
 // of the chunk, so its latency hides under the loop.  (Loads inside the epilogue serialise behind the epilogue's own global stores
 // -- the compiler must assume they alias -- one L2 round trip per tile: 70 of the 108 us of a layer launch.)
+// weight-fragment load: non-temporal.  A layer launch streams 1.5 MB of weights through each of its 24 workgroups; with the default
+// policy that stream displaces the operands of the backbone GEMMs running beside the head in the same L2s (measured with
+// tools/stretch_parts.py: the encoder's launches cost the pipelined step 0.55 ms with plain loads, 0.37 ms with these).
+// MVF_NT_OFF (build flag): plain loads, for A/B measurements.
+#ifdef MVF_NT_OFF
+#define WLOAD(p) (*reinterpret_cast<const bf16x8_t*>(p))
+#else
+#define WLOAD(p) __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(p))
+#endif
 struct NoAux {};
 struct Aux1 { float4 b; };            // bias
 struct Aux2 { float4 b, r; };         // bias + residual row
@@ -113,7 +122,7 @@ __device__ __forceinline__ void chain_gemm(const bf16_t* A, int lda, int K, cons
     for (int p = 0; p < PF; ++p) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        bq[p][nt] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)(nt * nsteps + p) * 512);
+        bq[p][nt] = WLOAD(wp + (size_t)(nt * nsteps + p) * 512);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -132,7 +141,7 @@ __device__ __forceinline__ void chain_gemm(const bf16_t* A, int lda, int K, cons
         }
         const int sr = min(st + PF, nsteps - 1);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bq[p][nt] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)(nt * nsteps + sr) * 512);
+        for (int nt = 0; nt < NT; ++nt) bq[p][nt] = WLOAD(wp + (size_t)(nt * nsteps + sr) * 512);
         a0 = a0n; a1 = a1n;
         __builtin_amdgcn_sched_barrier(0);
       }

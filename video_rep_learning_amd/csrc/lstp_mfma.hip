@@ -103,12 +103,19 @@ __global__ __launch_bounds__(512) void lstp_mfma_kernel(LstpMfmaArgs a) {
   // 63.6 / 58.3: not what the tile time is made of, and it needs the registers the vector fragments now live in.
   constexpr bool VREG = KS <= 9;      // the vector fragments live in registers (read from their LDS image once); C = 3072: in LDS
   u32x4_t stage_a[KS];
+// the taps are read once per pass (231 MB): non-temporal, so that the stream does not push the backbone GEMMs' operands (running
+  // beside this kernel on the other streams) out of the L2 -- MVF_NT_OFF (build flag): plain loads, for A/B measurements
+#ifdef MVF_NT_OFF
+#define LSTP_TAP_LOAD(p) (*(p))
+#else
+#define LSTP_TAP_LOAD(p) __builtin_nontemporal_load(p)
+#endif
 #define LSTP_LOAD_TILE(TILE, SET)                                                                              \
   _Pragma("unroll") for (int k = 0; k < KT; ++k) {                                                            \
     /* rows past the frame repeat its last token (their weights are 0) */                                     \
     const unsigned voff = (unsigned)(min((TILE) * 16 + rowk[k], N - 1) * DD + colk[k] * 8) * 2u;              \
     _Pragma("unroll") for (int tp = 0; tp < NT; ++tp)                                                         \
-      SET[tp * KT + k] = *reinterpret_cast<const u32x4_t*>(tapb[tp] + voff);                                  \
+      SET[tp * KT + k] = LSTP_TAP_LOAD(reinterpret_cast<const u32x4_t*>(tapb[tp] + voff));                    \
   }
 #define LSTP_STORE_TILE(SET)                                                                                   \
   _Pragma("unroll") for (int k = 0; k < KT; ++k)                                                              \

@@ -9,6 +9,14 @@
 
 namespace {
 
+#ifdef MVF_NT_OFF      // build flag, A/B measurements only
+#define NT_LD(p) (*(p))
+#define NT_ST(p, v) (*(p) = (v))
+#else
+#define NT_LD(p) __builtin_nontemporal_load(p)
+#define NT_ST(p, v) __builtin_nontemporal_store((v), (p))
+#endif
+
 // ticket of the one-launch norm (zero-initialised with the code object, reset by the last arriver; one optimizer step at a time)
 __device__ unsigned g_sqnorm_ticket;
 
@@ -68,14 +76,17 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   }
   const float step = lr / bc1;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    // moments and gradients are touched once per step: non-temporal, so that 134 MB of optimizer traffic do not push the backbone
+    // GEMMs' operands (the next batch's forward runs beside this kernel) out of the L2; the parameters are re-read by the next
+    // forward's kernels and keep the default policy
     const float pi = p[i];
-    const float gi = g[i] * coef + wd * pi;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
+    const float gi = NT_LD(g + i) * coef + wd * pi;
+    const float mi = b1 * NT_LD(m + i) + (1.f - b1) * gi;
+    const float vi = b2 * NT_LD(v + i) + (1.f - b2) * gi * gi;
+    NT_ST(m + i, mi);
+    NT_ST(v + i, vi);
     p[i] = pi - step * mi / (sqrtf(vi) / bc2_sqrt + eps);
-    if (zero_grad) g[i] = 0.f;      // the next step's zero_grad() in the pass that has the gradient in registers anyway
+    if (zero_grad) NT_ST(g + i, 0.f);      // the next step's zero_grad() in the pass that has the gradient in registers anyway
   }
 }
 
@@ -86,7 +97,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 extern "C" int mvf_grad_norm(const float* g, size_t n, const float* extra_sq, float* scratch, float* norm_out,
                              hipStream_t st) {
   MVF_CHECK_ARG(g && scratch && norm_out && n > 0 && ((uintptr_t)g & 15) == 0);
-  const int nblk = (int)std::min<size_t>(1024, (n / 4 + 255) / 256 + 1);
+  // 256 workgroups at most: every arrival is one atomic on the same ticket word (~11 ns each, serialised)
+  const int nblk = (int)std::min<size_t>(256, (n / 4 + 255) / 256 + 1);
   hipLaunchKernelGGL(sqnorm_kernel, dim3(nblk), dim3(256), 0, st, g, n, scratch, extra_sq, norm_out);
   MVF_LAUNCH_CHECK();
   return MVF_OK;

@@ -449,6 +449,80 @@ typedef struct MvfEncBwd {
 } MvfEncBwd;
 int mvf_enc_layer_bwd(const MvfEncBwd* args_host, hipStream_t stream);
 
+/* One Linear of the head with everything row-wise around it (csrc/head_rowlin.hip): the per-entity FC stack and video_emb
+ * (models/mvformer.py:70-86,150-160), entity reduction + embedding layer (mvformer.py:181-199), projection head + normalisation
+ * (models/resnet_c2d.py:112-126, models/transformer.py:226-228).  Rows m < M, 32 per workgroup.
+ *   Y [M, N] = epi( pro(X) W^T + bias ),   pro, in this order (each optional):
+ *      entity reduction (g_ntok > 0): X is [B, g_ntok, g_T, Cin], row m = (b, t) takes token 0 (g_mode 0) / the mean (1) / the max (2,
+ *        arg-max written to g_arg [M, Cin]) over the g_ntok entities;
+ *      BatchNorm1d (+ReLU) with the GIVEN batch statistics bn_mean / bn_var (biased), affine bn_g / bn_b;
+ *      entity one-hot: oh_ntok columns appended, column j = [(m / oh_div) % oh_ntok == j];
+ *      dropout drop_in (element index m * (Cin + oh_ntok) + c);
+ *   epi: + table[(m % tab_mod), :] (sin/cos positions), dropout drop_out (index m * N + n), or l2norm != 0: Y / max(||Y||, l2_eps)
+ *      (norms to nrm [M]).
+ *   st_part != NULL: the batch statistics of Y for the BatchNorm that FOLLOWS: st_mean / st_var [N] (biased variance; Chan's merge
+ *      of per-workgroup mean / M2, fixed order, finished by the workgroup that arrives last) and, if given, the running
+ *      statistics updated like nn.BatchNorm1d (momentum, unbiased variance).  st_part: 2 * ceil(M / 32) * N floats of scratch.
+ *   xT (may be NULL): FM image of pro(X)^T [Cin + oh_ntok (padded to 64), Mp] for mvf_head_dw.
+ * w16: mvf_head_pack_weights image.  Cin % 4 == 0, N % 128 == 0, N <= 512, Cin + oh_ntok <= 512 (else MVF_ERR_UNSUPPORTED). */
+typedef struct MvfRowLinFwd {
+  int M, Cin, N, Mp;
+  const float* X;
+  long ldx;
+  int g_ntok, g_T, g_mode;
+  int* g_arg;
+  const float *bn_mean, *bn_var, *bn_g, *bn_b;
+  float bn_eps;
+  int bn_relu;
+  int oh_ntok, oh_div;
+  MvfDrop drop_in, drop_out;
+  const void* w16;
+  const float* bias;
+  const float* table;
+  int tab_mod;
+  int l2norm;
+  float l2_eps;
+  float *Y, *nrm;
+  void* xT;
+  float *st_part, *st_mean, *st_var, *st_rmean, *st_rvar;
+  float st_momentum;
+} MvfRowLinFwd;
+int mvf_rowlin_fwd(const MvfRowLinFwd* args_host, hipStream_t stream);
+
+/* The same stage backwards.  dY [M, N]: the gradient w.r.t. Y -- or, nb_Y != NULL, the masked gradient dZ w.r.t. the OUTPUT of the
+ * BatchNorm (+ReLU) that consumes Y, which is turned into dY here: dY = g rstd (dZ - s1 / count - xhat s2 / count) with that
+ * BatchNorm's statistics (nb_mean, nb_var), affine weight nb_g, input nb_Y (= the forward's Y) and column sums nb_s1 / nb_s2.
+ * Then epi' (dropout mask drop_out | l2norm backward with the forward's normalised output l2_y and norms l2_nrm), g -> gT (FM
+ * transpose for mvf_head_dw, may be NULL), dXp = g W (w16t image), pro' (dropout mask drop_in, one-hot columns dropped, ReLU mask of
+ * the forward's BatchNorm recomputed from X and its statistics) -> dX [M, Cin] (row stride lddx; scattered back to
+ * [B, g_ntok, g_T, Cin] through the entity reduction).  With bn_mean != NULL what is written to dX is dZ, the masked gradient w.r.t.
+ * that BatchNorm's output, and st_part != NULL also gives its column sums s1 = sum dZ, s2 = sum dZ xhat (2 * ceil(M / 32) * Cin
+ * floats of scratch; the last workgroup to arrive adds them) and ACCUMULATES dgamma += s2, dbeta += s1 (may be NULL). */
+typedef struct MvfRowLinBwd {
+  int M, Cin, N, Mp;
+  const float* dY;
+  const float *nb_Y, *nb_mean, *nb_var, *nb_g, *nb_s1, *nb_s2;
+  float nb_eps, nb_count;
+  MvfDrop drop_out, drop_in;
+  int l2norm;
+  const float *l2_y, *l2_nrm;
+  float l2_eps;
+  const void* w16t;
+  void* gT;
+  int oh_ntok;
+  const float* X;
+  long ldx;
+  const float *bn_mean, *bn_var, *bn_g, *bn_b;
+  float bn_eps;
+  int bn_relu;
+  float *st_part, *s1, *s2, *dgamma, *dbeta;
+  int g_ntok, g_T, g_mode;
+  const int* g_arg;
+  float* dX;
+  long lddx;
+} MvfRowLinBwd;
+int mvf_rowlin_bwd(const MvfRowLinBwd* args_host, hipStream_t stream);
+
 /* Weight / bias gradients of n <= 16 Linears in one launch: dw[n][k] (+)= sum_m gT[n][m] xT[k][m], db[n] (+)= sum_m gT[n][m]
  * (db may be NULL); gT, xT: FM images of [N, Mp] and [K, Mp] (the transposed saves above; Mp % 128 == 0).  accumulate != 0: add into dw / db (the flat
  * gradient buffer).  Fixed summation order (no atomics). */

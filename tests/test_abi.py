@@ -69,7 +69,12 @@ def test_struct_layouts_match_the_header(tmp_path):
               ('MvfPackEntry', ['w', 'ld', 'N', 'K', 'w16', 'w16t']),
               ('MvfEncFwd', ['M', 'Mp', 'ln_eps', 'o', 'wo', 'ln1_b', 'drop_attn', 'drop_ffn', 'x1', 'a', 'x2', 'aT', 'wqkv', 'qkv', 'h0T']),
               ('MvfEncBwd', ['M', 'Mp', 'dqkv', 'dqkvT', 'dres', 'dx_out', 'drop_ffn', 'drop_attn', 'w2T', 'a', 'dln1_b', 'goT', 'd_o']),
-              ('MvfDwProblem', ['gT', 'xT', 'dw', 'lddw', 'db', 'N', 'K'])]
+              ('MvfDwProblem', ['gT', 'xT', 'dw', 'lddw', 'db', 'N', 'K']),
+              ('MvfRowLinFwd', ['M', 'Mp', 'X', 'ldx', 'g_ntok', 'g_arg', 'bn_mean', 'bn_eps', 'bn_relu', 'oh_ntok', 'drop_in', 'drop_out', 'w16',
+                                'table', 'tab_mod', 'l2norm', 'l2_eps', 'Y', 'xT', 'st_part', 'st_rvar', 'st_momentum']),
+              ('MvfRowLinBwd', ['M', 'Mp', 'dY', 'nb_Y', 'nb_s2', 'nb_eps', 'nb_count', 'drop_out', 'drop_in', 'l2norm', 'l2_y', 'l2_eps',
+                                'w16t', 'gT', 'oh_ntok', 'X', 'ldx', 'bn_mean', 'bn_eps', 'bn_relu', 'st_part', 'dbeta', 'g_ntok', 'g_arg',
+                                'dX', 'lddx'])]
     body = ''.join('printf("%s %%zu", sizeof(%s));%sprintf("\\n");\n' % (
         st, st, ''.join('printf(" %%zu", offsetof(%s, %s));' % (st, f) for f in fs)) for st, fs in probes)
     src = tmp_path / 'layout.c'

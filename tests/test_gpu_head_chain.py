@@ -147,3 +147,172 @@ def test_encoder_chain_gradient_slots_equal_plain_gradients():
         got = q._mvf_grad.detach().cpu()
         e = rel_l2(got, g0[n])
         assert e < (1e-5 if 'norm' in n else 1e-6), (n, e)      # LayerNorm gradients are atomically summed
+
+
+# ------------------------------------------------------------------------------------------------ the whole head on row chains
+def _small_head_model(dropout, seed=3, **kw):
+    import test_gpu_model as T
+    base = dict(T.SMALL)
+    base.update(dropout=dropout, head_dtype='bf16', **kw)
+    return T, T.make(seed, **base)
+
+
+def _loss_and_grads(T, cfg, model, videos, seq_lens, steps, masks):
+    from video_rep_learning_amd.algos import get_algo
+    model.train()
+    model.zero_grad()
+    model.embed.drop_state = ops.DropoutState(7)
+    loss = get_algo(cfg).compute_loss(model, videos.to(DEV), seq_lens, steps, masks)['loss']
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss.detach().cpu(), {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}, \
+        {k: v.detach().cpu().clone() for k, v in model.named_buffers() if 'running_' in k and not k.startswith('backbone')}
+
+
+@pytest.mark.parametrize('variant', ['penn', 'avg_nst6', 'max_none'])
+@pytest.mark.parametrize('p', [0.0, 0.1])
+def test_head_row_chains_vs_fp32_kernels_same_dropout_masks(variant, p):
+    """FC stack + video_emb, temporal encoder, entity reduction + embedding layer, projection head + normalisation: the bf16 row
+    chains against the one-kernel-per-operator fp32 head of the same model on the same taps, same dropout masks, same BatchNorm
+    running statistics before the step."""
+    kw = {'avg_nst6': dict(SMART_FINAL='avg', SMART_TOKENS=6), 'max_none': dict(SMART_FINAL='max', SMART_ONE_HOT='none')}.get(variant, {})
+    T, (cfg, model) = _small_head_model(p, **kw)
+    videos, seq_lens, steps, masks = T.batch(cfg, 5, pad=3)
+    assert model.head_dtype == 'bf16'
+    pre = model.head_bf16_linears()
+    assert {'video_encoder.', 'video_emb', 'embedding_layer', 'net.0'} <= set(pre), pre
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    l1, g1, r1 = _loss_and_grads(T, cfg, model, videos, seq_lens, steps, masks)
+    model.load_state_dict(state)
+    model.set_head_dtype('fp32')
+    assert model.head_bf16_linears() == ()
+    l0, g0, r0 = _loss_and_grads(T, cfg, model, videos, seq_lens, steps, masks)
+    e_l = abs(l1.item() - l0.item()) / abs(l0.item())
+    gall = torch.cat([g0[n].double().flatten() for n in g0]).norm().item()
+    # (identically-zero gradients -- biases in front of a BatchNorm -- are rounding noise in both: scale floor as in bf16_head_report)
+    worst = max(((g1[n].double() - g0[n].double()).norm().item() / max(g0[n].double().norm().item(), 1e-2 * gall), n) for n in g0)
+    va, vb = torch.cat([g1[n].double().flatten() for n in g0]), torch.cat([g0[n].double().flatten() for n in g0])
+    cos = torch.nn.functional.cosine_similarity(va, vb, dim=0).item()
+    e_run = max(rel_l2(r1[k], r0[k]) for k in r0)
+    record_parity('head row chains (%s, dropout %.1f) vs fp32 kernels: loss rel %.2e, gradient cosine %.5f, worst tensor %.2e (%s), BN running '
+                  'statistics %.2e' % (variant, p, e_l, cos, worst[0], worst[1], e_run))
+    assert set(g1) == set(g0)
+    # a gross-error net (the stage-by-stage tests below are the sharp ones): at 96 rows and an SCL temperature of 0.1 the bf16
+    # operands move the loss by up to 1e-2 and single small gradient tensors (the pooling queries) by tens of percent
+    assert e_l < 2e-2 and cos > 0.985 and worst[0] < 0.6 and e_run < 1e-2, (e_l, cos, worst, e_run)
+
+
+def test_head_row_chains_vs_emulating_oracle_small():
+    T, (cfg, model) = _small_head_model(0.0, seed=9)
+    videos, seq_lens, steps, masks = T.batch(cfg, 6, pad=2)
+    model.compute_dtype = 'fp32'
+    r = T.bf16_head_report(cfg, model, videos, seq_lens, steps, masks)
+    record_parity('small model, %s' % r['text'])
+    assert r['loss_emu'] < 5e-3 and r['loss_fp'] < 5e-3 and r['grad_cos'] > 0.995, r
+    assert r['grad_all'] < r['grad_all_dtype'] + 5e-3 and r['grad_dev'] < r['grad_dtype'] + 2e-2, r
+
+
+# ------------------------------------------------------------------------------------------------ row-linear stages, one by one
+class _EmuLin(torch.autograd.Function):
+    """fp64 Linear with both operands rounded to bf16 in forward, input gradient and weight gradient (oracle/head.py _EmuLinear)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xr, wr = OH.bf16r(x), OH.bf16r(w)
+        ctx.save_for_backward(xr, wr)
+        return xr @ wr.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, wr = ctx.saved_tensors
+        g = OH.bf16r(dy)
+        return g @ wr, g.t() @ xr, g.sum(0)
+
+
+def _mask(shape, p, seed, off):
+    """the device's dropout mask x 1 / (1 - p) for a dense [rows, cols] tensor (mvf_dropout_add on ones)"""
+    ones = torch.ones(shape, device=DEV)
+    out = torch.empty_like(ones)
+    _lib.call('mvf_dropout_add', ones.data_ptr(), None, out.data_ptr(), ones.numel(), p, seed, off, torch.cuda.current_stream().cuda_stream)
+    return out.double().cpu()
+
+
+@pytest.mark.parametrize('rows,T,ntok', [(96, 8, 3), (75, 25, 3)])
+def test_rowlin_trunk_stages_vs_reference(rows, T, ntok):
+    """one-hot -> dropout -> Linear(387, 512) -> BatchNorm (batch statistics, running update) -> ReLU -> dropout -> Linear(512, 256)
+    + table -> dropout: two mvf_rowlin launches each way against an fp64 composition that rounds the GEMM operands to bf16."""
+    g = torch.Generator().manual_seed(21)
+    C, H1, H2 = 384, 512, 256
+    x = torch.randn(rows, C, generator=g)
+    w1, b1 = torch.randn(H1, C + ntok, generator=g) * 0.05, torch.randn(H1, generator=g) * 0.1
+    gam, bet = 1 + 0.1 * torch.randn(H1, generator=g), 0.1 * torch.randn(H1, generator=g)
+    w2, b2 = torch.randn(H2, H1, generator=g) * 0.05, torch.randn(H2, generator=g) * 0.1
+    table = torch.randn(T, H2, generator=g)
+    go = torch.randn(rows, H2, generator=g)
+    rm0, rv0 = torch.randn(H1, generator=g) * 0.1, 1 + 0.1 * torch.rand(H1, generator=g)
+    p, seed = 0.1, 11
+    d1, d2, d3 = (p, seed, 0), (p, seed, 100000), (p, seed, 200000)
+    P = [t.to(DEV).requires_grad_(True) for t in (w1, b1, gam, bet, w2, b2)]
+    rm, rv = rm0.to(DEV), rv0.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    stages = [ops.RowLinStage(0, 1, onehot=(ntok, T), drop_in=d1, bn_out=(rm, rv, 0.1)),
+              ops.RowLinStage(4, 5, bn_in=(2, 3, 1e-5, True), drop_in=d2, table=(table.to(DEV), T), drop_out=d3)]
+    y = ops.rowlin_chain(xd, stages, P, True, ops.HeadPack())
+    (y * go.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    # reference
+    R = [t.double().requires_grad_(True) for t in (w1, b1, gam, bet, w2, b2)]
+    xr = x.double().requires_grad_(True)
+    ent = (torch.arange(rows) // T) % ntok
+    xin = torch.cat([xr, torch.nn.functional.one_hot(ent, ntok).double()], 1) * _mask((rows, C + ntok), *d1)
+    y1 = _EmuLin.apply(xin, R[0], R[1])
+    mean, var = y1.mean(0), ((y1 - y1.mean(0)) ** 2).mean(0)
+    h = torch.relu((y1 - mean) / torch.sqrt(var + 1e-5) * R[2] + R[3]) * _mask((rows, H1), *d2)
+    y2 = (_EmuLin.apply(h, R[4], R[5]) + table.double()[torch.arange(rows) % T]) * _mask((rows, H2), *d3)
+    (y2 * go.double()).sum().backward()
+    errs = {'y': rel_l2(y, y2), 'dx': rel_l2(xd.grad, xr.grad)}
+    for n, a, b in zip(('w1', 'b1', 'gamma', 'beta', 'w2', 'b2'), P, R):
+        errs['d' + n] = (a.grad.double().cpu() - b.grad).norm().item() / max(b.grad.norm().item(), 1e-3 * R[4].grad.norm().item())
+    errs['running_mean'] = rel_l2(rm, 0.9 * rm0.double() + 0.1 * mean.detach())
+    errs['running_var'] = rel_l2(rv, 0.9 * rv0.double() + 0.1 * var.detach() * rows / (rows - 1))
+    record_parity('rowlin trunk stages rows %d: %s' % (rows, ', '.join('%s %.1e' % kv for kv in errs.items())))
+    # db1 (the bias in front of the BatchNorm) has an identically zero true gradient: rounding noise on both sides, not compared
+    assert all(v < 1e-4 for k, v in errs.items() if k != 'db1'), errs
+
+
+@pytest.mark.parametrize('mode', ['one', 'avg', 'max'])
+def test_rowlin_tail_stages_vs_reference(mode):
+    """entity reduction -> Linear(256, 128);  Linear(128, 128) -> BatchNorm -> ReLU -> Linear(128, 128) -> L2 normalise"""
+    g = torch.Generator().manual_seed(22)
+    B, ntok, T, D, E = 3, 3, 25, 256, 128
+    x = torch.randn(B * ntok * T, D, generator=g)
+    we, be = torch.randn(E, D, generator=g) * 0.05, torch.randn(E, generator=g) * 0.1
+    w0, b0 = torch.randn(E, E, generator=g) * 0.1, torch.randn(E, generator=g) * 0.1
+    gam, bet = 1 + 0.1 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g)
+    w1, b1 = torch.randn(E, E, generator=g) * 0.1, torch.randn(E, generator=g) * 0.1
+    go = torch.randn(B * T, E, generator=g)
+    P = [t.to(DEV).requires_grad_(True) for t in (we, be, w0, b0, gam, bet, w1, b1)]
+    xd = x.to(DEV).requires_grad_(True)
+    rm, rv = torch.zeros(E, device=DEV), torch.ones(E, device=DEV)
+    e = ops.rowlin_chain(xd, [ops.RowLinStage(0, 1, gather=(ntok, T, {'one': 0, 'avg': 1, 'max': 2}[mode]))], P[:2], True, ops.HeadPack())
+    y = ops.rowlin_chain(e, [ops.RowLinStage(0, 1, bn_out=(rm, rv, 0.1)), ops.RowLinStage(4, 5, bn_in=(2, 3, 1e-5, True), l2norm=1e-12)],
+                         P[2:], True, ops.HeadPack())
+    (y * go.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    R = [t.double().requires_grad_(True) for t in (we, be, w0, b0, gam, bet, w1, b1)]
+    xr = x.double().requires_grad_(True)
+    x4 = xr.view(B, ntok, T, D)
+    red = x4[:, 0] if mode == 'one' else (x4.mean(1) if mode == 'avg' else x4.max(1)[0])
+    er = _EmuLin.apply(red.reshape(B * T, D), R[0], R[1])
+    y0 = _EmuLin.apply(er, R[2], R[3])
+    mean, var = y0.mean(0), ((y0 - y0.mean(0)) ** 2).mean(0)
+    h = torch.relu((y0 - mean) / torch.sqrt(var + 1e-5) * R[4] + R[5])
+    y1 = _EmuLin.apply(h, R[6], R[7])
+    yr = y1 / y1.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    (yr * go.double()).sum().backward()
+    errs = {'y': rel_l2(y, yr), 'dx': rel_l2(xd.grad, xr.grad)}
+    for n, a, b in zip(('we', 'be', 'w0', 'b0', 'gamma', 'beta', 'w1', 'b1'), P, R):
+        errs['d' + n] = (a.grad.double().cpu() - b.grad).norm().item() / max(b.grad.norm().item(), 1e-3 * R[6].grad.norm().item())
+    record_parity('rowlin tail stages (%s): %s' % (mode, ', '.join('%s %.1e' % kv for kv in errs.items())))
+    # dbe, db0: biases in front of the BatchNorm (through a Linear): identically zero true gradients, rounding noise on both sides
+    assert all(v < 1e-4 for k, v in errs.items() if k not in ('dbe', 'db0')), errs

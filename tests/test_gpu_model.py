@@ -437,8 +437,8 @@ def bf16_head_report(cfg, model, videos, seq_lens, steps, masks):
         p = dict(params)
         p.update(leaves)
         with OH.emulating(pre):
-            loss = OM.loss_from_backbone(feat_dev, cls_c, seq_lens, steps, masks, p, dict(vit_cfg, emulate=model.compute_dtype),
-                                         head_cfg, scl_cfg, training=True)
+            vc = vit_cfg if model.compute_dtype in ('fp32', 'f32') else dict(vit_cfg, emulate=model.compute_dtype)
+            loss = OM.loss_from_backbone(feat_dev, cls_c, seq_lens, steps, masks, p, vc, head_cfg, scl_cfg, training=True)
             loss.backward()
         return loss.detach(), {k: v.grad for k, v in leaves.items() if v.grad is not None}
     l_emu, g_emu = oracle(tuple('embed.' + q for q in prefixes) + prefixes)

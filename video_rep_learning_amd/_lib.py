@@ -104,6 +104,8 @@ SIGNATURES = {
     'mvf_enc_layer_fwd': 'pp',
     'mvf_enc_layer_bwd': 'pp',
     'mvf_head_dw': 'piiip',
+    'mvf_rowlin_fwd': 'pp',
+    'mvf_rowlin_bwd': 'pp',
     'mvf_scl_rows': 'ppppiip',
     'mvf_scl_fwd': 'pppppppppiiiiffp',
     'mvf_scl_bwd': 'pppppppppiiiiiiffp',
@@ -160,6 +162,25 @@ class MvfEncBwd(ctypes.Structure):
                 + [('drop_ffn', MvfDrop), ('drop_attn', MvfDrop)]
                 + [(n, _P) for n in ('w2T', 'w1T', 'woT', 'a', 'x1', 'mean1', 'rstd1', 'ln1_g', 'dln1_g', 'dln1_b', 'g2T', 'duT',
                                      'goT', 'dx1_out', 'd_o')])
+
+
+class MvfRowLinFwd(ctypes.Structure):
+    """Mirror of `struct MvfRowLinFwd`."""
+    _fields_ = [('M', _I), ('Cin', _I), ('N', _I), ('Mp', _I), ('X', _P), ('ldx', _L), ('g_ntok', _I), ('g_T', _I), ('g_mode', _I),
+                ('g_arg', _P), ('bn_mean', _P), ('bn_var', _P), ('bn_g', _P), ('bn_b', _P), ('bn_eps', _F), ('bn_relu', _I),
+                ('oh_ntok', _I), ('oh_div', _I), ('drop_in', MvfDrop), ('drop_out', MvfDrop), ('w16', _P), ('bias', _P), ('table', _P),
+                ('tab_mod', _I), ('l2norm', _I), ('l2_eps', _F), ('Y', _P), ('nrm', _P), ('xT', _P), ('st_part', _P), ('st_mean', _P),
+                ('st_var', _P), ('st_rmean', _P), ('st_rvar', _P), ('st_momentum', _F)]
+
+
+class MvfRowLinBwd(ctypes.Structure):
+    """Mirror of `struct MvfRowLinBwd`."""
+    _fields_ = [('M', _I), ('Cin', _I), ('N', _I), ('Mp', _I), ('dY', _P), ('nb_Y', _P), ('nb_mean', _P), ('nb_var', _P), ('nb_g', _P),
+                ('nb_s1', _P), ('nb_s2', _P), ('nb_eps', _F), ('nb_count', _F), ('drop_out', MvfDrop), ('drop_in', MvfDrop),
+                ('l2norm', _I), ('l2_y', _P), ('l2_nrm', _P), ('l2_eps', _F), ('w16t', _P), ('gT', _P), ('oh_ntok', _I), ('X', _P),
+                ('ldx', _L), ('bn_mean', _P), ('bn_var', _P), ('bn_g', _P), ('bn_b', _P), ('bn_eps', _F), ('bn_relu', _I),
+                ('st_part', _P), ('s1', _P), ('s2', _P), ('dgamma', _P), ('dbeta', _P), ('g_ntok', _I), ('g_T', _I), ('g_mode', _I),
+                ('g_arg', _P), ('dX', _P), ('lddx', _L)]
 
 
 class MvfDwProblem(ctypes.Structure):

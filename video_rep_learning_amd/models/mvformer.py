@@ -230,9 +230,72 @@ class MultiEntityTransformerEmbModel(nn.Module):
         self.in_backbone_warmup = 'BACKBONE_WARMUP' in self.cfg.TRAIN
         self.drop_state = ops.DropoutState(seed=int(cfg.RNG_SEED) if 'RNG_SEED' in cfg else 0)
         self.sync_group = None
+        # 'bf16': FC stack / video_emb and entity reduction / embedding layer on the row-chain kernels (csrc/head_rowlin.hip)
+        self.head_dtype = ops.head_dtype_of(cfg)
+        self._pack_trunk, self._pack_tail = ops.HeadPack(), ops.HeadPack()
 
     def set_warmup_status(self, new_status):
         self.in_backbone_warmup = new_status
+
+    def invalidate_packed(self):
+        """The fused optimizer updated the parameters through raw pointers: the bf16 operand copies are stale."""
+        self._pack_trunk.invalidate()
+        self._pack_tail.invalidate()
+
+    def _bn_chainable(self, bn):
+        from ..utils.distributed import collectives_active
+        return bn.momentum is not None and bn.affine and bn.track_running_stats and \
+            not (isinstance(bn, nn.SyncBatchNorm) and collectives_active())
+
+    def trunk_chain_active(self, c_in=None):
+        """The FC stack + video_emb run as row chains (one launch per Linear each way): bf16 head, the one-hot (if any) appended
+        before the stack, every width within the kernels' panels, BatchNorm statistics local to the rank."""
+        if self.head_dtype != 'bf16' or isinstance(self.fc_layers, nn.Identity) or self.one_hot_pos == 'enc':
+            return False
+        mods = list(self.fc_layers)
+        lins = [mods[i + 1] for i in range(0, len(mods), 4)] + [self.video_emb]
+        if not all(self._bn_chainable(mods[i + 2]) for i in range(0, len(mods), 4)):
+            return False
+        k0 = lins[0].weight.shape[1] - ((self.nst + self.nsdt) if self.one_hot_pos == 'pool' else 0)
+        if c_in is not None and c_in != k0:
+            return False
+        return k0 % 4 == 0 and all(ops.rowlin_supported(l.weight.shape[1] if j else k0, l.weight.shape[0]) and l.weight.shape[1] <= 512
+                                   for j, l in enumerate(lins))
+
+    def tail_chain_active(self):
+        return self.head_dtype == 'bf16' and self.smart_final in ('one', 'avg', 'max') and \
+            ops.rowlin_supported(self.embedding_layer.weight.shape[1], self.embedding_layer.weight.shape[0])
+
+    def _trunk_chain(self, x, ntok, T):
+        """[rows (clip, entity, frame), c] -> [rows, hidden]: one-hot, (dropout, Linear, BatchNorm, ReLU) x n, video_emb + sin/cos
+        table, dropout -- mvformer.py:144-160 -- as n + 1 launches."""
+        mods = list(self.fc_layers)
+        nblk = len(mods) // 4
+        params, stages, eval_stats = [], [], []
+        prev = None
+        for i in range(nblk):
+            drop, lin, bn = mods[4 * i], mods[4 * i + 1], mods[4 * i + 2]
+            if bn.training != self.training:
+                bn.train(self.training)
+            iw = len(params)
+            params += [lin.weight, lin.bias]
+            kin = lin.weight.shape[1]
+            st = ops.RowLinStage(iw, iw + 1, bn_in=prev, onehot=(ntok, T) if (i == 0 and self.one_hot_pos == 'pool') else None,
+                                 drop_in=ops.drop_args(drop.p, self.training, self.drop_state, x.shape[0] * kin),
+                                 bn_out=(bn.running_mean, bn.running_var, bn.momentum))
+            eval_stats.append(None if i == 0 else (mods[4 * i - 2].running_mean, mods[4 * i - 2].running_var))
+            stages.append(st)
+            ig = len(params)
+            params += [bn.weight, bn.bias]
+            prev = (ig, ig + 1, bn.eps, True)
+        iw = len(params)
+        params += [self.video_emb.weight, self.video_emb.bias]
+        last_bn = mods[4 * nblk - 2]
+        stages.append(ops.RowLinStage(iw, iw + 1, bn_in=prev, table=(self.video_pos_enc.table(T, x.device), T),
+                                      drop_out=ops.drop_args(self.video_pos_enc.dout_p, self.training, self.drop_state,
+                                                             x.shape[0] * self.video_emb.weight.shape[0])))
+        eval_stats.append((last_bn.running_mean, last_bn.running_var))
+        return ops.rowlin_chain(x, stages, params, self.training, self._pack_trunk, tuple(eval_stats))
 
     def _bn(self, x, bn, relu):
         return ops.batch_norm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training and bn.training,
@@ -247,20 +310,23 @@ class MultiEntityTransformerEmbModel(nn.Module):
         x = self.pooling(taps, cls_emb)                                    # [Bc, ntok, T, c]
         ntok = x.shape[1]
         x = x.reshape(Bc * ntok * T, -1)
-        if self.one_hot_pos == 'pool':
-            x = ops.concat_onehot(x, ntok, T)
-        if not isinstance(self.fc_layers, nn.Identity):
-            mods = list(self.fc_layers)
-            for i in range(0, len(mods), 4):
-                x = ops.dropout_add(x, None, mods[i].p, self.training, self.drop_state)
-                bn = mods[i + 2]
-                if bn.training != self.training:
-                    bn.train(self.training)
-                x = self._bn(ops.linear(x, mods[i + 1].weight, mods[i + 1].bias), bn, relu=True)
-        # video_emb GEMM with the sin/cos table added in its epilogue (row r -> frame r % T), then PE dropout
-        x = ops.linear(x, self.video_emb.weight, self.video_emb.bias, table=self.video_pos_enc.table(T, x.device),
-                       tab_div=1, tab_mod=T)
-        x = ops.dropout_add(x, None, self.video_pos_enc.dout_p, self.training, self.drop_state)
+        if x.is_cuda and self.trunk_chain_active(x.shape[1]):
+            x = self._trunk_chain(x, ntok, T)
+        else:
+            if self.one_hot_pos == 'pool':
+                x = ops.concat_onehot(x, ntok, T)
+            if not isinstance(self.fc_layers, nn.Identity):
+                mods = list(self.fc_layers)
+                for i in range(0, len(mods), 4):
+                    x = ops.dropout_add(x, None, mods[i].p, self.training, self.drop_state)
+                    bn = mods[i + 2]
+                    if bn.training != self.training:
+                        bn.train(self.training)
+                    x = self._bn(ops.linear(x, mods[i + 1].weight, mods[i + 1].bias), bn, relu=True)
+            # video_emb GEMM with the sin/cos table added in its epilogue (row r -> frame r % T), then PE dropout
+            x = ops.linear(x, self.video_emb.weight, self.video_emb.bias, table=self.video_pos_enc.table(T, x.device),
+                           tab_div=1, tab_mod=T)
+            x = ops.dropout_add(x, None, self.video_pos_enc.dout_p, self.training, self.drop_state)
         if self.one_hot_pos == 'enc':
             x = ops.concat_onehot(x, ntok, T)
         x = x.view(Bc, ntok * T, -1)
@@ -269,6 +335,12 @@ class MultiEntityTransformerEmbModel(nn.Module):
             # [Bc, T] mask periodically instead (key (j, t) -> column t), so nothing is copied
             vm = video_masks.reshape(Bc, 1, T) if video_masks is not None else None
             x = self.video_encoder(x, src_mask=vm, drop_state=self.drop_state)
+        if x.is_cuda and self.tail_chain_active():
+            # entity reduction + embedding layer (mvformer.py:181-199) as one launch each way
+            st = ops.RowLinStage(0, 1, gather=(ntok, T, {'one': 0, 'avg': 1, 'max': 2}[self.smart_final]))
+            x = ops.rowlin_chain(x.reshape(Bc * ntok * T, -1), [st], [self.embedding_layer.weight, self.embedding_layer.bias],
+                                 self.training, self._pack_tail)
+            return x.view(Bc, T, self.embedding_size)
         x = x.view(Bc, ntok, T, -1)
         if self.smart_final == 'lin':
             x = x.permute(0, 2, 1, 3).reshape(Bc * T, -1)

@@ -13,11 +13,34 @@ class MLPHead(nn.Module):
         self.net = nn.Sequential(nn.Linear(self.embedding_size, hidden), nn.BatchNorm1d(hidden), nn.ReLU(True),
                                  nn.Linear(hidden, self.embedding_size))
         self.sync_group = None
+        # 'bf16': both Linears as row chains (csrc/head_rowlin.hip), BatchNorm and the caller's normalisation inside them
+        self.head_dtype = ops.head_dtype_of(cfg)
+        self._pack = ops.HeadPack()
 
-    def forward(self, x):
+    def invalidate_packed(self):
+        self._pack.invalidate()
+
+    def chain_active(self):
+        from ..utils.distributed import collectives_active
+        lin0, bn, _, lin1 = self.net
+        return self.head_dtype == 'bf16' and bn.momentum is not None and bn.affine and bn.track_running_stats and \
+            not (isinstance(bn, nn.SyncBatchNorm) and collectives_active()) and \
+            ops.rowlin_supported(lin0.weight.shape[1], lin0.weight.shape[0]) and ops.rowlin_supported(lin1.weight.shape[1], lin1.weight.shape[0])
+
+    def forward(self, x, normalize=False):
+        """normalize: also F.normalize(dim = -1) the result (models/transformer.py:228 does that to this head's output)."""
         b, l, c = x.shape
         lin0, bn, _, lin1 = self.net
+        if x.is_cuda and self.chain_active():
+            if bn.training != self.training:
+                bn.train(self.training)
+            stages = [ops.RowLinStage(0, 1, bn_out=(bn.running_mean, bn.running_var, bn.momentum)),
+                      ops.RowLinStage(4, 5, bn_in=(2, 3, bn.eps, True), l2norm=1e-12 if normalize else None)]
+            y = ops.rowlin_chain(x.reshape(-1, c), stages, [lin0.weight, lin0.bias, bn.weight, bn.bias, lin1.weight, lin1.bias], self.training,
+                                 self._pack, (None, (bn.running_mean, bn.running_var)))
+            return y.view(b, l, -1)
         h = ops.linear(x.reshape(-1, c), lin0.weight, lin0.bias)
         h = ops.batch_norm(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, momentum=bn.momentum,
                            eps=bn.eps, relu=True, sync=isinstance(bn, nn.SyncBatchNorm), group=self.sync_group)
-        return ops.linear(h, lin1.weight, lin1.bias).view(b, l, c)
+        y = ops.linear(h, lin1.weight, lin1.bias).view(b, l, c)
+        return ops.l2_normalize(y) if normalize else y

@@ -200,6 +200,12 @@ class TransformerModel(nn.Module):
         enc = getattr(self.embed, 'video_encoder', None)
         if enc is not None and enc.chain_active():
             pre.append('video_encoder.')
+        if getattr(self.embed, 'trunk_chain_active', None) is not None and self.embed.trunk_chain_active():
+            pre += ['fc_layers.%d' % (4 * i + 1) for i in range(len(list(self.embed.fc_layers)) // 4)] + ['video_emb']
+        if getattr(self.embed, 'tail_chain_active', None) is not None and self.embed.tail_chain_active():
+            pre.append('embedding_layer')
+        if self.cfg.MODEL.PROJECTION and self.ssl_projection.chain_active():
+            pre += ['ssl_projection.net.0', 'ssl_projection.net.3', 'net.0', 'net.3']
         return tuple(pre)
 
     # ---- backbone pipeline: the frozen ViT runs on its own HIP stream, optionally one batch ahead of the head ----
@@ -273,7 +279,7 @@ class TransformerModel(nn.Module):
             pooled = ops.token_pool(feats.tensors, feats.n_clips * feats.n_frames, feats.n_tokens, self.embed.flatten_method)
             x = self.embed(pooled, feats.n_clips, feats.n_frames, video_masks=video_masks)
         if self.cfg.MODEL.PROJECTION and project:
-            x = ops.l2_normalize(self.ssl_projection(x))
+            x = self.ssl_projection(x, normalize=True)
         elif self.cfg.MODEL.L2_NORMALIZE:
             x = ops.l2_normalize(x)
         if self.use_cls_res:

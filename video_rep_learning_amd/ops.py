@@ -1078,6 +1078,172 @@ class _EncoderChain(torch.autograd.Function):
         return (dx_out if ctx.needs_input_grad[0] else None, None, None, None, None, None, None, None, None, None) + tuple(grads)
 
 
+class RowLinStage:
+    """One Linear of a row chain (csrc/head_rowlin.hip mvf_rowlin_fwd) and what surrounds it.  Parameter fields hold INDICES into
+    the chain's flat parameter list (None: absent)."""
+
+    def __init__(self, w, b, gather=None, bn_in=None, onehot=None, drop_in=None, table=None, drop_out=None, l2norm=None, bn_out=None):
+        self.w, self.b = w, b
+        self.gather = gather          # (ntok, T, mode 0 | 1 | 2): entity reduction of the input rows
+        self.bn_in = bn_in            # the BatchNorm (+ReLU) in front: (index of gamma, index of beta, eps, relu); its statistics come
+        #                               from the previous stage's bn_out (training) or from `running` (eval)
+        self.onehot = onehot          # (ntok, div)
+        self.drop_in, self.drop_out = drop_in, drop_out      # (p, seed, offset) | None
+        self.table = table            # (tensor [mod, N], mod)
+        self.l2norm = l2norm          # eps | None
+        self.bn_out = bn_out          # the BatchNorm that follows: (running_mean, running_var, momentum) buffers (or Nones)
+
+
+def rowlin_supported(n_in, n_out):
+    return HEAD_CHAIN and n_in % 4 == 0 and n_in <= 512 and n_out % 128 == 0 and n_out <= 512
+
+
+class _RowLinChain(torch.autograd.Function):
+    """A run of Linear stages with BatchNorms between them as one autograd node: one launch per stage each way (BatchNorm statistics,
+    application, ReLU, dropout, one-hot, entity reduction, normalisation all inside), one weight-gradient launch at the end."""
+
+    @staticmethod
+    def forward(ctx, x, stages, training, pack, slots, owners, eval_stats, *params):
+        dev = x.device
+        need = any(ctx.needs_input_grad)
+        x = x.contiguous()
+        W = pack.get([('s%d' % i, params[st.w]) for i, st in enumerate(stages)])
+        cur = x.view(-1, x.shape[-1])
+        rec = []
+        stats = None                   # (mean, var) of the BatchNorm in front of the next stage
+        for i, st in enumerate(stages):
+            w = params[st.w]
+            N, Kin = w.shape
+            rows_in, Cin = cur.shape
+            M = rows_in // st.gather[0] if st.gather else rows_in
+            Mp = (M + 127) // 128 * 128
+            G = (M + 31) // 32
+            a = _lib.MvfRowLinFwd()
+            a.M, a.Cin, a.N, a.Mp, a.X, a.ldx = M, Cin, N, Mp, ptr(cur), cur.stride(0)
+            g_arg = None
+            if st.gather:
+                a.g_ntok, a.g_T, a.g_mode = st.gather
+                if st.gather[2] == 2:
+                    g_arg = torch.empty(M, Cin, device=dev, dtype=torch.int32)
+                    a.g_arg = ptr(g_arg)
+            bn_stats = None
+            if st.bn_in is not None:
+                ig, ib, eps, relu = st.bn_in
+                bn_stats = stats if training else eval_stats[i]
+                a.bn_mean, a.bn_var, a.bn_g, a.bn_b, a.bn_eps, a.bn_relu = ptr(bn_stats[0]), ptr(bn_stats[1]), ptr(params[ig]), ptr(params[ib]), eps, int(relu)
+            if st.onehot:
+                a.oh_ntok, a.oh_div = st.onehot
+            assert Cin + (st.onehot[0] if st.onehot else 0) == Kin, (Cin, Kin)
+            a.drop_in, a.drop_out = _drop_c(st.drop_in), _drop_c(st.drop_out)
+            a.w16, a.bias = W['s%d' % i][0], ptr(params[st.b]) if st.b is not None else None
+            if st.table is not None:
+                a.table, a.tab_mod = ptr(st.table[0]), st.table[1]
+            Y = torch.empty(M, N, device=dev, dtype=torch.float32)
+            nrm = None
+            if st.l2norm is not None:
+                nrm = torch.empty(M, device=dev, dtype=torch.float32)
+                a.l2norm, a.l2_eps, a.nrm = 1, st.l2norm, ptr(nrm)
+            a.Y = ptr(Y)
+            xT = torch.empty((Kin + 63) // 64 * 64, Mp, device=dev, dtype=torch.bfloat16) if need else None
+            a.xT = ptr(xT)
+            stats = None
+            if st.bn_out is not None and training:
+                part = torch.empty(2 * G * N, device=dev, dtype=torch.float32)
+                mean, var = torch.empty(N, device=dev, dtype=torch.float32), torch.empty(N, device=dev, dtype=torch.float32)
+                a.st_part, a.st_mean, a.st_var = ptr(part), ptr(mean), ptr(var)
+                rm, rv, mom = st.bn_out
+                if rm is not None:
+                    a.st_rmean, a.st_rvar, a.st_momentum = ptr(rm), ptr(rv), float(mom)
+                stats = (mean, var)
+            call('mvf_rowlin_fwd', ctypes.byref(a), stream())
+            rec.append(dict(X=cur, Y=Y, bn=bn_stats, xT=xT, nrm=nrm, g_arg=g_arg, M=M, Mp=Mp, Cin=Cin, Kin=Kin, N=N))
+            cur = Y
+        if need:
+            ctx.rec, ctx.stages, ctx.params, ctx.W, ctx.slots, ctx.owners, ctx.training = rec, stages, params, W, slots, owners, training
+            ctx.keep = pack.buf
+            ctx.xshape = x.shape
+        return cur
+
+    @staticmethod
+    def backward(ctx, dy):
+        rec, stages, params, W, slots, owners, training = ctx.rec, ctx.stages, ctx.params, ctx.W, ctx.slots, ctx.owners, ctx.training
+        dev = dy.device
+        use_slots = slots is not None
+        grads = [None] * len(params)
+
+        def gbuf(i, zero):
+            if use_slots:
+                return slots[i]
+            if grads[i] is None:
+                grads[i] = (torch.zeros_like if zero else torch.empty_like)(params[i])
+            return grads[i]
+
+        dcur = dy.contiguous().view(rec[-1]['M'], rec[-1]['N'])
+        nb = None
+        probs, keep = [], []
+        for i in range(len(stages) - 1, -1, -1):
+            st, R = stages[i], rec[i]
+            M, Cin, Kin, N, Mp = R['M'], R['Cin'], R['Kin'], R['N'], R['Mp']
+            G = (M + 31) // 32
+            a = _lib.MvfRowLinBwd()
+            a.M, a.Cin, a.N, a.Mp, a.dY = M, Cin, N, Mp, ptr(dcur)
+            if nb is not None:          # the BatchNorm that consumes this stage's Y: its backward, applied while dZ is loaded
+                a.nb_Y, a.nb_mean, a.nb_var, a.nb_g, a.nb_s1, a.nb_s2, a.nb_eps, a.nb_count = nb
+            a.drop_out, a.drop_in = _drop_c(st.drop_out), _drop_c(st.drop_in)
+            if st.l2norm is not None:
+                a.l2norm, a.l2_y, a.l2_nrm, a.l2_eps = 1, ptr(R['Y']), ptr(R['nrm']), st.l2norm
+            gT = torch.empty((N + 63) // 64 * 64, Mp, device=dev, dtype=torch.bfloat16)
+            a.w16t, a.gT = W['s%d' % i][1], ptr(gT)
+            a.oh_ntok = st.onehot[0] if st.onehot else 0
+            nb = None
+            if st.bn_in is not None:
+                ig, ib, eps, relu = st.bn_in
+                mean, var = R['bn']
+                a.X, a.ldx = ptr(R['X']), R['X'].stride(0)
+                a.bn_mean, a.bn_var, a.bn_g, a.bn_b, a.bn_eps, a.bn_relu = ptr(mean), ptr(var), ptr(params[ig]), ptr(params[ib]), eps, int(relu)
+                part = torch.empty(2 * G * Cin, device=dev, dtype=torch.float32)
+                s1, s2 = torch.empty(Cin, device=dev, dtype=torch.float32), torch.empty(Cin, device=dev, dtype=torch.float32)
+                a.st_part, a.s1, a.s2 = ptr(part), ptr(s1), ptr(s2)
+                a.dgamma, a.dbeta = gbuf(ig, True).data_ptr(), gbuf(ib, True).data_ptr()
+                nb = (ptr(R['X']), ptr(mean), ptr(var), ptr(params[ig]), ptr(s1), ptr(s2), eps, float(M) if training else 0.0)
+                keep += [part, s1, s2]
+            rows_in = R['X'].shape[0]
+            dX = torch.empty(rows_in, Cin, device=dev, dtype=torch.float32)
+            if st.gather:
+                a.g_ntok, a.g_T, a.g_mode = st.gather
+                a.g_arg = ptr(R['g_arg'])
+            a.dX, a.lddx = ptr(dX), Cin
+            call('mvf_rowlin_bwd', ctypes.byref(a), stream())
+            probs.append((gT, R['xT'], st.w, st.b, N, Kin))
+            keep.append(gT)
+            dcur = dX
+        for i0 in range(0, len(probs), 16):
+            chunk = probs[i0:i0 + 16]
+            arr = (_lib.MvfDwProblem * len(chunk))()
+            mp = None
+            for e, (gT, xT, iw, ib, N, K) in zip(arr, chunk):
+                gw = gbuf(iw, False)
+                e.gT, e.xT, e.dw, e.lddw, e.N, e.K = ptr(gT), ptr(xT), gw.data_ptr(), gw.stride(0) if gw.dim() == 2 else K, N, K
+                e.db = gbuf(ib, False).data_ptr() if ib is not None else None
+                mp = gT.shape[1] if mp is None else mp
+                assert gT.shape[1] == mp
+            call('mvf_head_dw', arr, len(chunk), mp, 1 if use_slots else 0, stream())
+        if use_slots:
+            grad_ready(*owners)
+        ctx.rec = None
+        dx = dcur.view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        return (dx, None, None, None, None, None, None) + tuple(grads)
+
+
+def rowlin_chain(x, stages, params, training, pack, eval_stats=None):
+    """x [..., C] through the stages (RowLinStage, indices into `params`); parameter gradients go straight into their flat-gradient
+    slots when every parameter has one.  eval_stats[i] = (running_mean, running_var) of stage i's bn_in (eval mode)."""
+    slots = [grad_slot(p) for p in params]
+    use_slots = x.requires_grad and all(s_ is not None for s_ in slots)
+    return _RowLinChain.apply(x, tuple(stages), bool(training), pack, tuple(slots) if use_slots else None, tuple(params) if use_slots else (),
+                              eval_stats, *params)
+
+
 def encoder_chain(x, mask, layers, H, eps, drops, pack):
     """x [B, S, D] -> [B, S, D].  layers: per EncoderLayer a dict with the 12 parameter tensors in _EncoderChain's order
     ('params'), and for parameters that live in the flat gradient buffer 'slots' (12 gradient views, the Q|K|V one over the

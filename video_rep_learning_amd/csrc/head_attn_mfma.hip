@@ -186,15 +186,14 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(TAttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------ dQ
 template <int DK>
-__global__ __launch_bounds__(256) void tattn_mfma_dq_kernel(TAttnArgs a) {
+__device__ __forceinline__ void tattn_dq_body(const TAttnArgs& a, int h, float* lds) {
   using I = Img<DK>;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
   float* kf = lds;                       // K fragment image (S^T)
   float* ks = kf + I::FRAG_F;            // K scalar image (dQ^T)
   float* vf = ks + I::SCAL_F;            // V fragment image (dP^T)
   float* sm = vf + I::FRAG_F;            // [64] key mask
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int b = blockIdx.z;
   const size_t ld = (size_t)3 * a.Dm;
   const float* base = a.qkv + (size_t)b * a.S * ld + h * DK;
   const int q = blockIdx.x * BLK + wave * 16 + c;
@@ -253,9 +252,8 @@ __global__ __launch_bounds__(256) void tattn_mfma_dq_kernel(TAttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------ dK, dV
 template <int DK>
-__global__ __launch_bounds__(256) void tattn_mfma_dkv_kernel(TAttnArgs a) {
+__device__ __forceinline__ void tattn_dkv_body(const TAttnArgs& a, int h, float* lds) {
   using I = Img<DK>;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
   float* qfi = lds;                      // Q fragment image (S)
   float* qsi = qfi + I::FRAG_F;          // Q scalar image (dK^T)
   float* gfi = qsi + I::SCAL_F;          // dO fragment image (dP)
@@ -263,7 +261,7 @@ __global__ __launch_bounds__(256) void tattn_mfma_dkv_kernel(TAttnArgs a) {
   float* slse = gsi + I::SCAL_F;         // [64] lse of the block's queries (+big for rows >= S -> p = 0)
   float* sdel = slse + BLK;              // [64] delta of the block's queries
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int b = blockIdx.z;
   const size_t ld = (size_t)3 * a.Dm;
   const float* base = a.qkv + (size_t)b * a.S * ld + h * DK;
   const float* gbase = a.d_o + (size_t)b * a.S * a.Dm + h * DK;
@@ -329,6 +327,15 @@ __global__ __launch_bounds__(256) void tattn_mfma_dkv_kernel(TAttnArgs a) {
   }
 }
 
+// dQ and dK/dV of one attention in ONE launch: the two are independent (both read q, k, v, o, dO, lse), blockIdx.y < H takes the
+// query-owning form, the rest the key-owning form
+template <int DK>
+__global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(TAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if ((int)blockIdx.y < a.H) tattn_dq_body<DK>(a, blockIdx.y, lds);
+  else tattn_dkv_body<DK>(a, blockIdx.y - a.H, lds);
+}
+
 template <int DK>
 int run(int which, const TAttnArgs& a, hipStream_t st) {
   using I = Img<DK>;
@@ -338,15 +345,15 @@ int run(int which, const TAttnArgs& a, hipStream_t st) {
   const size_t lds_kv = (size_t)(2 * I::FRAG_F + 2 * I::SCAL_F + 2 * BLK) * 4;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tattn_mfma_dkv_kernel<DK>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tattn_mfma_bwd_kernel<DK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     attr = true;
   }
   if (which == 0) {
     hipLaunchKernelGGL(tattn_mfma_fwd_kernel<DK>, grid, dim3(256), lds_f, st, a);
   } else {
-    hipLaunchKernelGGL(tattn_mfma_dq_kernel<DK>, grid, dim3(256), lds_q, st, a);
-    hipLaunchKernelGGL(tattn_mfma_dkv_kernel<DK>, grid, dim3(256), lds_kv, st, a);
+    (void)lds_q;
+    hipLaunchKernelGGL(tattn_mfma_bwd_kernel<DK>, dim3(grid.x, 2 * a.H, grid.z), dim3(256), lds_kv, st, a);
   }
   MVF_LAUNCH_CHECK();
   return MVF_OK;

@@ -295,7 +295,7 @@ class MultiEntityTransformerEmbModel(nn.Module):
                                       drop_out=ops.drop_args(self.video_pos_enc.dout_p, self.training, self.drop_state,
                                                              x.shape[0] * self.video_emb.weight.shape[0])))
         eval_stats.append((last_bn.running_mean, last_bn.running_var))
-        return ops.rowlin_chain(x, stages, params, self.training, self._pack_trunk, tuple(eval_stats))
+        return ops.rowlin_chain(x, stages, params, self.training, self._pack_trunk, tuple(eval_stats), tag='trunk.')
 
     def _bn(self, x, bn, relu):
         return ops.batch_norm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training and bn.training,
@@ -339,7 +339,7 @@ class MultiEntityTransformerEmbModel(nn.Module):
             # entity reduction + embedding layer (mvformer.py:181-199) as one launch each way
             st = ops.RowLinStage(0, 1, gather=(ntok, T, {'one': 0, 'avg': 1, 'max': 2}[self.smart_final]))
             x = ops.rowlin_chain(x.reshape(Bc * ntok * T, -1), [st], [self.embedding_layer.weight, self.embedding_layer.bias],
-                                 self.training, self._pack_tail)
+                                 self.training, self._pack_tail, tag='tail.')
             return x.view(Bc, T, self.embedding_size)
         x = x.view(Bc, ntok, T, -1)
         if self.smart_final == 'lin':

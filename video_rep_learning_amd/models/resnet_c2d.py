@@ -37,7 +37,7 @@ class MLPHead(nn.Module):
             stages = [ops.RowLinStage(0, 1, bn_out=(bn.running_mean, bn.running_var, bn.momentum)),
                       ops.RowLinStage(4, 5, bn_in=(2, 3, bn.eps, True), l2norm=1e-12 if normalize else None)]
             y = ops.rowlin_chain(x.reshape(-1, c), stages, [lin0.weight, lin0.bias, bn.weight, bn.bias, lin1.weight, lin1.bias], self.training,
-                                 self._pack, (None, (bn.running_mean, bn.running_var)))
+                                 self._pack, (None, (bn.running_mean, bn.running_var)), tag='proj.')
             return y.view(b, l, -1)
         h = ops.linear(x.reshape(-1, c), lin0.weight, lin0.bias)
         h = ops.batch_norm(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, momentum=bn.momentum,

@@ -175,6 +175,12 @@ class TransformerModel(nn.Module):
             ('bf16' if ('USE_AMP' in cfg and cfg.USE_AMP) else 'fp32')
         self.frames_per_chunk = int(mi['FRAMES_PER_CHUNK']) if 'FRAMES_PER_CHUNK' in mi else 0
         self.head_dtype = ops.head_dtype_of(cfg)
+        # one pack of bf16 weight images for every row-chain module of the head: refreshed by one launch per optimizer step
+        shared = ops.HeadPack()
+        for m in self.modules():
+            for attr in ('_pack', '_pack_trunk', '_pack_tail'):
+                if isinstance(getattr(m, attr, None), ops.HeadPack):
+                    setattr(m, attr, shared)
         if self.compute_dtype in ('fp16', 'f16') and getattr(self, 'split_layer', None) is not None:
             raise NotImplementedError('MI355X.COMPUTE_DTYPE fp16 covers the FROZEN backbone (MODEL.BASE_MODEL.LAYER >= depth); the '
                                       'trainable back-end blocks of a partially frozen one run in bf16 or fp32')

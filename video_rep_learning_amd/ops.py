@@ -869,22 +869,37 @@ def head_dtype_of(cfg):
 class HeadPack:
     """bf16 operand copies (fragment-major images of W and of W^T) of a set of nn.Linear weights, refreshed by ONE launch when any source
     changed: torch's version counters catch in-place writes (load_state_dict, torch optimizers), `invalidate()` is what the
-    fused optimizer calls after it updated the parameters through raw pointers (FusedAdam.packed_owners)."""
+    fused optimizer calls after it updated the parameters through raw pointers (FusedAdam.packed_owners).
+    One instance may serve several modules (models.transformer.TransformerModel shares one across the head): every caller's weights
+    stay registered under its `tag`, and whichever caller finds the pack stale refreshes ALL of them in the same launch."""
 
     def __init__(self):
         self.key = None
         self.buf = None
         self.views = {}
         self.stale = True
+        self.registry = {}            # tag -> [(name, weight)] as last seen
 
     def invalidate(self):
         self.stale = True
 
-    def get(self, named):
+    @staticmethod
+    def _key(named):
+        return tuple((n, w.data_ptr(), w._version, tuple(w.shape), w.stride(0)) for n, w in named)
+
+    def get(self, named, tag=''):
         """named: [(name, weight [N, K] fp32 with unit inner stride)] -> {name: (w16 ptr, w16t ptr)}"""
-        key = tuple((n, w.data_ptr(), w._version, tuple(w.shape), w.stride(0)) for n, w in named)
-        if not self.stale and key == self.key:
-            return self.views
+        named = [(tag + n, w) for n, w in named]
+        old = self.registry.get(tag)
+        self.registry[tag] = named
+        allw = [nw for t in sorted(self.registry) for nw in self.registry[t]]
+        key = self._key(allw)
+        if self.stale or key != self.key or old is None:
+            self._pack(allw)
+            self.key, self.stale = key, False
+        return {n[len(tag):]: self.views[n] for n, _w in named}
+
+    def _pack(self, named):
         lib = _lib.load()
         dev = named[0][1].device
         sizes = [(lib.mvf_head_pack_elems(w.shape[0], w.shape[1], 0), lib.mvf_head_pack_elems(w.shape[0], w.shape[1], 1))
@@ -906,8 +921,7 @@ class HeadPack:
         for i0 in range(0, len(named), 32):
             n = min(32, len(named) - i0)
             call('mvf_head_pack_weights', ctypes.byref(ents, i0 * ctypes.sizeof(_lib.MvfPackEntry)), n, stream())
-        self.key, self.views, self.stale = key, views, False
-        return views
+        self.views = views
 
 
 def _drop_c(d):
@@ -944,7 +958,7 @@ class _EncoderChain(torch.autograd.Function):
         for l in range(L):
             P = params[l * 12:(l + 1) * 12]
             named += [('qkv%d' % l, P[2]), ('o%d' % l, P[4]), ('f1%d' % l, P[8]), ('f2%d' % l, P[10])]
-        W = pack.get(named)
+        W = pack.get(named, 'enc.')
         mlen, mk = S, None
         if mask is not None:
             mk = mask.reshape(B, -1)
@@ -1103,11 +1117,11 @@ class _RowLinChain(torch.autograd.Function):
     application, ReLU, dropout, one-hot, entity reduction, normalisation all inside), one weight-gradient launch at the end."""
 
     @staticmethod
-    def forward(ctx, x, stages, training, pack, slots, owners, eval_stats, *params):
+    def forward(ctx, x, stages, training, pack, slots, owners, eval_stats, tag, *params):
         dev = x.device
         need = any(ctx.needs_input_grad)
         x = x.contiguous()
-        W = pack.get([('s%d' % i, params[st.w]) for i, st in enumerate(stages)])
+        W = pack.get([('s%d' % i, params[st.w]) for i, st in enumerate(stages)], tag)
         cur = x.view(-1, x.shape[-1])
         rec = []
         stats = None                   # (mean, var) of the BatchNorm in front of the next stage
@@ -1232,16 +1246,16 @@ class _RowLinChain(torch.autograd.Function):
             grad_ready(*owners)
         ctx.rec = None
         dx = dcur.view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        return (dx, None, None, None, None, None, None) + tuple(grads)
+        return (dx, None, None, None, None, None, None, None) + tuple(grads)
 
 
-def rowlin_chain(x, stages, params, training, pack, eval_stats=None):
+def rowlin_chain(x, stages, params, training, pack, eval_stats=None, tag=''):
     """x [..., C] through the stages (RowLinStage, indices into `params`); parameter gradients go straight into their flat-gradient
     slots when every parameter has one.  eval_stats[i] = (running_mean, running_var) of stage i's bn_in (eval mode)."""
     slots = [grad_slot(p) for p in params]
     use_slots = x.requires_grad and all(s_ is not None for s_ in slots)
     return _RowLinChain.apply(x, tuple(stages), bool(training), pack, tuple(slots) if use_slots else None, tuple(params) if use_slots else (),
-                              eval_stats, *params)
+                              eval_stats, tag, *params)
 
 
 def encoder_chain(x, mask, layers, H, eps, drops, pack):

@@ -199,6 +199,10 @@ int mvf_layernorm_fwd(int out_dtype, const float* x, size_t in_stride, const flo
  * 2 = the earlier kernels (one tile per wave / synchronously staged 224-key blocks; what other values fall back to),
  * 4 = streamed 64-key blocks */
 int mvf_vit_attn_fwd(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t stream);
+/* softmax normalisation convention of the 16-bit kernels (variant 0 and the fused qkv + attention kernel): 1 = the row sum is taken over
+ * the probabilities AFTER their rounding to bf16 / fp16 (N = 193..208: on the matrix pipe beside P.V), 0 = over the fp32 values (every
+ * other N).  Both are softmax to within the operand rounding; the emulating oracle follows this function's answer (tests/test_abi.py). */
+int mvf_vit_attn_rowsum_rounded(int dtype, int N);
 /* timm Attention.qkv FUSED into the attention core (reached from models/transformer.py:188): out [F*N, D] = per (frame, head)
  * softmax(q k^T / 8) v with [q | k | v] = A[f] W_h^T + bias (ln_c / ln_mr NULL), or the folded-LayerNorm form
  * rstd (A W'^T - mean ln_c) + bias of mvf_gemm_tc_ln (ln_c [3D]; the rows' statistics as ln_mr [F*N][2], or -- ln_mr NULL -- as the

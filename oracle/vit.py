@@ -171,6 +171,13 @@ def vit_block(x, w, p, heads, eps=1e-6, emulate=None):
     return x + h
 
 
+def rowsum_rounded(n):
+    """Softmax normalisation of the 16-bit emulation for n tokens: True = the row sum runs over the probabilities after their rounding
+    to the operand type (what the device's kernels for 193..208 tokens do, beside P.V on the matrix pipe), False = over the fp32 values.
+    Mirrors `mvf_vit_attn_rowsum_rounded` (include/mvf_hip.h); tests/test_abi.py holds the two together for every n up to 2 048."""
+    return 193 <= n <= 208
+
+
 def ln_linear_bf16(x, g, beta, W, b, eps, fold):
     """Linear(LayerNorm(x)) before the output rounding, bf16 mode.  fold: the product's folded form (module docstring),
     statistics as its kernels take them (sum and sum of squares of the fp32 row, biased variance E[x^2] - mean^2)."""
@@ -214,7 +221,7 @@ def vit_block_bf16(x, w, p, heads, eps=1e-6, fold1=False, fold2=False, mx=False,
     # the row sum: over the SAME rounded values where the product's kernel takes it on the matrix pipe (a fifth P.V column of ones,
     # fp32 accumulation: the 193..208-token kernels of vit_attn.hip / vit_qkv_attn.hip), over the unrounded fp32 values in its
     # streamed kernel for every other sequence length
-    rs = prr.sum(-1, keepdim=True) if 193 <= n <= 208 else pr.sum(-1, keepdim=True)
+    rs = prr.sum(-1, keepdim=True) if rowsum_rounded(n) else pr.sum(-1, keepdim=True)
     a = r((prr @ v) / rs)
     a = a.transpose(1, 2).reshape(f, n, d)
     if defer_proj:

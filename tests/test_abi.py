@@ -46,6 +46,18 @@ def test_argument_errors_are_reported_before_any_launch(lib):
         _lib.call('mvf_layernorm_fwd', 0, None, 0, None, None, None, 0, 0, 0, 1e-6, None)
 
 
+def test_softmax_rowsum_convention_is_the_same_in_library_and_oracle(lib):
+    """The 16-bit attention kernels normalise by the sum of the ROUNDED probabilities for some token counts and by the fp32 sum for the
+    others; the emulating oracle must follow the library's dispatch, not a copy of it (a host-side query: no launch)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import vit as OV
+    for dt in (_lib.BF16, _lib.F16):
+        for n in range(1, 2049):
+            assert bool(lib.mvf_vit_attn_rowsum_rounded(dt, n)) == OV.rowsum_rounded(n), (dt, n)
+    assert lib.mvf_vit_attn_rowsum_rounded(_lib.F32, 197) == 0
+
+
 def test_product_path_refuses_cpu_tensors():
     import torch
     from video_rep_learning_amd import ops

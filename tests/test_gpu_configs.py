@@ -177,6 +177,9 @@ def test_full_size_fp32_and_bf16_vs_oracle(tag):
     # last-bit change of the taps: measured 2.6e-2 (round 2), 1.0e-1 (round 4, two flipped rows of fc_layers.5): counted by
     # flip_bound above, bounded here only against a gross error
     assert r['loss_head'] <= 1e-3 and r['flips'] <= T.flip_bound(r['nelem']) and r['head_grad_raw'] <= 0.25, r
+    # ... and the loose bound covers ONLY the elements of the (few) flipped units' rows: every element outside them sits under the
+    # report's 2e-2 gate, so a genuine gradient error -- which would not stay inside a handful of rows -- still trips this test
+    assert r['head_grad'] <= 2e-2 and r['flip_rows'] <= 8, r
     assert r['grad_cos'] >= 0.98, r
     # ---- fp16 mode (the reference's own autocast dtype, CARL_MVF/train.py:113,301) at the benchmarked shape: closer to the fp32
     # oracle than bf16 is, by about the three mantissa bits it has more

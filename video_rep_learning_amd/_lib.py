@@ -50,6 +50,7 @@ SIGNATURES = {
     'mvf_patchify': 'ippiiiip',
     'mvf_layernorm_fwd': 'ipzpppziifp',
     'mvf_vit_attn_fwd': 'ippiiiiip',
+    'mvf_vit_attn_rowsum_rounded': 'ii',
     'mvf_vit_qkv_attn_fwd': 'ipipppp' + 'pif' + 'piiiip',
     'mvf_cast_f32_bf16': 'ppzp',
     'mvf_cast_f32_f16': 'ppzp',

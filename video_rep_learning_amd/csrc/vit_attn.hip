@@ -591,6 +591,14 @@ extern "C" int mvf_vit_attn_fwd_lse(const void* qkv, void* out, float* lse, int 
   return MVF_OK;
 }
 
+// 1 when the default (variant 0) 16-bit kernel for N tokens normalises by the row sum of the ROUNDED probabilities (taken on the
+// matrix pipe with the P.V product), 0 when by the fp32 sum of the unrounded ones.  The one statement of that convention: the
+// dispatch below and vit_qkv_attn.hip's fused kernel follow it, the emulating oracle is tested against it (tests/test_abi.py).
+static bool attn_rowsum_rounded(int N) { return ceil_div(N, KB) == 1 && ceil_div(N, 16) == 13; }
+extern "C" int mvf_vit_attn_rowsum_rounded(int dtype, int N) {
+  return (dtype == MVF_BF16 || dtype == MVF_F16) && N > 0 && attn_rowsum_rounded(N) ? 1 : 0;
+}
+
 int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t st) {
   MVF_CHECK_ARG(qkv && out && F > 0 && N > 0 && H > 0 && D == H * HD);
   MVF_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0);
@@ -608,7 +616,7 @@ int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H
     const int ntile = ceil_div(N, 16);
     const dim3 fg(F * H, ceil_div(ntile, 8));   // streamed kernels: 8 query tiles per workgroup
     if (variant == 1) hipLaunchKernelGGL((vit_attn_bf16_kernel<false, KT>), grid, dim3(256), 0, st, a);
-    else if (a.nblk == 1 && ntile == 13 && variant == 0)      // row sums on the matrix pipe: 73.8 -> 72.3 us, 1 358 -> 1 325 W sustained
+    else if (attn_rowsum_rounded(N) && variant == 0)          // row sums on the matrix pipe: 73.8 -> 72.3 us, 1 358 -> 1 325 W sustained
       hipLaunchKernelGGL((vit_attn_bf16_pair_kernel<13, 3, false, true>), grid, dim3(256), 0, st, a);
     else if (a.nblk == 1 && ntile == 13 && variant == 6)     // row sums on the VALU from the unrounded probabilities (the earlier form)
       hipLaunchKernelGGL((vit_attn_bf16_pair_kernel<13, 3>), grid, dim3(256), 0, st, a);
@@ -619,7 +627,7 @@ int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H
   } else if (dtype == MVF_F16) {   // fp16 q / k / v / out: the two-tile kernel (N = 193 .. 208) or the streamed kernel (any N)
     const int ntile = ceil_div(N, 16);
     const dim3 fg(F * H, ceil_div(ntile, 8));
-    if (a.nblk == 1 && ntile == 13) hipLaunchKernelGGL((vit_attn_bf16_pair_kernel<13, 3, true, true>), grid, dim3(256), 0, st, a);
+    if (attn_rowsum_rounded(N)) hipLaunchKernelGGL((vit_attn_bf16_pair_kernel<13, 3, true, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<6, 3, 4, true>), fg, dim3(256), 0, st, a);
   } else if (dtype == MVF_F32) {
     static bool attr = false;

@@ -99,6 +99,9 @@ def get_cfg():
 # ---- build-specific (optional) keys, all probed with `in` so reference YAMLs stay valid -------------
 # cfg.MI355X.COMPUTE_DTYPE   'bf16' | 'fp32' | 'fp16' | 'fp8'   backbone compute dtype (default bf16 under USE_AMP, else fp32 = parity
 #                            mode; fp16 = the reference's own autocast dtype, frozen backbones only; fp8 = MX-fp8 GEMM operands)
+# cfg.MI355X.HEAD_DTYPE      'bf16' | 'fp32'    the trainable head's Linears: bf16 operands on the matrix cores in row-chain kernels (fp32 master
+#                            weights, statistics, loss, optimizer) -- default beside a bf16 / fp8 backbone or USE_AMP -- or the fp32 kernels
+#                            (default in fp32 / fp16 mode)
 # cfg.MI355X.FRAMES_PER_CHUNK int              frames per backbone pass (0 = MODEL.BASE_MODEL.FRAMES_PER_BATCH*clips)
 # cfg.MI355X.GATHER_EMBEDDINGS bool            cross-GPU embedding all-gather for the SCL negatives
 # cfg.MODEL.BASE_MODEL.WEIGHTS path            timm-format state dict for the backbone (no network download)

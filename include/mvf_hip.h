@@ -397,6 +397,7 @@ int mvf_head_chain_debug(int bits);
 /* diagnostic: pull `bytes` of read-only data into every XCD's L2 (256 workgroups, slice b / 8 each) */
 int mvf_head_l2_warm(const void* p, size_t bytes, hipStream_t stream);
 int mvf_head_chain_debug_stamps(long long* stamps16);   /* device buffer of 16 int64, or NULL (default): stage time stamps of workgroup 0 */
+int mvf_rowlin_debug_stamps(long long* buf, int slots);   /* slots x 16 int64 (or NULL): stage stamps of the next `slots` mvf_rowlin_* launches */
 size_t mvf_head_pack_elems(int N, int K, int transposed);
 
 /* One temporal EncoderLayer minus its attention core (models/utils.py:196-226; ResidualConnection :147-159,

@@ -101,6 +101,7 @@ SIGNATURES = {
     'mvf_head_chain_debug': 'i',
     'mvf_head_l2_warm': 'pzp',
     'mvf_head_chain_debug_stamps': 'p',
+    'mvf_rowlin_debug_stamps': 'pi',
     'mvf_head_pack_elems': 'iii',
     'mvf_enc_layer_fwd': 'pp',
     'mvf_enc_layer_bwd': 'pp',

@@ -35,14 +35,15 @@ __device__ __forceinline__ float drop_apply(const Drop& d, float v, uint64_t idx
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 
-// weight-fragment load: non-temporal.  A layer launch streams 1.5 MB of weights through each of its 24 workgroups; with the default
-// policy that stream displaces the operands of the backbone GEMMs running beside the head in the same L2s (measured with
-// tools/stretch_parts.py: the encoder's launches cost the pipelined step 0.55 ms with plain loads, 0.37 ms with these).
-// MVF_NT_OFF (build flag): plain loads, for A/B measurements.
-#ifdef MVF_NT_OFF
-#define WLOAD(p) (*reinterpret_cast<const bf16x8_t*>(p))
-#else
+// weight-fragment load: plain (default cache policy).  Every workgroup of a launch streams the same weights (1.5 MB per encoder layer),
+// three workgroups per XCD: with the non-temporal hint the fragments were not kept in the L2 for the neighbours and every wave paid the
+// Infinity-Cache latency -- a 512 x 512 GEMM stage 14.0 us against 7.0 with plain loads, the encoder-layer launches 46 / 52 -> 33 / 41 us
+// in the serial step, the pipelined step 10.747 -> 10.726 ms (three alternating runs each, profiles/r05/lib_ab_ntoff_chain.txt).
+// MVF_NT_WEIGHTS (build flag): the non-temporal form, for A/B measurements.
+#ifdef MVF_NT_WEIGHTS
 #define WLOAD(p) __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(p))
+#else
+#define WLOAD(p) (*reinterpret_cast<const bf16x8_t*>(p))
 #endif
 struct NoAux {};
 struct Aux1 { float4 b; };            // bias

@@ -23,6 +23,12 @@ using namespace chain;
 
 __device__ unsigned g_rl_ticket_f, g_rl_ticket_b;
 
+// diagnostic (tools/rowlin_probe.py): stage time stamps of workgroup 0, one 16-slot record per launch
+long long* g_rl_stamps = nullptr;
+int g_rl_stamp_slots = 0, g_rl_stamp_next = 0;
+long long* next_stamps() { return g_rl_stamps != nullptr && g_rl_stamp_next < g_rl_stamp_slots ? g_rl_stamps + 16 * g_rl_stamp_next++ : nullptr; }
+#define RSTAMP(i) do { if (k.stamps != nullptr && threadIdx.x == 0 && blockIdx.x == 0) k.stamps[i] = wall_clock64(); } while (0)
+
 struct RowLinFwdK {
   int M, Cin, Kin, N, Mp;
   const float* X; long ldx;
@@ -36,6 +42,7 @@ struct RowLinFwdK {
   float *Y, *nrm;
   bf16_t* xT;
   float *st_part, *st_mean, *st_var, *st_rmean, *st_rvar; float st_momentum;
+  long long* stamps;
 };
 
 // LDS carve-up (bytes): bf16 input panel, fp32 output panel, per-column (scale, shift) of the input BatchNorm
@@ -62,6 +69,7 @@ __global__ __launch_bounds__(NTH) void rowlin_fwd_kernel(RowLinFwdK k) {
   const int m0 = blockIdx.x * TM, M = k.M, Cin = k.Cin, Kin = k.Kin, N = k.N;
   const int Kp = fm_steps(Kin) * 32;
   const bool bn = k.bn_mean != nullptr;
+  RSTAMP(0);
   if (bn) {
     for (int c = threadIdx.x; c < Cin; c += NTH) {
       const float s = k.bn_g[c] * rsqrtf(k.bn_var[c] + k.bn_eps);
@@ -70,11 +78,12 @@ __global__ __launch_bounds__(NTH) void rowlin_fwd_kernel(RowLinFwdK k) {
     }
     LDS_BARRIER();
   }
+  RSTAMP(1);
   // ---- loader: X rows -> pro() -> bf16 panel ----
   {
     const int c4 = Cin >> 2;       // Cin % 4 == 0
     const int total = TM * c4;
-    constexpr int U = 4;
+    constexpr int U = 8;
     for (int i0 = threadIdx.x; i0 < total; i0 += NTH * U) {
       f32x4_t v[U];
 #pragma unroll
@@ -137,7 +146,9 @@ __global__ __launch_bounds__(NTH) void rowlin_fwd_kernel(RowLinFwdK k) {
     }
   }
   LDS_BARRIER();
+  RSTAMP(2);
   store_T(Pa, L.lda, Kin, k.xT, k.Mp, m0, M);
+  RSTAMP(3);
   // ---- Y = pro(X) W^T + b [+ table] [dropout] ----
   chain_gemm<NT, 4>(Pa, L.lda, Kin, k.w, N, [&](int m, int n) {
     Aux2 a;
@@ -157,6 +168,7 @@ __global__ __launch_bounds__(NTH) void rowlin_fwd_kernel(RowLinFwdK k) {
     *reinterpret_cast<float4*>(Po + m * L.ldo + n) = r;
   });
   LDS_BARRIER();
+  RSTAMP(4);
   if (k.l2norm) {       // F.normalize(dim = -1): 16 lanes per row
     const int r = threadIdx.x >> 4, sub = threadIdx.x & 15;
     float s = 0.f;
@@ -173,6 +185,7 @@ __global__ __launch_bounds__(NTH) void rowlin_fwd_kernel(RowLinFwdK k) {
       if (m0 + r < M) *reinterpret_cast<float4*>(k.Y + (size_t)(m0 + r) * N + 4 * q) = *reinterpret_cast<const float4*>(Po + r * L.ldo + 4 * q);
     }
   }
+  RSTAMP(5);
   if (k.st_part == nullptr) return;
   // ---- batch statistics of Y for the BatchNorm that follows ----
   const int cnt = min(TM, M - m0);
@@ -185,16 +198,28 @@ __global__ __launch_bounds__(NTH) void rowlin_fwd_kernel(RowLinFwdK k) {
     k.st_part[((size_t)blockIdx.x * 2 + 0) * N + c] = mu;
     k.st_part[((size_t)blockIdx.x * 2 + 1) * N + c] = q2;
   }
-  if (!last_arriver(&g_rl_ticket_f, gridDim.x)) return;
+  RSTAMP(6);
+  if (!last_arriver(&g_rl_ticket_f, gridDim.x)) { RSTAMP(7); return; }
   for (int c = threadIdx.x; c < N; c += NTH) {
     float n = 0.f, mu = 0.f, m2 = 0.f;
-    for (int w = 0; w < (int)gridDim.x; ++w) {       // Chan's merge, workgroup order
-      const float nb = (float)min(TM, M - w * TM);
-      const float mw = k.st_part[((size_t)w * 2 + 0) * N + c], qw = k.st_part[((size_t)w * 2 + 1) * N + c];
-      const float d = mw - mu, tot = n + nb;
-      mu += d * nb / tot;
-      m2 += qw + d * d * n * nb / tot;
-      n = tot;
+    const int nwg = (int)gridDim.x;
+    for (int w0 = 0; w0 < nwg; w0 += 8) {       // Chan's merge, workgroup order; the partials of 8 workgroups requested together
+      float mw[8], qw[8];                        // (a load -> use loop pays an L2 round trip per workgroup: 24 of them = 17 us)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int w = min(w0 + u, nwg - 1);
+        mw[u] = k.st_part[((size_t)w * 2 + 0) * N + c];
+        qw[u] = k.st_part[((size_t)w * 2 + 1) * N + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (w0 + u >= nwg) break;
+        const float nb = (float)min(TM, M - (w0 + u) * TM);
+        const float d = mw[u] - mu, tot = n + nb;
+        mu += d * nb / tot;
+        m2 += qw[u] + d * d * n * nb / tot;
+        n = tot;
+      }
     }
     const float var = m2 / n;
     k.st_mean[c] = mu;
@@ -218,6 +243,7 @@ struct RowLinBwdK {
   float *st_part, *s1, *s2, *dgamma, *dbeta;
   int g_ntok, g_T, g_mode; const int* g_arg;
   float* dX; long lddx;
+  long long* stamps;
 };
 
 struct RlLdsB { int ldg, ldd; size_t pg, pd, cst, total; };
@@ -247,6 +273,7 @@ __global__ __launch_bounds__(NTH) void rowlin_bwd_kernel(RowLinBwdK k) {
   const int m0 = blockIdx.x * TM, M = k.M, Cin = k.Cin, Kin = k.Kin, N = k.N;
   const int Np = fm_steps(N) * 32;
   const bool nb = k.nb_Y != nullptr;
+  RSTAMP(0);
   if (nb) {     // BatchNorm backward of the layer that consumes Y: dY = a0 (dZ - a1 - xhat a2), xhat = (Y - mean) rstd
     for (int n = threadIdx.x; n < N; n += NTH) {
       const float rs = rsqrtf(k.nb_var[n] + k.nb_eps);
@@ -254,10 +281,11 @@ __global__ __launch_bounds__(NTH) void rowlin_bwd_kernel(RowLinBwdK k) {
     }
     LDS_BARRIER();
   }
+  RSTAMP(1);
   // ---- dY rows -> fp32 panel (BatchNorm backward applied, dropout mask) ----
   {
     const int q4 = N >> 2, total = TM * q4;
-    constexpr int U = 4;
+    constexpr int U = 8;
     for (int i0 = threadIdx.x; i0 < total; i0 += NTH * U) {
       f32x4_t v[U], y[U];
 #pragma unroll
@@ -300,6 +328,7 @@ __global__ __launch_bounds__(NTH) void rowlin_bwd_kernel(RowLinBwdK k) {
     }
     LDS_BARRIER();
   }
+  RSTAMP(2);
   // g -> bf16 panel (zero padding up to the image's reduction length), its transpose for the weight gradient
   for (int i = threadIdx.x; i < TM * (Np >> 2); i += NTH) {
     const int r = i / (Np >> 2), q = i - r * (Np >> 2);
@@ -308,12 +337,15 @@ __global__ __launch_bounds__(NTH) void rowlin_bwd_kernel(RowLinBwdK k) {
     *reinterpret_cast<u32x2_t*>(Pg + r * L.ldg + 4 * q) = (u32x2_t){pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3])};
   }
   LDS_BARRIER();
+  RSTAMP(3);
   store_T(Pg, L.ldg, N, k.gT, k.Mp, m0, M);
+  RSTAMP(4);
   // ---- dXp = g W  (W^T image: rows = input features, padded to 64) ----
   const int Kr = (Kin + 63) & ~63;
   chain_gemm<NT, 4>(Pg, L.ldg, N, k.wT, Kr, [](int, int) { return NoAux{}; }, [&](int m, int n, const f32x4_t& v, const NoAux&) {
     *reinterpret_cast<float4*>(Pd + m * L.ldd + n) = make_float4(v[0], v[1], v[2], v[3]);
   });
+  RSTAMP(5);
   const bool bn = k.bn_mean != nullptr;
   if (bn) {     // forward prologue's BatchNorm: scale / shift for the ReLU mask, mean / rstd for xhat (arrays reused: c0..c3)
     LDS_BARRIER();
@@ -323,10 +355,11 @@ __global__ __launch_bounds__(NTH) void rowlin_bwd_kernel(RowLinBwdK k) {
     }
   }
   LDS_BARRIER();
+  RSTAMP(6);
   // ---- pro': dropout mask, (one-hot columns dropped), ReLU mask -> dZ (in the panel and to memory) ----
   {
     const int q4 = Cin >> 2, total = TM * q4;
-    constexpr int U = 4;
+    constexpr int U = 8;
     for (int i0 = threadIdx.x; i0 < total; i0 += NTH * U) {
       f32x4_t x[U];
 #pragma unroll
@@ -369,24 +402,45 @@ __global__ __launch_bounds__(NTH) void rowlin_bwd_kernel(RowLinBwdK k) {
       }
     }
   }
+  RSTAMP(7);
   if (k.st_part == nullptr) return;
   LDS_BARRIER();
   // ---- s1 = sum dZ, s2 = sum dZ xhat over this workgroup's rows; the last arriver adds the workgroups' partial sums ----
   for (int c = threadIdx.x; c < Cin; c += NTH) {
     float a = 0.f, b2 = 0.f;
     const int cnt = min(TM, M - m0);
-    for (int r = 0; r < cnt; ++r) {
-      const float d = Pd[r * L.ldd + c];
-      a += d;
-      b2 += d * ((k.X[(size_t)(m0 + r) * k.ldx + c] - c2[c]) * c3[c]);
+    for (int r0 = 0; r0 < cnt; r0 += 8) {       // X rows in batches of 8 loads (a load -> use loop: one L2 round trip per row)
+      float xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xv[u] = k.X[(size_t)(m0 + min(r0 + u, cnt - 1)) * k.ldx + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (r0 + u >= cnt) break;
+        const float d = Pd[(r0 + u) * L.ldd + c];
+        a += d;
+        b2 += d * ((xv[u] - c2[c]) * c3[c]);
+      }
     }
     k.st_part[((size_t)blockIdx.x * 2 + 0) * Cin + c] = a;
     k.st_part[((size_t)blockIdx.x * 2 + 1) * Cin + c] = b2;
   }
-  if (!last_arriver(&g_rl_ticket_b, gridDim.x)) return;
+  RSTAMP(8);
+  if (!last_arriver(&g_rl_ticket_b, gridDim.x)) { RSTAMP(9); return; }
   for (int c = threadIdx.x; c < Cin; c += NTH) {
     float a = 0.f, b2 = 0.f;
-    for (int w = 0; w < (int)gridDim.x; ++w) { a += k.st_part[((size_t)w * 2 + 0) * Cin + c]; b2 += k.st_part[((size_t)w * 2 + 1) * Cin + c]; }
+    const int nwg = (int)gridDim.x;
+    for (int w0 = 0; w0 < nwg; w0 += 8) {       // workgroup order, 8 workgroups' partials requested together
+      float pa[8], pb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int w = min(w0 + u, nwg - 1);
+        pa[u] = k.st_part[((size_t)w * 2 + 0) * Cin + c];
+        pb[u] = k.st_part[((size_t)w * 2 + 1) * Cin + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (w0 + u < nwg) { a += pa[u]; b2 += pb[u]; }
+    }
     k.s1[c] = a;
     k.s2[c] = b2;
     if (k.dgamma != nullptr) { k.dgamma[c] += b2; k.dbeta[c] += a; }
@@ -410,6 +464,12 @@ int launch_bwd(K kern, const RowLinBwdK& k, size_t lds, hipStream_t st, uint64_t
 
 }  // namespace
 
+// diagnostic: device buffer of slots x 16 int64 (or NULL): the next `slots` row-chain launches of this file record their stage stamps
+extern "C" int mvf_rowlin_debug_stamps(long long* buf, int slots) {
+  g_rl_stamps = buf; g_rl_stamp_slots = buf != nullptr ? slots : 0; g_rl_stamp_next = 0;
+  return MVF_OK;
+}
+
 extern "C" int mvf_rowlin_fwd(const MvfRowLinFwd* s, hipStream_t st) {
   MVF_CHECK_ARG(s && s->M > 0 && s->Cin > 0 && s->Cin % 4 == 0 && s->N > 0 && s->N % 128 == 0 && s->X && s->w16 && s->Y && s->ldx >= s->Cin &&
                 s->ldx % 4 == 0 && al16(s->X) && al16(s->Y));
@@ -431,6 +491,7 @@ extern "C" int mvf_rowlin_fwd(const MvfRowLinFwd* s, hipStream_t st) {
   k.w = (const bf16_t*)s->w16; k.bias = s->bias; k.table = s->table; k.tab_mod = s->tab_mod > 0 ? s->tab_mod : 1;
   k.l2norm = s->l2norm; k.l2_eps = s->l2_eps; k.Y = s->Y; k.nrm = s->nrm; k.xT = (bf16_t*)s->xT;
   k.st_part = s->st_part; k.st_mean = s->st_mean; k.st_var = s->st_var; k.st_rmean = s->st_rmean; k.st_rvar = s->st_rvar; k.st_momentum = s->st_momentum;
+  k.stamps = next_stamps();
   static uint64_t a1 = 0, a2 = 0, a4 = 0;
   int rc;
   if (s->N >= 512) rc = launch_fwd(rowlin_fwd_kernel<4>, k, L.total, st, a4);
@@ -465,6 +526,7 @@ extern "C" int mvf_rowlin_bwd(const MvfRowLinBwd* s, hipStream_t st) {
   k.st_part = s->st_part; k.s1 = s->s1; k.s2 = s->s2; k.dgamma = s->dgamma; k.dbeta = s->dbeta;
   k.g_ntok = s->g_ntok; k.g_T = s->g_T; k.g_mode = s->g_mode; k.g_arg = s->g_arg; k.dX = s->dX; k.lddx = s->lddx;
   const int Kr = (Kin + 63) & ~63;
+  k.stamps = next_stamps();
   static uint64_t a1 = 0, a2 = 0, a4 = 0;
   int rc;
   if (Kr >= 384) rc = launch_bwd(rowlin_bwd_kernel<4>, k, L.total, st, a4);

@@ -24,30 +24,47 @@ __device__ unsigned g_sqnorm_ticket;
 // order (reproducible) -- one launch instead of a partial and a final one.
 // norm_out[1] += 1 when that norm is not finite: the count of optimizer steps adam_kernel has SKIPPED (what
 // torch.cuda.amp.GradScaler.step does for the reference's fp16 path, train.py:127-133: no update, no step count)
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part,
-                                                     const float* __restrict__ extra_sq, float* __restrict__ norm_out) {
-  __shared__ float red[4];
+constexpr int SQ_TH = 1024;
+__global__ __launch_bounds__(SQ_TH) void sqnorm_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part,
+                                                       const float* __restrict__ extra_sq, float* __restrict__ norm_out) {
+  __shared__ float red[SQ_TH / 64];
   float s = 0.f;
-  const size_t n4 = n / 4;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    const float4 v = reinterpret_cast<const float4*>(g)[i];
-    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  const size_t n4 = n / 4, stride = (size_t)gridDim.x * SQ_TH;
+  // a thread's loads go out four at a time (as a load -> use loop the ~18 float4 per thread were as many dependent round trips)
+  for (size_t i0 = (size_t)blockIdx.x * SQ_TH + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t i = i0 + u * stride;
+      v[u] = reinterpret_cast<const float4*>(g)[i < n4 ? i : n4 - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u * stride < n4) s += v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z + v[u].w * v[u].w;
   }
   if (blockIdx.x == 0)
-    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) s += g[i] * g[i];
+    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += SQ_TH) s += g[i] * g[i];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < SQ_TH / 64; ++w) a += red[w];
+    part[blockIdx.x] = a;
+  }
   if (!last_arriver(&g_sqnorm_ticket, gridDim.x)) return;
   float t = 0.f;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += part[i];
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += SQ_TH) t += part[i];
   t = wave_sum(t);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3] + (extra_sq ? extra_sq[0] : 0.f));
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < SQ_TH / 64; ++w) a += red[w];
+    const float nrm = sqrtf(a + (extra_sq ? extra_sq[0] : 0.f));
     norm_out[0] = nrm;
     if (!isfinite(nrm)) norm_out[1] += 1.f;
   }
@@ -98,8 +115,8 @@ extern "C" int mvf_grad_norm(const float* g, size_t n, const float* extra_sq, fl
                              hipStream_t st) {
   MVF_CHECK_ARG(g && scratch && norm_out && n > 0 && ((uintptr_t)g & 15) == 0);
   // 256 workgroups at most: every arrival is one atomic on the same ticket word (~11 ns each, serialised)
-  const int nblk = (int)std::min<size_t>(256, (n / 4 + 255) / 256 + 1);
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(nblk), dim3(256), 0, st, g, n, scratch, extra_sq, norm_out);
+  const int nblk = (int)std::min<size_t>(256, (n / 4 + SQ_TH - 1) / SQ_TH + 1);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(nblk), dim3(SQ_TH), 0, st, g, n, scratch, extra_sq, norm_out);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

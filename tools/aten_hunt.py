@@ -59,7 +59,8 @@ def main():
         for kn in kernels:
             mine = any(t in kn for t in ('gemm_tc', 'vit_attn', 'layernorm_kernel', 'lstp', 'hgemm', 'hlinear', 'tattn', 'scl_', 'adam',
                                          'sqnorm', 'bn_', 'ln_', 'im2col', 'cls_row', 'final_reduce', 'l2norm', 'dropout', 'relu',
-                                         'colsum', 'concat_onehot', 'token_pool', 'quant', 'vattn', 'grad_prep', 'gelu'))
+                                         'colsum', 'concat_onehot', 'token_pool', 'quant', 'vattn', 'grad_prep', 'gelu', 'enc_fwd', 'enc_bwd', 'rowlin_',
+                                         'head_dw', 'head_pack', 'static_query', 'vit_qkv'))
             if mine:
                 continue
             frames = [f for f in (ev.stack or []) if 'video_rep_learning_amd' in f or 'bench.py' in f or 'aten_hunt' in f]

@@ -21,12 +21,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _setup(gather=False):
+def _setup(gather=False, head='fp32'):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from video_rep_learning_amd.utils import presets
+    # head 'bf16': the row-chain kernels (SyncBatchNorm statistics and backward sums exchanged BETWEEN their launches)
     cfg = presets.make_cfg(network='TIMM-vit_small_patch16_224.dino', num_frames=8, batch_size=4, image_size=32,
-                           compute_dtype='fp32', dropout=0.0)
+                           compute_dtype='fp32', dropout=0.0, head_dtype=head)
     cfg.OPTIMIZER.LR.INITIAL_LR = 1e-3
     if gather:     # cross-GPU embedding all-gather enlarging the negative set
         cfg.SCL.NEGATIVE_TYPE = 'batch_noself'
@@ -67,12 +68,12 @@ def _train_one_step(cfg, batch, sync_bn):
     return loss.item(), sd, init
 
 
-def _worker(rank, world, port, ret, gather, backend='gloo'):
+def _worker(rank, world, port, ret, gather, backend='gloo', head='fp32'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     if backend == 'nccl':          # one GPU per rank, collectives over RCCL / xGMI
         os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(rank)
-    cfg = _setup(gather)
+    cfg = _setup(gather, head)
     full = _batch(cfg)
     ref_loss, ref_sd, init = _train_one_step(cfg, full, sync_bn=False) if rank == 0 else (None, None, None)
     dist.init_process_group(backend, rank=rank, world_size=world)
@@ -88,7 +89,7 @@ def _worker(rank, world, port, ret, gather, backend='gloo'):
             # sign, so exactly-null-gradient biases are skipped and the metric is dominated by well-conditioned elements)
             null = ('linear_V2d.bias', 'linear_K2d.bias', 'fc_layers.1.bias', 'fc_layers.5.bias', 'feed_forward.fc2.bias',
                     'embedding_layer.bias', 'net.0.bias', 'num_batches_tracked')
-            worst = ('', 0.0)
+            worst, errs = ('', 0.0), []
             for k, v in ref_sd.items():
                 if not v.dtype.is_floating_point or any(k.endswith(n) for n in null):
                     continue
@@ -99,21 +100,100 @@ def _worker(rank, world, port, ret, gather, backend='gloo'):
                     e = ((du_got - du_ref).norm() / du_ref.norm().clamp_min(1e-12)).item()
                 if e > worst[1]:
                     worst = (k, e)
+                errs.append((e, k))
             ret['out'] = (ref_loss, float(sum(l.item() for l in losses) / world), worst)
+            ret['errs'] = sorted(errs, reverse=True)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('gather', [False, True])
-def test_two_ranks_equal_one_process_on_the_whole_batch(gather):
+def _rowlin_case(x, wgt, sync, seed=3):
+    """Two row-chain Linear stages with a BatchNorm + ReLU between them (csrc/head_rowlin.hip) on rows x: outputs, input gradient,
+    parameter gradients of sum(y * wgt), and the running statistics after the step."""
+    from video_rep_learning_amd import ops
+    dev = x.device
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.2).to(dev).requires_grad_(True)
+    w0, b0, w1, b1 = mk(128, 64), mk(128), mk(128, 128), mk(128)
+    gam, bet = (torch.rand(128, generator=g) + 0.5).to(dev).requires_grad_(True), mk(128)
+    rm, rv = torch.zeros(128, device=dev), torch.ones(128, device=dev)
+    stages = [ops.RowLinStage(0, 1, bn_out=(rm, rv, 0.1), sync=sync), ops.RowLinStage(4, 5, bn_in=(2, 3, 1e-5, True))]
+    params = [w0, b0, gam, bet, w1, b1]
+    x = x.clone().requires_grad_(True)
+    y = ops.rowlin_chain(x, stages, params, True, ops.HeadPack())
+    (y * wgt).sum().backward()
+    torch.cuda.synchronize()
+    return dict(y=y.detach().cpu(), dx=x.grad.cpu(), rm=rm.cpu(), rv=rv.cpu(), **{'p%d' % i: p.grad.cpu() for i, p in enumerate(params)})
+
+
+def _rowlin_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    dev = torch.device('cuda', 0)
+    g = torch.Generator().manual_seed(11)
+    M = 192
+    x, wgt = torch.randn(M, 64, generator=g).to(dev), torch.randn(M, 128, generator=g).to(dev)
+    ref = _rowlin_case(x, wgt, None) if rank == 0 else None
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        per = M // world
+        sl = slice(rank * per, (rank + 1) * per)
+        out = _rowlin_case(x[sl], wgt[sl], (None,))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, out)
+        if rank == 0:
+            rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+            errs = {'y': rel(torch.cat([o['y'] for o in gathered]), ref['y']), 'dx': rel(torch.cat([o['dx'] for o in gathered]), ref['dx']),
+                    'rm': rel(out['rm'], ref['rm']), 'rv': rel(out['rv'], ref['rv'])}
+            for i in range(6):        # parameter gradients: the ranks' local gradients add up to the whole batch's
+                errs['p%d' % i] = rel(sum(o['p%d' % i] for o in gathered), ref['p%d' % i])
+            errs['rm_same_on_all_ranks'] = max(rel(o['rm'], out['rm']) for o in gathered)
+            ret['errs'] = errs
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_chain_syncbn_two_ranks_equal_the_whole_batch():
+    """SyncBatchNorm inside the row-chain Linear launches (ops._RowLinChain: statistics merged between the forward launches, the
+    backward sums all-reduced between the backward launches): two ranks on half the rows each against one process on all rows with a
+    local BatchNorm.  Rows are independent apart from the BatchNorm, so the two must agree to bf16-rounding-flip level; a missing or
+    mis-scaled exchange shows as O(1)."""
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), ret, gather), nprocs=2, join=True)
+    mp.spawn(_rowlin_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    errs = dict(ret['errs'])
+    from conftest import record_parity
+    record_parity('row-chain Linear + SyncBN + ReLU + Linear, two ranks vs the whole batch: rel-L2 ' +
+                  ', '.join('%s %.2e' % kv for kv in sorted(errs.items())))
+    assert errs['rm'] <= 1e-5 and errs['rv'] <= 1e-5 and errs['rm_same_on_all_ranks'] == 0.0, errs
+    assert all(v <= 1e-2 for v in errs.values()), errs
+
+
+@pytest.mark.parametrize('gather,head', [(False, 'fp32'), (True, 'fp32'), (False, 'bf16')])
+def test_two_ranks_equal_one_process_on_the_whole_batch(gather, head):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret, gather, 'gloo', head), nprocs=2, join=True)
     ref_loss, mean_loss, worst = ret['out']
+    if os.environ.get('MVF_DDP_VERBOSE') == '1':
+        print('\n'.join('%.3e %s' % e for e in ret['errs']))
+    from conftest import record_parity
+    record_parity('two ranks (gloo, SyncBN, bucketed all-reduce) vs one process on the whole batch, head %s%s: loss %.6f vs %.6f, worst '
+                  'parameter-update rel-L2 %.2e (%s)' % (head, ', gathered embeddings' if gather else '', mean_loss, ref_loss, worst[1], worst[0]))
     # 'single_noself' negatives: the global loss is the mean of the per-rank losses; with gathered embeddings and
     # 'batch_noself' negatives every rank evaluates the SAME global loss, so the mean is that loss again
-    assert abs(ref_loss - mean_loss) <= 1e-4 * abs(ref_loss), (ref_loss, mean_loss)
-    assert worst[1] <= 2e-2, worst
+    # (bf16 head: both sides run the same row-chain kernels; the merged SyncBN statistics differ from the one-pass ones in the last
+    # fp32 bits, which moves single bf16 roundings of the activations behind them)
+    assert abs(ref_loss - mean_loss) <= (1e-4 if head == 'fp32' else 3e-3) * abs(ref_loss), (ref_loss, mean_loss)
+    if head == 'fp32':
+        assert worst[1] <= 2e-2, worst
+    else:
+        # Adam's first step is lr x sign(g): the few-percent gradient deviation a bf16 head shows between ANY two summation orders
+        # (tests/test_gpu_head_chain.py) flips the sign of the near-zero elements -- measured 3 - 4 % of them, i.e. rel-L2 0.35 - 0.45 of
+        # every tensor's update (0.73 on the sparsest bias).  The exchange itself is pinned by the row-chain test above and by the
+        # BatchNorm running statistics (part of this state dict: 1e-7 .. 4e-4); here only a gross failure is excluded
+        stats = [e for e, k in ret['errs'] if 'running_' in k]
+        assert max(stats) <= 2e-3 and worst[1] <= 0.9, (worst, stats)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='two GPUs (one per rank) for the RCCL form of the two-rank test')

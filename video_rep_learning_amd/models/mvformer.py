@@ -243,13 +243,16 @@ class MultiEntityTransformerEmbModel(nn.Module):
         self._pack_tail.invalidate()
 
     def _bn_chainable(self, bn):
+        return bn.momentum is not None and bn.affine and bn.track_running_stats
+
+    def _bn_sync(self, bn):
+        """RowLinStage.sync of the stage in front of `bn`: a SyncBatchNorm with live collectives exchanges its statistics between launches."""
         from ..utils.distributed import collectives_active
-        return bn.momentum is not None and bn.affine and bn.track_running_stats and \
-            not (isinstance(bn, nn.SyncBatchNorm) and collectives_active())
+        return (self.sync_group,) if isinstance(bn, nn.SyncBatchNorm) and collectives_active() else None
 
     def trunk_chain_active(self, c_in=None):
         """The FC stack + video_emb run as row chains (one launch per Linear each way): bf16 head, the one-hot (if any) appended
-        before the stack, every width within the kernels' panels, BatchNorm statistics local to the rank."""
+        before the stack, every width within the kernels' panels (a SyncBatchNorm's exchange happens between the launches)."""
         if self.head_dtype != 'bf16' or isinstance(self.fc_layers, nn.Identity) or self.one_hot_pos == 'enc':
             return False
         mods = list(self.fc_layers)
@@ -282,7 +285,7 @@ class MultiEntityTransformerEmbModel(nn.Module):
             kin = lin.weight.shape[1]
             st = ops.RowLinStage(iw, iw + 1, bn_in=prev, onehot=(ntok, T) if (i == 0 and self.one_hot_pos == 'pool') else None,
                                  drop_in=ops.drop_args(drop.p, self.training, self.drop_state, x.shape[0] * kin),
-                                 bn_out=(bn.running_mean, bn.running_var, bn.momentum))
+                                 bn_out=(bn.running_mean, bn.running_var, bn.momentum), sync=self._bn_sync(bn))
             eval_stats.append(None if i == 0 else (mods[4 * i - 2].running_mean, mods[4 * i - 2].running_var))
             stages.append(st)
             ig = len(params)

@@ -1096,7 +1096,8 @@ class RowLinStage:
     """One Linear of a row chain (csrc/head_rowlin.hip mvf_rowlin_fwd) and what surrounds it.  Parameter fields hold INDICES into
     the chain's flat parameter list (None: absent)."""
 
-    def __init__(self, w, b, gather=None, bn_in=None, onehot=None, drop_in=None, table=None, drop_out=None, l2norm=None, bn_out=None):
+    def __init__(self, w, b, gather=None, bn_in=None, onehot=None, drop_in=None, table=None, drop_out=None, l2norm=None, bn_out=None,
+                 sync=None):
         self.w, self.b = w, b
         self.gather = gather          # (ntok, T, mode 0 | 1 | 2): entity reduction of the input rows
         self.bn_in = bn_in            # the BatchNorm (+ReLU) in front: (index of gamma, index of beta, eps, relu); its statistics come
@@ -1106,6 +1107,8 @@ class RowLinStage:
         self.table = table            # (tensor [mod, N], mod)
         self.l2norm = l2norm          # eps | None
         self.bn_out = bn_out          # the BatchNorm that follows: (running_mean, running_var, momentum) buffers (or Nones)
+        self.sync = sync              # (process group | None,): bn_out is a SyncBatchNorm with live collectives -- its statistics (forward)
+        #                               and its backward sums are exchanged between this stage's launch and the next one's
 
 
 def rowlin_supported(n_in, n_out):
@@ -1125,6 +1128,7 @@ class _RowLinChain(torch.autograd.Function):
         cur = x.view(-1, x.shape[-1])
         rec = []
         stats = None                   # (mean, var) of the BatchNorm in front of the next stage
+        in_count = 0.0                 # rows behind those statistics (all ranks' rows for a SyncBatchNorm)
         for i, st in enumerate(stages):
             w = params[st.w]
             N, Kin = w.shape
@@ -1160,17 +1164,29 @@ class _RowLinChain(torch.autograd.Function):
             a.Y = ptr(Y)
             xT = torch.empty((Kin + 63) // 64 * 64, Mp, device=dev, dtype=torch.bfloat16) if need else None
             a.xT = ptr(xT)
-            stats = None
+            stats, out_count = None, float(M)
+            synced = st.sync is not None and st.bn_out is not None and training
             if st.bn_out is not None and training:
                 part = torch.empty(2 * G * N, device=dev, dtype=torch.float32)
                 mean, var = torch.empty(N, device=dev, dtype=torch.float32), torch.empty(N, device=dev, dtype=torch.float32)
                 a.st_part, a.st_mean, a.st_var = ptr(part), ptr(mean), ptr(var)
                 rm, rv, mom = st.bn_out
-                if rm is not None:
+                if rm is not None and not synced:      # (SyncBatchNorm: the running buffers take the merged statistics, below)
                     a.st_rmean, a.st_rvar, a.st_momentum = ptr(rm), ptr(rv), float(mom)
                 stats = (mean, var)
             call('mvf_rowlin_fwd', ctypes.byref(a), stream())
-            rec.append(dict(X=cur, Y=Y, bn=bn_stats, xT=xT, nrm=nrm, g_arg=g_arg, M=M, Mp=Mp, Cin=Cin, Kin=Kin, N=N))
+            if synced:
+                # SyncBatchNorm: (mean, biased var, count) of every rank merged (Chan) between this launch and the next -- collective
+                # C2 of SURVEY.md, 2N + 1 floats per rank
+                mean, var, out_count = sync_bn_stats(stats[0], stats[1], float(M), st.sync[0], equal_counts=True)
+                rm, rv, mom = st.bn_out
+                if rm is not None:
+                    with torch.no_grad():
+                        rm.mul_(1 - mom).add_(mean, alpha=mom)
+                        rv.mul_(1 - mom).add_(var, alpha=mom * out_count / max(out_count - 1.0, 1.0))
+                stats = (mean, var)
+            rec.append(dict(X=cur, Y=Y, bn=bn_stats, bn_count=in_count, xT=xT, nrm=nrm, g_arg=g_arg, M=M, Mp=Mp, Cin=Cin, Kin=Kin, N=N))
+            in_count = out_count
             cur = Y
         if need:
             ctx.rec, ctx.stages, ctx.params, ctx.W, ctx.slots, ctx.owners, ctx.training = rec, stages, params, W, slots, owners, training
@@ -1209,18 +1225,20 @@ class _RowLinChain(torch.autograd.Function):
             gT = torch.empty((N + 63) // 64 * 64, Mp, device=dev, dtype=torch.bfloat16)
             a.w16t, a.gT = W['s%d' % i][1], ptr(gT)
             a.oh_ntok = st.onehot[0] if st.onehot else 0
-            nb = None
+            nb, sync_sums = None, None
             if st.bn_in is not None:
                 ig, ib, eps, relu = st.bn_in
                 mean, var = R['bn']
                 a.X, a.ldx = ptr(R['X']), R['X'].stride(0)
                 a.bn_mean, a.bn_var, a.bn_g, a.bn_b, a.bn_eps, a.bn_relu = ptr(mean), ptr(var), ptr(params[ig]), ptr(params[ib]), eps, int(relu)
                 part = torch.empty(2 * G * Cin, device=dev, dtype=torch.float32)
-                s1, s2 = torch.empty(Cin, device=dev, dtype=torch.float32), torch.empty(Cin, device=dev, dtype=torch.float32)
+                s12 = torch.empty(2, Cin, device=dev, dtype=torch.float32)
+                s1, s2 = s12[0], s12[1]
                 a.st_part, a.s1, a.s2 = ptr(part), ptr(s1), ptr(s2)
                 a.dgamma, a.dbeta = gbuf(ig, True).data_ptr(), gbuf(ib, True).data_ptr()
-                nb = (ptr(R['X']), ptr(mean), ptr(var), ptr(params[ig]), ptr(s1), ptr(s2), eps, float(M) if training else 0.0)
-                keep += [part, s1, s2]
+                nb = (ptr(R['X']), ptr(mean), ptr(var), ptr(params[ig]), ptr(s1), ptr(s2), eps, R['bn_count'] if training else 0.0)
+                keep += [part, s12]
+                sync_sums = s12 if (training and i > 0 and stages[i - 1].sync is not None) else None
             rows_in = R['X'].shape[0]
             dX = torch.empty(rows_in, Cin, device=dev, dtype=torch.float32)
             if st.gather:
@@ -1228,6 +1246,10 @@ class _RowLinChain(torch.autograd.Function):
                 a.g_arg = ptr(R['g_arg'])
             a.dX, a.lddx = ptr(dX), Cin
             call('mvf_rowlin_bwd', ctypes.byref(a), stream())
+            if sync_sums is not None:
+                # SyncBatchNorm backward: sum dZ and sum dZ xhat over ALL ranks' rows (collective C3 of SURVEY.md) before the previous
+                # stage's launch applies them; dgamma / dbeta stay local (the gradient all-reduce averages them like every parameter)
+                dist.all_reduce(sync_sums, group=stages[i - 1].sync[0])
             probs.append((gT, R['xT'], st.w, st.b, N, Kin))
             keep.append(gT)
             dcur = dX

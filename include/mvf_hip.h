@@ -573,6 +573,10 @@ int mvf_grad_norm(const float* g, size_t n, const float* extra_sq, float* scratc
 int mvf_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, float clip, const float* norm, float gscale, int zero_grad,
                   hipStream_t stream);
+/* compute units the optimizer's two launches may hold: 0 = wide forms (every CU that falls free), > 0 = that many whole-CU workgroups
+ * (beside the persistent backbone GEMM a CU with any optimizer workgroup on it is lost to the GEMM: few CUs for longer cost the pipelined
+ * step less than all CUs briefly).  Default: env MVF_OPT_WIDTH, else the library's measured choice. */
+int mvf_optim_set_width(int cus);
 
 /* ------------------------------------------------------------------------------------------------
  * GPU-side view augmentation: one clip [T,3,H,W] of floats in [0,1] -> [T,3,S,S], normalised

@@ -114,6 +114,7 @@ SIGNATURES = {
     'mvf_scl_select': 'i',
     'mvf_grad_norm': 'pzpppp',
     'mvf_adam_step': 'ppppzfffffifpfip',
+    'mvf_optim_set_width': 'i',
     'mvf_augment_workspace_bytes': 'iii',
     'mvf_augment_clips': 'ppiiiiippzp',
 }

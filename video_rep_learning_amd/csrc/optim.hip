@@ -107,7 +107,93 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   }
 }
 
+// The same update on FEW compute units: 1 024-thread workgroups that each take a CU to themselves (launched with a large dynamic LDS
+// request), float4 accesses, two batches of loads in flight per thread.  The wide form puts 2 048 small workgroups on every CU that
+// falls free; beside the frozen backbone's persistent GEMM (one 512-register workgroup per CU) each of those CUs is then lost to the
+// GEMM until its last optimizer workgroup has gone -- the optimizer's 37 us cost the pipelined step 0.10 - 0.13 ms.  Narrow, it
+// holds `width` CUs for longer instead (mvf_optim_set_width).  All four pointers 16-byte aligned, n4 = n / 4 vectors.
+constexpr int AD_TH = 1024;
+__global__ __launch_bounds__(AD_TH) void adam_narrow_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                            float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                                                            float wd, float bc1, float bc2_sqrt, float clip,
+                                                            const float* __restrict__ norm, float gscale, int step_no, int zero_grad) {
+  float coef = gscale;
+  const size_t n4 = n / 4, stride = (size_t)gridDim.x * AD_TH, t0 = (size_t)blockIdx.x * AD_TH + threadIdx.x;
+  if (norm != nullptr) {
+    if (!isfinite(norm[0])) {
+      if (zero_grad)
+        for (size_t i = t0; i < n; i += stride) g[i] = 0.f;
+      return;
+    }
+    const float skipped = norm[1];
+    if (skipped > 0.f) {
+      const double eff = fmax((double)step_no - (double)skipped, 1.0);
+      bc1 = (float)(1.0 - pow((double)b1, eff));
+      bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, eff));
+    }
+    if (clip > 0.f) coef *= fminf(1.f, clip / (norm[0] * gscale + 1e-6f));
+  }
+  const float step = lr / bc1;
+  auto upd = [&](float pi, float gr, float mo, float vo, float& po, float& mn, float& vn) {
+    const float gi = gr * coef + wd * pi;
+    mn = b1 * mo + (1.f - b1) * gi;
+    vn = b2 * vo + (1.f - b2) * gi * gi;
+    po = pi - step * mn / (sqrtf(vn) / bc2_sqrt + eps);
+  };
+  f32x4_t* p4 = reinterpret_cast<f32x4_t*>(p);
+  f32x4_t* g4 = reinterpret_cast<f32x4_t*>(g);
+  f32x4_t* m4 = reinterpret_cast<f32x4_t*>(m);
+  f32x4_t* v4 = reinterpret_cast<f32x4_t*>(v);
+  constexpr int U = 2;
+  for (size_t i0 = t0; i0 < n4; i0 += U * stride) {
+    f32x4_t pv[U], gv[U], mv[U], vv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + u * stride < n4 ? i0 + u * stride : n4 - 1;
+      pv[u] = p4[i];
+      gv[u] = NT_LD(g4 + i);
+      mv[u] = NT_LD(m4 + i);
+      vv[u] = NT_LD(v4 + i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + u * stride;
+      if (i >= n4) break;
+      f32x4_t po, mn, vn;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a, b, c;
+        upd(pv[u][e], gv[u][e], mv[u][e], vv[u][e], a, b, c);
+        po[e] = a; mn[e] = b; vn[e] = c;
+      }
+      NT_ST(m4 + i, mn);
+      NT_ST(v4 + i, vn);
+      p4[i] = po;
+      if (zero_grad) NT_ST(g4 + i, ((f32x4_t){0.f, 0.f, 0.f, 0.f}));
+    }
+  }
+  if (blockIdx.x == 0)       // the n % 4 tail
+    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += AD_TH) {
+      float po, mn, vn;
+      upd(p[i], g[i], m[i], v[i], po, mn, vn);
+      m[i] = mn; v[i] = vn; p[i] = po;
+      if (zero_grad) g[i] = 0.f;
+    }
+}
+
+// compute units the optimizer's two launches may hold (0 = the wide forms); env MVF_OPT_WIDTH.  Measured beside the backbone forwards
+// (tools/stretch_parts.py --parts none,opt; ms the optimizer adds to the step): wide 0.055, 16 CUs 0.053, 32: 0.043, 64: 0.030,
+// 128: 0.045, 256: 0.07 -- profiles/r05/opt_width.txt
+int g_opt_width = [] { const char* e = getenv("MVF_OPT_WIDTH"); return e ? atoi(e) : 64; }();
+constexpr size_t OPT_LDS_HOLD = 96 * 1024;      // dynamic LDS request that keeps a second workgroup off the CU
+
 }  // namespace
+
+extern "C" int mvf_optim_set_width(int cus) {
+  MVF_CHECK_ARG(cus >= 0 && cus <= 256);
+  g_opt_width = cus;
+  return MVF_OK;
+}
 
 // norm_out[0] = || g ||_2 (optionally sqrt(||g||^2 + extra_sq[0])); norm_out[1] (zeroed ONCE by the caller) counts the
 // calls whose norm was not finite; scratch: >= 1024 floats
@@ -115,8 +201,15 @@ extern "C" int mvf_grad_norm(const float* g, size_t n, const float* extra_sq, fl
                              hipStream_t st) {
   MVF_CHECK_ARG(g && scratch && norm_out && n > 0 && ((uintptr_t)g & 15) == 0);
   // 256 workgroups at most: every arrival is one atomic on the same ticket word (~11 ns each, serialised)
-  const int nblk = (int)std::min<size_t>(256, (n / 4 + SQ_TH - 1) / SQ_TH + 1);
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(nblk), dim3(SQ_TH), 0, st, g, n, scratch, extra_sq, norm_out);
+  int nblk = (int)std::min<size_t>(256, (n / 4 + SQ_TH - 1) / SQ_TH + 1);
+  size_t lds = 0;
+  if (g_opt_width > 0) {       // narrow form: `width` workgroups, each alone on its CU
+    static uint64_t attr = 0;
+    if (mvf_ensure_lds(reinterpret_cast<const void*>(sqnorm_kernel), OPT_LDS_HOLD, attr) != MVF_OK) return MVF_ERR_UNSUPPORTED;
+    nblk = std::min(nblk, g_opt_width);
+    lds = OPT_LDS_HOLD;
+  }
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(nblk), dim3(SQ_TH), lds, st, g, n, scratch, extra_sq, norm_out);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }
@@ -132,6 +225,15 @@ extern "C" int mvf_adam_step(float* p, float* g, float* m, float* v, size_t n, f
   MVF_CHECK_ARG(p && g && m && v && n > 0 && step >= 1);
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  if (g_opt_width > 0 && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && n >= 4) {
+    static uint64_t attr = 0;
+    if (mvf_ensure_lds(reinterpret_cast<const void*>(adam_narrow_kernel), OPT_LDS_HOLD, attr) != MVF_OK) return MVF_ERR_UNSUPPORTED;
+    const int nb = (int)std::min<size_t>(g_opt_width, (n / 4 + AD_TH - 1) / AD_TH);
+    hipLaunchKernelGGL(adam_narrow_kernel, dim3(nb), dim3(AD_TH), OPT_LDS_HOLD, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                       bc1, bc2s, clip, norm, gscale, step, zero_grad);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+  }
   const int nblk = (int)std::min<size_t>(2048, (n + 255) / 256);
   hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1,
                      bc2s, clip, norm, gscale, step, zero_grad);

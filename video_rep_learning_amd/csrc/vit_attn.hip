@@ -13,6 +13,7 @@
 //    (or 2-byte gathers, selectable, used to cross-check the transposing read on hardware)
 //  * f32 (parity mode): v_mfma_f32_16x16x4_f32, exact fp32
 //  * online softmax across key blocks (only one block for N = 197)
+#include <type_traits>
 #include "common.h"
 #include "mvf_hip_internal.h"
 #include "vit_attn_tiles.h"
@@ -304,6 +305,8 @@ __global__ __launch_bounds__(256, OCC) void vit_attn_bf16_pair_kernel(AttnArgs a
 // (280 TFLOP/s at N = 785, 160 at N = 257); this one keeps 2 x KT*16 keys in flight per workgroup.  Measured, F = 80,
 // N = 785: KT = 6 (96 keys, 168 VGPRs, 3 waves/SIMD) 295 us = 514 TFLOP/s; KT = 4 (4 waves/SIMD) 345; KT = 2 344; KT = 8
 // (2 waves/SIMD) 523; 8 waves per workgroup with KT = 4: 365.  N = 257 (F = 256): 149 / 166 / 192 / 355 / 240 us.
+// Round 5: the last key block walks only the key tiles that hold keys (N = 16 k + 1 with the CLS token leaves ONE key in the last
+// 96-key block at N = 577, 17 at N = 785): 652.8 -> 613.0 us (F = 256, N = 577), 313.8 -> 290.7 us (F = 80, N = 785), bit-identical.
 template <int KT, int OCC, int NW = 4, bool F16 = false>
 __global__ __launch_bounds__(NW * 64, OCC) void vit_attn_bf16_flash_kernel(AttnArgs a) {
   constexpr int KROWS = KT * 16;               // keys per block
@@ -353,18 +356,14 @@ __global__ __launch_bounds__(NW * 64, OCC) void vit_attn_bf16_flash_kernel(AttnA
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[i][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  issue(0);
-  for (int b = 0; b < nblk; ++b) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of block b
-    __builtin_amdgcn_s_barrier();                      // everyone's pieces; and everyone is done with block b-1's buffer
-    if (b + 1 < nblk) issue(b + 1);
-    if (!active) continue;
-    const char* sk = smem + (b & 1) * 2 * BLK;
-    const char* sv = sk + BLK;
-    const int nkeys = a.N - b * KROWS;                 // valid keys in this block (>= KROWS except in the last block)
-    f32x4_t s[2][KT];
+  // one key block: KTB (<= KT, even) key tiles of it take part -- full blocks run KT, the last block only the tiles that hold keys
+  // (N = 16 k + 1 with the CLS token: one key in a 96-key block at N = 577, 17 at N = 785).  Skipped tiles would contribute exact zeros
+  // (masked scores -> weight 0), so the result is bit-identical to walking all KT.
+  auto block = [&](auto ktb_tag, const char* sk, const char* sv, int nkeys) __attribute__((always_inline)) {
+    constexpr int KTB = decltype(ktb_tag)::value;
+    f32x4_t s[2][KTB];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
+    for (int kt = 0; kt < KTB; ++kt) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) s[i][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -374,11 +373,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void vit_attn_bf16_flash_kernel(AttnA
         for (int i = 0; i < 2; ++i) s[i][kt] = mfma16x16x32<F16>(kf, qf[i][ks], s[i][kt]);
       }
     }
-    if (nkeys < KROWS) {                               // last block: keys beyond N never win the max and get weight 0
+    if (nkeys < KTB * 16) {                            // last block: keys beyond N never win the max and get weight 0
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+        for (int kt = 0; kt < KTB; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[i][kt][r] = kt * 16 + 4 * g + r < nkeys ? s[i][kt][r] : -1e30f;
     }
@@ -386,7 +385,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void vit_attn_bf16_flash_kernel(AttnA
     for (int i = 0; i < 2; ++i) {
       float mx = -1e30f;     // 3-input maxima and packed fp32 arithmetic: see attn_tiles
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) mx = max3f(max3f(mx, s[i][kt][0], s[i][kt][1]), s[i][kt][2], s[i][kt][3]);
+      for (int kt = 0; kt < KTB; ++kt) mx = max3f(max3f(mx, s[i][kt][0], s[i][kt][1]), s[i][kt][2], s[i][kt][3]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[i], mx);
@@ -394,7 +393,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void vit_attn_bf16_flash_kernel(AttnA
       const f32x2_t sc2 = {a.scale_log2, a.scale_log2}, nm2 = {nm, nm};
       f32x2_t ls2 = {0.f, 0.f};
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
+      for (int kt = 0; kt < KTB; ++kt) {
         const f32x2_t e0 = pk_fma((f32x2_t){s[i][kt][0], s[i][kt][1]}, sc2, nm2);
         const f32x2_t e1 = pk_fma((f32x2_t){s[i][kt][2], s[i][kt][3]}, sc2, nm2);
         const f32x2_t p0 = {__builtin_amdgcn_exp2f(e0[0]), __builtin_amdgcn_exp2f(e0[1])};
@@ -414,7 +413,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void vit_attn_bf16_flash_kernel(AttnA
         for (int r = 0; r < 4; ++r) o[i][dt][r] *= alpha;
     }
 #pragma unroll
-    for (int st = 0; st < KT / 2; ++st) {
+    for (int st = 0; st < KTB / 2; ++st) {
       union { bf16x8_t v; uint32_t u[4]; } pf[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -433,8 +432,27 @@ __global__ __launch_bounds__(NW * 64, OCC) void vit_attn_bf16_flash_kernel(AttnA
         for (int i = 0; i < 2; ++i) o[i][dt] = mfma16x16x32<F16>(vf.v, pf[i].v, o[i][dt]);
       }
     }
+  };
+
+  issue(0);
+  for (int b = 0; b + 1 < nblk; ++b) {                 // full blocks
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of block b
+    __builtin_amdgcn_s_barrier();                      // everyone's pieces; and everyone is done with block b-1's buffer
+    issue(b + 1);
+    if (!active) continue;
+    const char* sk = smem + (b & 1) * 2 * BLK;
+    block(std::integral_constant<int, KT>{}, sk, sk + BLK, KROWS);
   }
-  if (!active) return;
+  {                                                    // the last block: only the key tiles that hold keys
+    const int b = nblk - 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (!active) return;
+    const char* sk = smem + (b & 1) * 2 * BLK;
+    const int nkeys = a.N - b * KROWS;
+    if (KT >= 6 && nkeys <= 32) block(std::integral_constant<int, 2>{}, sk, sk + BLK, nkeys);
+    else block(std::integral_constant<int, KT>{}, sk, sk + BLK, nkeys);
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int q = (qt0 + i) * 16 + li;

@@ -55,3 +55,37 @@ def test_skipped_steps_state_dict_and_reload(clip):
     ref.step(max_norm=clip)
     for a, b in zip(ps, ref_ps):
         assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('n', [4_801_536, 1027, 3])
+def test_narrow_and_wide_optimizer_launches_agree(n):
+    """mvf_optim_set_width: the gradient norm and the Adam update on few whole-CU workgroups (the product default) against the wide forms:
+    the same arithmetic per element (parameters and both moments equal to the last bits given the same clip coefficient), the norm up to
+    its summation order; an n % 4 tail and a tensor smaller than one vector included."""
+    from video_rep_learning_amd import _lib
+    g = torch.Generator().manual_seed(n)
+    base = [torch.randn(n, generator=g).to(DEV) for _ in range(3)] + [torch.rand(n, generator=g).to(DEV)]
+    st = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    try:
+        common = None
+        for width in (0, 64, 7):
+            _lib.call('mvf_optim_set_width', width)
+            p, gr, m, v = (t.clone() for t in base)
+            scratch, norm = torch.zeros(1024, device=DEV), torch.zeros(2, device=DEV)
+            _lib.call('mvf_grad_norm', gr.data_ptr(), n, None, scratch.data_ptr(), norm.data_ptr(), st)
+            if common is None:
+                common = norm.clone()        # every form's update uses the SAME clip coefficient
+            _lib.call('mvf_adam_step', p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-2, 0.9, 0.999, 1e-8, 1e-5, 3, 10.0,
+                      common.data_ptr(), 1.0, 1, st)
+            torch.cuda.synchronize()
+            outs[width] = (p.cpu(), m.cpu(), v.cpu(), gr.cpu(), norm.cpu())
+    finally:
+        _lib.call('mvf_optim_set_width', 64)
+    ref_norm = base[1].double().norm().item()
+    for width in (0, 64, 7):
+        assert abs(outs[width][4][0].item() - ref_norm) <= 1e-5 * ref_norm, (width, outs[width][4], ref_norm)
+        assert float(outs[width][3].abs().max()) == 0.0                      # zero_grad inside the pass
+        # (hipcc contracts a * b + c into fmas differently in the vector and the scalar kernel: last-bit differences, no more)
+        for a, b in zip(outs[width][:3], outs[0][:3]):
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), (width, (a - b).abs().max())

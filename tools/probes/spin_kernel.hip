@@ -1,6 +1,10 @@
-// Diagnostic (GPU box, tools/step_timeline.py --dummy spin:...): a kernel that only occupies resources -- `grid` workgroups of 256
-// threads, `lds` bytes of dynamic LDS each, spinning for `us` microseconds on the constant 100 MHz s_memtime clock -- to find out
-// what it is about the head's kernels that stretches the backbone forward running beside them.
+// Diagnostic (GPU box, tools/step_timeline.py --dummy spin...): kernels that only occupy resources, to find out what it is about the
+// head's kernels that stretches the backbone forward running beside them.
+//   spin_launch : `grid` workgroups of 256 threads, `lds` bytes of dynamic LDS each, sleeping for `us` microseconds (s_memtime, 100 MHz)
+//   spin_launch2: `grid` workgroups of `threads` threads, `lds` bytes of LDS, busy for `us` microseconds with
+//                 mode 0 = s_sleep, 1 = every wave streams the first `bytes` of `buf` over and over (16-byte loads, default cache policy:
+//                 L2 hits after the first pass -- what a row-chain workgroup's weight stream looks like), 2 = a dependent MFMA chain,
+//                 3 = LDS reads / writes
 //   hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/probes/libspin.so tools/probes/spin_kernel.hip
 #include <hip/hip_runtime.h>
 __global__ __launch_bounds__(256) void spin_kernel(int ticks, float* out) {
@@ -15,5 +19,43 @@ extern "C" int spin_launch(int grid, int lds, int us, float* out, hipStream_t st
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   hipLaunchKernelGGL(spin_kernel, dim3(grid), dim3(256), lds, st, us * 100, out);
+  return (int)hipGetLastError();
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(1024) void spin2_kernel(int ticks, int mode, const u32x4* __restrict__ buf, size_t n16, unsigned* sink) {
+  extern __shared__ float smem[];
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  unsigned acc = 0;
+  f32x4 c = {0.f, 0.f, 0.f, 0.f};
+  size_t i = threadIdx.x;
+  while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)ticks) {
+    if (mode == 0) {
+      __builtin_amdgcn_s_sleep(8);
+    } else if (mode == 1) {
+      u32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { v[u] = buf[i]; i += blockDim.x; if (i >= n16) i = threadIdx.x; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc ^= v[u][0] ^ v[u][3];
+    } else if (mode == 2) {
+      bf16x8 a = {1, 2, 3, 4, 5, 6, 7, 8};
+#pragma unroll
+      for (int u = 0; u < 16; ++u) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, a, c, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { smem[(threadIdx.x + 64 * u) & 8191] += 1.0f; }
+      __syncthreads();
+    }
+  }
+  if (sink != nullptr && (acc == 0x9e3779b9u || c[0] == 12345.f)) *sink = acc;
+}
+extern "C" int spin_launch2(int grid, int threads, int lds, int us, int mode, const void* buf, size_t bytes, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spin2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  if (lds < 32768 && mode == 3) lds = 32768;
+  hipLaunchKernelGGL(spin2_kernel, dim3(grid), dim3(threads), lds, st, us * 100, mode, reinterpret_cast<const u32x4*>(buf), bytes / 16, (unsigned*)nullptr);
   return (int)hipGetLastError();
 }

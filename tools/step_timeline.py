@@ -30,6 +30,8 @@ def main():
     p.add_argument('--fwd-only', action='store_true', help='head forward + loss only (no backward, no optimizer)')
     p.add_argument('--dummy', default='', help="instead of the head: 'tiny:N' = N one-workgroup elementwise launches per step, "
                                                "'gemm:N' = N head-sized fp32 GEMM launches (768 x 512 x 512) per step")
+    p.add_argument('--prof', type=int, default=0, help='after the timed loop: N more steps with the library\'s per-launch HIP events around '
+                                                       'every backbone GEMM / fused qkv + attention launch (pipelined, both lanes)')
     a = p.parse_args()
     dev = torch.device('cuda', 0)
     cfg = presets.baseline_config_2('bf16')
@@ -69,6 +71,7 @@ def main():
     spin = None
     if a.dummy.startswith('spin'):
         spin = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'probes', 'libspin.so'))
+    spin_buf = torch.zeros(32 * 1024 * 1024, device=dev, dtype=torch.bfloat16)      # up to 64 MB (default footprint 1.5 MB: one encoder layer's weight images)
     dummy_small = torch.zeros(256, device=dev)
     dummy_x, dummy_w = torch.randn(768, 512, device=dev), torch.randn(512, 512, device=dev)
     dummy_o, dummy_o2 = torch.zeros(3, 384, device=dev), torch.zeros(768, 512, device=dev)
@@ -84,6 +87,12 @@ def main():
             for _ in range(int(cnt)):
                 if kind == 'tiny':
                     dummy_small.add_(1.0)
+                elif kind.startswith('spin2'):   # spin2-<grid>-<threads>-<lds bytes>-<us>-<mode>:N   (mode 0 sleep, 1 L2 stream, 2 MFMA, 3 LDS)
+                    _f = [int(v) for v in kind.split('-')[1:]]
+                    _g, _t, _l, _u, _m = _f[:5]
+                    _kb = _f[5] if len(_f) > 5 else 1536      # footprint of the streamed buffer in KB
+                    spin.spin_launch2(_g, _t, _l, _u, _m, ctypes.c_void_p(spin_buf.data_ptr()), ctypes.c_size_t(_kb * 1024),
+                                      ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
                 elif kind.startswith('spin'):    # spin-<grid>-<lds bytes>-<us>:N   (tools/probes/spin_kernel.hip)
                     _g, _l, _u = (int(v) for v in kind.split('-')[1:])
                     spin.spin_launch(_g, _l, _u, None, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
@@ -136,6 +145,24 @@ def main():
     gap = sum(bs[i + 1] - be[i] for i in range(n - 1)) / (n - 1)
     print('wall %.3f ms/step (host enqueue %.3f ms/step);  backbone period %.3f ms, forward start-to-end %.3f ms, idle gap between forwards '
           '%.3f ms' % (wall, sum(host[n0:]) / len(host[n0:]) * 1e3, period, dur, gap))
+    if a.prof:
+        torch.cuda.synchronize()
+        _lib.call('mvf_prof_enable', 1)
+        for _ in range(a.prof):
+            step()
+        torch.cuda.synchronize()
+        _lib.call('mvf_prof_enable', 0)
+        G = 16
+        ms, fl = (ctypes.c_double * G)(), (ctypes.c_double * G)()
+        cnt, epi, nn, kk = (ctypes.c_int * G)(), (ctypes.c_int * G)(), (ctypes.c_int * G)(), (ctypes.c_int * G)()
+        ng = ctypes.c_int(0)
+        _lib.call('mvf_prof_collect', ms, fl, cnt, epi, nn, kk, G, ctypes.byref(ng))
+        tot = 0.0
+        for g in range(ng.value):
+            print('   launches epi %d N %4d K %4d: %5.1f per step, avg %7.1f us, %7.3f ms per step (both lanes)' % (
+                epi[g], nn[g], kk[g], cnt[g] / a.prof, ms[g] * 1e3 / max(cnt[g], 1), ms[g] / a.prof))
+            tot += ms[g] / a.prof
+        print('   sum over the GEMM / fused launches: %.3f ms per step = %.3f ms per lane' % (tot, tot / 2))
     if not a.no_head and not a.dummy:
         # the head of batch k (consumes the forward launched one step earlier) against the forward running beside it
         he = [ref.elapsed_time(e) for e in h_end[n0:]]

@@ -1036,6 +1036,40 @@ def test_batch_norm_fwd_bwd(training, relu):
         check(rv, pr['bn.running_var'], 1e-5, 'running_var')
 
 
+def test_two_stage_reductions_in_flight_on_two_streams():
+    """Kernels that finish their reduction in the workgroup that arrives last (common.h last_arriver) take their ticket word from a ring per
+    kernel family (mvf_hip_internal.h TicketRing): launches of one family in flight on two streams at once must not disturb each other.
+    BatchNorm statistics (a ticket per column block) and the gradient norm, 40 rounds on two streams against each stream's own inputs."""
+    g = gen(31)
+    R, Cn = 768, 512
+    xs = [(torch.randn(R, Cn, generator=g) * (1 + i) + i).to(DEV) for i in range(2)]
+    gs = [torch.randn(1 << 20, generator=g).to(DEV) * (1 + i) for i in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    lib = _lib.load()
+    ws = [torch.empty(lib.mvf_bn_workspace_floats(R, Cn), device=DEV) for _ in range(2)]
+    scr = [torch.zeros(1024, device=DEV) for _ in range(2)]
+    outs = [[], []]
+    torch.cuda.synchronize()
+    for _ in range(40):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                mean, var, nrm = torch.empty(Cn, device=DEV), torch.empty(Cn, device=DEV), torch.zeros(2, device=DEV)
+                st = streams[i].cuda_stream
+                _lib.call('mvf_bn_stats', xs[i].data_ptr(), R, Cn, mean.data_ptr(), var.data_ptr(), None, None, 0.1, ws[i].data_ptr(),
+                          ws[i].numel(), st)
+                _lib.call('mvf_grad_norm', gs[i].data_ptr(), gs[i].numel(), None, scr[i].data_ptr(), nrm.data_ptr(), st)
+                outs[i].append((mean, var, nrm))
+    torch.cuda.synchronize()
+    for i in range(2):
+        rm, rv = xs[i].double().mean(0), xs[i].double().var(0, unbiased=False)
+        rn = gs[i].double().norm().item()
+        for mean, var, nrm in outs[i]:
+            assert torch.equal(mean, outs[i][0][0]) and torch.equal(var, outs[i][0][1]) and torch.equal(nrm, outs[i][0][2])
+        check(outs[i][0][0], rm, 1e-5, 'mean on stream %d' % i)
+        check(outs[i][0][1], rv, 1e-5, 'var on stream %d' % i)
+        assert abs(outs[i][0][2][0].item() - rn) <= 1e-5 * rn
+
+
 # dk = 32 / 8 / 32 / 64 / 16: the matrix-core kernels serve dk in {16, 32, 64}, the scalar ones the rest; `scalar` forces the
 # scalar kernels so both implementations are checked on the same cases
 @pytest.mark.parametrize('scalar', [0, 1])

@@ -124,7 +124,8 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t offset, uint64
 // Nobody waits for anybody (no co-residency assumption).  Agent-scope release on the way in, acquire in the last arriver (per-XCD L2s
 // are not coherent and a CU's L1 is never refreshed by other CUs' stores: /opt/skills/guides/MI355X_MICROARCH.md, "Valid forms"); the
 // explicit s_waitcnt keeps the ticket from overtaking the write-back.  `ticket` is a zero-initialised device word that the last
-// arriver resets, so launches that share it must be ordered on one stream.
+// arriver resets; launches that could be in flight together (different streams) must not share one: the callers take theirs from a ring
+// of TICKET_SLOTS words per kernel family (mvf_hip_internal.h TicketRing).
 __device__ __forceinline__ bool last_arriver(unsigned* ticket, unsigned n) {
   __shared__ int s_last_arriver;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

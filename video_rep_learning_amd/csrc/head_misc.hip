@@ -100,11 +100,12 @@ __host__ __device__ inline int bn_splits(int rows) { return rows >= 1024 ? 32 : 
 // (plain E[x^2] - E[x]^2 would cancel catastrophically in fp32 when |mean| >> std)
 // (stage 2 runs in the same launch: the last of a column block's RS workgroups to arrive adds the partial sums -- common.h
 // last_arriver, one ticket per column block)
-__device__ unsigned g_bn_ticket[512];
+__device__ unsigned g_bn_ticket[TICKET_SLOTS][512];
+TicketRing g_bn_ring;
 
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int rows, int C, int RS, float* __restrict__ ws,
                                                        float* __restrict__ mean, float* __restrict__ var, float* __restrict__ rmean,
-                                                       float* __restrict__ rvar, float momentum) {
+                                                       float* __restrict__ rvar, float momentum, int ticket) {
   __shared__ float r1[4][64], r2[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl, rs = blockIdx.y;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     ws[((size_t)rs * 2 + 1) * C + c] = r2[0][cl] + r2[1][cl] + r2[2][cl] + r2[3][cl];
   }
   // stage 2: mean, biased variance; optionally the running statistics (nn.BatchNorm1d: momentum, unbiased variance)
-  if (!last_arriver(&g_bn_ticket[blockIdx.x], (unsigned)RS)) return;
+  if (!last_arriver(&g_bn_ticket[ticket][blockIdx.x], (unsigned)RS)) return;
   if (rl != 0 || c >= C) return;
   a = 0.f; b = 0.f;
   for (int q = 0; q < RS; ++q) { a += ws[((size_t)q * 2 + 0) * C + c]; b += ws[((size_t)q * 2 + 1) * C + c]; }
@@ -149,14 +150,16 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ x
 // s1[c] = sum_r dy_eff ; s2[c] = sum_r dy_eff * xhat     (dy_eff = dy * [bn(x) > 0] when relu); stage 1: partial sums
 // stage 2 (the last of a column block's RS workgroups): s1, s2 and (optionally) the parameter gradients dbeta (+)= s1,
 // dgamma (+)= s2 of THIS rank's rows
-__device__ unsigned g_bn_bwd_ticket[512];
+__device__ unsigned g_bn_bwd_ticket[TICKET_SLOTS][512];
+TicketRing g_bn_bwd_ring;
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ var,
                                                             const float* __restrict__ g, const float* __restrict__ b,
                                                             float* __restrict__ ws, int rows, int C, int RS, float eps,
                                                             int relu, float* __restrict__ s1, float* __restrict__ s2,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                                            int ticket) {
   __shared__ float r1[4][64], r2[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl, rs = blockIdx.y;
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     ws[((size_t)rs * 2 + 0) * C + c] = r1[0][cl] + r1[1][cl] + r1[2][cl] + r1[3][cl];
     ws[((size_t)rs * 2 + 1) * C + c] = r2[0][cl] + r2[1][cl] + r2[2][cl] + r2[3][cl];
   }
-  if (!last_arriver(&g_bn_bwd_ticket[blockIdx.x], (unsigned)RS)) return;
+  if (!last_arriver(&g_bn_bwd_ticket[ticket][blockIdx.x], (unsigned)RS)) return;
   if (rl != 0 || c >= C) return;
   float sa = 0.f, sb = 0.f;
   for (int q = 0; q < RS; ++q) { sa += ws[((size_t)q * 2 + 0) * C + c]; sb += ws[((size_t)q * 2 + 1) * C + c]; }
@@ -397,7 +400,7 @@ extern "C" int mvf_bn_stats(const float* x, int rows, int C, float* mean, float*
   MVF_CHECK_ARG(ws_floats >= (size_t)RS * 2 * C);
   MVF_CHECK_ARG(ceil_div(C, 64) <= 512);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(ceil_div(C, 64), RS), dim3(256), 0, st, x, rows, C, RS, ws, mean, var, running_mean,
-                     running_var, momentum);
+                     running_var, momentum, g_bn_ring.take());
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }
@@ -422,7 +425,7 @@ extern "C" int mvf_bn_bwd_reduce(const float* dy, const float* x, const float* m
   MVF_CHECK_ARG(ws_floats >= (size_t)RS * 2 * C);
   MVF_CHECK_ARG(ceil_div(C, 64) <= 512);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(C, 64), RS), dim3(256), 0, st, dy, x, mean, var, g, b, ws, rows, C,
-                     RS, eps, relu, s1, s2, dgamma, dbeta, accumulate_params);
+                     RS, eps, relu, s1, s2, dgamma, dbeta, accumulate_params, g_bn_bwd_ring.take());
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

@@ -21,7 +21,8 @@
 namespace {
 using namespace chain;
 
-__device__ unsigned g_rl_ticket_f, g_rl_ticket_b;
+__device__ unsigned g_rl_ticket_f[TICKET_SLOTS], g_rl_ticket_b[TICKET_SLOTS];
+TicketRing g_rl_ring_f, g_rl_ring_b;
 
 // diagnostic (tools/rowlin_probe.py): stage time stamps of workgroup 0, one 16-slot record per launch
 long long* g_rl_stamps = nullptr;
@@ -43,6 +44,7 @@ struct RowLinFwdK {
   bf16_t* xT;
   float *st_part, *st_mean, *st_var, *st_rmean, *st_rvar; float st_momentum;
   long long* stamps;
+  int ticket;
 };
 
 // LDS carve-up (bytes): bf16 input panel, fp32 output panel, per-column (scale, shift) of the input BatchNorm
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(NTH) void rowlin_fwd_kernel(RowLinFwdK k) {
     k.st_part[((size_t)blockIdx.x * 2 + 1) * N + c] = q2;
   }
   RSTAMP(6);
-  if (!last_arriver(&g_rl_ticket_f, gridDim.x)) { RSTAMP(7); return; }
+  if (!last_arriver(&g_rl_ticket_f[k.ticket], gridDim.x)) { RSTAMP(7); return; }
   for (int c = threadIdx.x; c < N; c += NTH) {
     float n = 0.f, mu = 0.f, m2 = 0.f;
     const int nwg = (int)gridDim.x;
@@ -244,6 +246,7 @@ struct RowLinBwdK {
   int g_ntok, g_T, g_mode; const int* g_arg;
   float* dX; long lddx;
   long long* stamps;
+  int ticket;
 };
 
 struct RlLdsB { int ldg, ldd; size_t pg, pd, cst, total; };
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(NTH) void rowlin_bwd_kernel(RowLinBwdK k) {
     k.st_part[((size_t)blockIdx.x * 2 + 1) * Cin + c] = b2;
   }
   RSTAMP(8);
-  if (!last_arriver(&g_rl_ticket_b, gridDim.x)) { RSTAMP(9); return; }
+  if (!last_arriver(&g_rl_ticket_b[k.ticket], gridDim.x)) { RSTAMP(9); return; }
   for (int c = threadIdx.x; c < Cin; c += NTH) {
     float a = 0.f, b2 = 0.f;
     const int nwg = (int)gridDim.x;
@@ -492,6 +495,7 @@ extern "C" int mvf_rowlin_fwd(const MvfRowLinFwd* s, hipStream_t st) {
   k.l2norm = s->l2norm; k.l2_eps = s->l2_eps; k.Y = s->Y; k.nrm = s->nrm; k.xT = (bf16_t*)s->xT;
   k.st_part = s->st_part; k.st_mean = s->st_mean; k.st_var = s->st_var; k.st_rmean = s->st_rmean; k.st_rvar = s->st_rvar; k.st_momentum = s->st_momentum;
   k.stamps = next_stamps();
+  k.ticket = g_rl_ring_f.take();
   static uint64_t a1 = 0, a2 = 0, a4 = 0;
   int rc;
   if (s->N >= 512) rc = launch_fwd(rowlin_fwd_kernel<4>, k, L.total, st, a4);
@@ -527,6 +531,7 @@ extern "C" int mvf_rowlin_bwd(const MvfRowLinBwd* s, hipStream_t st) {
   k.g_ntok = s->g_ntok; k.g_T = s->g_T; k.g_mode = s->g_mode; k.g_arg = s->g_arg; k.dX = s->dX; k.lddx = s->lddx;
   const int Kr = (Kin + 63) & ~63;
   k.stamps = next_stamps();
+  k.ticket = g_rl_ring_b.take();
   static uint64_t a1 = 0, a2 = 0, a4 = 0;
   int rc;
   if (Kr >= 384) rc = launch_bwd(rowlin_bwd_kernel<4>, k, L.total, st, a4);

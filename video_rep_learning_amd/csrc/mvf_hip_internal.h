@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <atomic>
 #include "../../include/mvf_hip.h"
 #include "common.h"
 
@@ -17,6 +18,15 @@ static inline int mvf_ensure_lds(const void* fn, size_t bytes, uint64_t& done_ma
   if (dev < 64) done_mask |= 1ull << dev;
   return MVF_OK;
 }
+
+// Ticket slots for common.h last_arriver(): every launch of a kernel family takes the next of TICKET_SLOTS zero-initialised device
+// words, so launches in flight on DIFFERENT streams never count on the same word (the last arriver resets its word; a collision would
+// need 16 launches of one family in flight at once).
+constexpr int TICKET_SLOTS = 16;
+struct TicketRing {
+  std::atomic<unsigned> next{0};
+  int take() { return (int)(next.fetch_add(1u, std::memory_order_relaxed) % TICKET_SLOTS); }
+};
 
 // ---- backbone ----
 // LayerNorm folded into the GEMMs (bf16 256x256 kernel only): producer side (epi 2) xb / stats, consumer side (epi 0, 1)

@@ -18,7 +18,8 @@ namespace {
 #endif
 
 // ticket of the one-launch norm (zero-initialised with the code object, reset by the last arriver; one optimizer step at a time)
-__device__ unsigned g_sqnorm_ticket;
+__device__ unsigned g_sqnorm_ticket[TICKET_SLOTS];
+TicketRing g_sqnorm_ring;
 
 // norm_out[0] = sqrt(sum g^2 + extra_sq[0]): every workgroup stores its partial sum, the last one to arrive adds them in a fixed
 // order (reproducible) -- one launch instead of a partial and a final one.
@@ -26,7 +27,7 @@ __device__ unsigned g_sqnorm_ticket;
 // torch.cuda.amp.GradScaler.step does for the reference's fp16 path, train.py:127-133: no update, no step count)
 constexpr int SQ_TH = 1024;
 __global__ __launch_bounds__(SQ_TH) void sqnorm_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part,
-                                                       const float* __restrict__ extra_sq, float* __restrict__ norm_out) {
+                                                       const float* __restrict__ extra_sq, float* __restrict__ norm_out, int ticket) {
   __shared__ float red[SQ_TH / 64];
   float s = 0.f;
   const size_t n4 = n / 4, stride = (size_t)gridDim.x * SQ_TH;
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(SQ_TH) void sqnorm_kernel(const float* __restrict__
     for (int w = 0; w < SQ_TH / 64; ++w) a += red[w];
     part[blockIdx.x] = a;
   }
-  if (!last_arriver(&g_sqnorm_ticket, gridDim.x)) return;
+  if (!last_arriver(&g_sqnorm_ticket[ticket], gridDim.x)) return;
   float t = 0.f;
   for (int i = threadIdx.x; i < (int)gridDim.x; i += SQ_TH) t += part[i];
   t = wave_sum(t);
@@ -209,7 +210,7 @@ extern "C" int mvf_grad_norm(const float* g, size_t n, const float* extra_sq, fl
     nblk = std::min(nblk, g_opt_width);
     lds = OPT_LDS_HOLD;
   }
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(nblk), dim3(SQ_TH), lds, st, g, n, scratch, extra_sq, norm_out);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(nblk), dim3(SQ_TH), lds, st, g, n, scratch, extra_sq, norm_out, g_sqnorm_ring.take());
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

@@ -32,12 +32,14 @@ struct SclArgs {
   float inv_tau, inv_2var;
   int row0, rows;
   float* loss;          // forward: the scalar, written by the workgroup that arrives last (common.h last_arriver)
+  int ticket;           // its ticket slot (mvf_hip_internal.h TicketRing)
 };
 
 // loss = sum(lossrow) / sum(mask), in the launch that produced lossrow: the last workgroup to arrive adds the rows in a fixed order
-__device__ unsigned g_scl_ticket;
+__device__ unsigned g_scl_ticket[TICKET_SLOTS];
+TicketRing g_scl_ring;
 __device__ __forceinline__ void scl_finalize(const SclArgs& a) {
-  if (a.loss == nullptr || !last_arriver(&g_scl_ticket, gridDim.x)) return;
+  if (a.loss == nullptr || !last_arriver(&g_scl_ticket[a.ticket], gridDim.x)) return;
   __shared__ float s1[16], s2[16];
   float x = 0.f, y = 0.f;
   for (int i = threadIdx.x; i < a.M; i += blockDim.x) { x += a.lossrow[i]; y += a.mask[i]; }
@@ -586,6 +588,7 @@ extern "C" int mvf_scl_fwd(const float* emb, const float* step, const float* len
   if (rc != MVF_OK) return rc;
   MVF_CHECK_ARG(loss);
   a.loss = loss;
+  a.ticket = g_scl_ring.take();
   if (scl_mfma_ok(E, T)) {
     MVF_CHECK_ARG(((uintptr_t)emb % 16) == 0);
     constexpr int NW = 8;     // two waves per SIMD at up to 256 registers: room for the look-ahead copies (E = 256: without them)

@@ -174,6 +174,12 @@ int mvf_debug_xcc_map(int* out, int nblocks, int threads, int lds_bytes, hipStre
  * budget so that RCCL's all-reduce / all-gather kernels (DDP / SyncBN of CARL_MVF/train.py:283-286) never wait for a GEMM
  * launch to drain before they get a CU; also the CU count of a CU-masked stream. */
 int mvf_gemm_tc_set_cus(int n);
+/* CUs a persistent launch leaves free where that costs it no tile round (default 32; env MVF_GEMM_SPARE): with one workgroup per CU a
+ * launch stays open until EVERY workgroup has run, so a workgroup whose CU is held by another queue's kernel -- the trainable head's
+ * row-chain launches hold 24 CUs for 30 - 40 us each beside the next batch's backbone -- delays the whole launch, and for the short
+ * lane-sized GEMMs (proj: two rounds of 15 us) by more than their own duration.  A lane-sized proj / fc2 (297 tiles, two rounds) runs on
+ * 224 workgroups as fast as on 256; fc1 (1 188 tiles, five rounds) keeps 240.  0 = one workgroup per CU of the budget. */
+int mvf_gemm_tc_set_spare(int cus);
 /* *out = workgroups a persistent launch uses under the current budget (a multiple of 8, at least 8) */
 int mvf_gemm_tc_get_wgs(int* out);
 /* tile-list order of the persistent 256x256 kernel (speed only, results unchanged): g > 0 = grouped by weight panels -- groups of g

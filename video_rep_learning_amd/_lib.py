@@ -44,6 +44,7 @@ SIGNATURES = {
     'mvf_gemm_tc_debug_ktile': 'i',
     'mvf_gemm_tc_debug_ablate': 'i',
     'mvf_gemm_tc_set_cus': 'i',
+    'mvf_gemm_tc_set_spare': 'i',
     'mvf_gemm_tc_get_wgs': 'p',
     'mvf_gemm_tc_set_ngroup': 'i',
     'mvf_debug_xcc_map': 'piiip',

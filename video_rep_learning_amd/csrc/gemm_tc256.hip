@@ -756,6 +756,11 @@ unsigned* sched_slot() {
   return ring == nullptr ? nullptr : ring + (size_t)(next.fetch_add(1) & 1023u) * 16;
 }
 
+// CUs a persistent launch leaves free where that costs no tile round (see launch_bm); MVF_GEMM_SPARE / mvf_gemm_tc_set_spare
+// Measured on the pipelined training step (profiles/r05/gemm_spare.txt, gemm_spare2.txt; the head's row-chain launches are 24 workgroups):
+// 0 / 16 / 24 spare CUs no gain, 32: -0.15 .. -0.28 ms per step, 40 .. 256: within 0.05 of that; forwards alone +0.08 .. +0.18 ms.
+int g_spare = [] { const char* e = getenv("MVF_GEMM_SPARE"); return e ? atoi(e) : 32; }();
+
 template <int EPI, bool DBG = false, bool LN = false, bool FP8 = false, int ABL = 0, bool ADD2 = false, int BMT = 256, bool F16 = false>
 int launch_bm(const GemmTcArgs& a0, bool persistent, hipStream_t st) {
   GemmTcArgs a = a0;
@@ -784,7 +789,17 @@ int launch_bm(const GemmTcArgs& a0, bool persistent, hipStream_t st) {
   const int ntiles = ((a.M + BMT - 1) / BMT) * ((a.N + BN - 1) / BN);
   // persistent: one workgroup per CU (a multiple of 8 so that every XCD gets the same number); otherwise (A/B
   // measurements) one workgroup per tile -- the same kernel, every workgroup then runs the cold prologue
-  const int grid = persistent ? std::min(ntiles, std::max(8, num_cus() & ~7)) : ntiles;
+  int grid = persistent ? std::min(ntiles, std::max(8, num_cus() & ~7)) : ntiles;
+  // Spare CUs (MVF_GEMM_SPARE = m, mvf_gemm_tc_set_spare): a persistent launch takes 256 - m workgroups where that needs no more
+  // tile rounds than one workgroup per CU (never fewer than the smallest grid with that round count).  A workgroup of a full-width
+  // launch that finds its CU held by another queue's kernel (the head's row-chain workgroups hold theirs for 30 - 40 us) keeps the
+  // whole launch open until it has run -- for the short lane-sized launches (proj: two rounds of 15 us) that wait is longer than the
+  // launch itself.
+  if (g_spare > 0 && persistent && grid < ntiles) {
+    const int rounds = (ntiles + grid - 1) / grid;
+    const int gmin = (((ntiles + rounds - 1) / rounds) + 7) & ~7;
+    grid = std::min(grid, std::max(gmin, (grid - g_spare) & ~7));
+  }
   hipLaunchKernelGGL((gemm_tc256_kernel<EPI, DBG, LN, FP8, ABL, ADD2, BMT, F16>), dim3(grid), dim3(512), lds_bytes, st, a);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
@@ -850,6 +865,12 @@ int launch(const GemmTcArgs& a, bool persistent, hipStream_t st) {
 extern "C" int mvf_gemm_tc_set_cus(int n) {
   MVF_CHECK_ARG(n >= 0 && n <= 4096);
   g_cu_budget = n;
+  return MVF_OK;
+}
+
+extern "C" int mvf_gemm_tc_set_spare(int cus) {
+  MVF_CHECK_ARG(cus >= 0 && cus <= 256);
+  g_spare = cus;
   return MVF_OK;
 }
 

@@ -1280,12 +1280,28 @@ def rowlin_chain(x, stages, params, training, pack, eval_stats=None, tag=''):
                               eval_stats, tag, *params)
 
 
+_SPARE_SET = [None]
+
+
+def _spare_cus_for_rows(rows):
+    """The backbone's persistent GEMM leaves the CUs free that the head's row-chain launches (one workgroup per 32 rows) will hold beside
+    it (include/mvf_hip.h mvf_gemm_tc_set_spare; measured at 24 workgroups: 32 spare CUs -0.15 .. -0.28 ms per step, fewer no gain,
+    more no further gain): 32 up to 1 024 rows, the workgroup count rounded up to a multiple of 8 beyond, 64 at most.  MVF_GEMM_SPARE pins it."""
+    if os.environ.get('MVF_GEMM_SPARE') is not None:
+        return
+    want = max(32, min(64, ((rows + 31) // 32 + 7) // 8 * 8))
+    if _SPARE_SET[0] != want:
+        call('mvf_gemm_tc_set_spare', want)
+        _SPARE_SET[0] = want
+
+
 def encoder_chain(x, mask, layers, H, eps, drops, pack):
     """x [B, S, D] -> [B, S, D].  layers: per EncoderLayer a dict with the 12 parameter tensors in _EncoderChain's order
     ('params'), and for parameters that live in the flat gradient buffer 'slots' (12 gradient views, the Q|K|V one over the
     three projections) + 'owners' (the nn.Parameters to report ready); drops: (p, seed, offset) | None per sub-layer
     (attention, feed-forward) in layer order."""
     B, S, D = x.shape
+    _spare_cus_for_rows(B * S)
     params, slots, owners = [], [], []
     use_slots = x.requires_grad and all(ly.get('slots') is not None for ly in layers)
     for ly in layers:

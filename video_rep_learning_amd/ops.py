@@ -1921,7 +1921,7 @@ VIT_LANE_MIN_ROWS = 22000
 # HIP priority of the streams the frozen backbone runs on (lane streams here, the lookahead stream of the model) and the
 # lane count of a split forward.  Measured in the full step (B = 4, 32 frames): priority -1 = priority 0 (12.14 vs 12.13 ms),
 # 4 lanes 12.75 ms, 2 lanes 12.13 ms, 1 lane 12.48 ms.
-BACKBONE_STREAM_PRIORITY = 0
+BACKBONE_STREAM_PRIORITY = int(os.environ.get('MVF_BACKBONE_PRIORITY', '0'))      # (the variable: A/B measurements)
 VIT_LANES = 2
 
 

@@ -228,6 +228,7 @@ class TransformerModel(nn.Module):
         if not x.is_cuda:          # the first kernel call of a step: fail loudly, there is no CPU compute path
             raise ops._lib.MvfError('the MV-Former forward received a %s tensor: its kernels only run on a gfx950 device '
                                     '(no CPU fallback)' % x.device)
+        ops.gemm_spare_mode(self.training and torch.is_grad_enabled())
         cur = torch.cuda.current_stream(x.device)
         if getattr(self, '_side', None) is None or self._side.device != x.device:
             self._side = torch.cuda.Stream(device=x.device, priority=ops.BACKBONE_STREAM_PRIORITY)

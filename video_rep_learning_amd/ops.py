@@ -1281,6 +1281,20 @@ def rowlin_chain(x, stages, params, training, pack, eval_stats=None, tag=''):
 
 
 _SPARE_SET = [None]
+_SPARE_MODE = [True]
+
+
+def gemm_spare_mode(on):
+    """on: the backbone's forwards run BESIDE head work (training with the one-batch lookahead: models/transformer.py) and the persistent GEMM
+    leaves spare CUs for it; off (evaluation: forward and head one after the other): one workgroup per CU, the spare would only cost."""
+    on = bool(on)
+    if _SPARE_MODE[0] != on:
+        _SPARE_MODE[0] = on
+        if os.environ.get('MVF_GEMM_SPARE') is None:
+            want = 32 if on else 0            # (on: the head's row count refines it, _spare_cus_for_rows)
+            if _SPARE_SET[0] != want:
+                call('mvf_gemm_tc_set_spare', want)
+                _SPARE_SET[0] = want
 
 
 def _spare_cus_for_rows(rows):
@@ -1289,7 +1303,7 @@ def _spare_cus_for_rows(rows):
     more no further gain): 32 up to 1 024 rows, the workgroup count rounded up to a multiple of 8 beyond, 64 at most.  MVF_GEMM_SPARE pins it."""
     if os.environ.get('MVF_GEMM_SPARE') is not None:
         return
-    want = max(32, min(64, ((rows + 31) // 32 + 7) // 8 * 8))
+    want = max(32, min(64, ((rows + 31) // 32 + 7) // 8 * 8)) if _SPARE_MODE[0] else 0
     if _SPARE_SET[0] != want:
         call('mvf_gemm_tc_set_spare', want)
         _SPARE_SET[0] = want

@@ -92,6 +92,35 @@ def test_gemm_tc256_equals_tc128_bitwise(M, N, K, epi):
         check(ref[0], A.double().cpu() @ W.double().cpu().t() + b.double().cpu(), 1e-2, 'gemm_tc256 vs fp64')
 
 
+@pytest.mark.parametrize('M,N,K,epi', [(25216, 768, 768, 0), (25216, 768, 3072, 2), (25216, 3072, 768, 1), (50432, 768, 768, 0)])
+def test_gemm_spare_cus_do_not_change_the_result(M, N, K, epi):
+    """mvf_gemm_tc_set_spare: the persistent launch on fewer workgroups (the product leaves 32 CUs free where that costs no tile round)
+    walks the same tiles -- bitwise the same C / residual / tap whatever the grid (297 tiles on 256, 224, 152 workgroups; 1 188 on 256 / 240;
+    594 on 256 / 224 / 200)."""
+    g = gen(43)
+    A = torch.randn(M, K, generator=g).to(DEV).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(DEV).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(DEV)
+    resid0 = torch.randn(M, N, generator=g).to(DEV) if epi == 2 else None
+    outs = []
+    try:
+        for spare in (0, 32, 104, 248):
+            _lib.call('mvf_gemm_tc_set_spare', spare)
+            Cd = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+            R = resid0.clone() if resid0 is not None else None
+            tap = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16) if epi == 2 else None
+            _lib.call('mvf_gemm_tc', _lib.BF16, epi, A.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), Cd.data_ptr(), N,
+                      _lib.ptr(R), N, _lib.ptr(tap), N, None, None, 197, M, N, K, S())
+            torch.cuda.synchronize()
+            outs.append((Cd, R, tap))
+    finally:
+        _lib.call('mvf_gemm_tc_set_spare', 32)
+    for o in outs[1:]:
+        for x, y in zip(o, outs[0]):
+            if x is not None:
+                assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize('M,N,K,layerscale', [(1000, 768, 768, False), (197 * 40 + 5, 768, 3072, True), (25216, 768, 768, False)])
 def test_gemm_ln_fold_producer_epilogue(M, N, K, layerscale):
     """Residual epilogue with the LN-fold extras (mvf_gemm_tc_ln, epi 2): the fp32 residual stream must be BITWISE what the

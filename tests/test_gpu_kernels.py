@@ -1220,7 +1220,13 @@ def test_lstp_pool_vs_plain_attention(dtype, nq, disjoint):
                                                          ('bf16', 1024, 257, 3, False, 1), ('bf16', 768, 7, 1, False, 3),
                                                          # 3 queries on 3 taps of 1024 channels (ViT-L, BASELINE configs[4]): beyond the
                                                          # VALU form's registers (it hands over to the chain), matrix-core form only
-                                                         ('bf16', 1024, 576, 3, False, 3)])
+                                                         ('bf16', 1024, 576, 3, False, 3),
+                                                         # 4 .. 7 queries (6 entities: fg99_mvf.yml, BASELINE configs[2]): the matrix-core
+                                                         # form with 8-row vector images lying on the token image; the VALU form has no
+                                                         # instantiation there and hands over to the chain
+                                                         ('bf16', 768, 196, 6, False, 3), ('bf16', 768, 784, 6, False, 3),
+                                                         ('bf16', 768, 196, 7, True, 3), ('bf16', 768, 197, 4, False, 1),
+                                                         ('bf16', 1024, 257, 5, False, 1)])
 def test_lstp_one_pass_equals_three_launch(dtype, D, N, nq, per_frame, ntap):
     """The one-pass pooling -- the VALU form (online softmax forward, one-sweep backward) and, for bf16 taps, the matrix-core form
     (csrc/lstp_mfma.hip) -- against the scores / softmax / weighted-sum chain on the same taps: pooled output, attention weights

@@ -56,7 +56,10 @@ __device__ __forceinline__ void split_bf16(float v, bf16_t& hi, bf16_t& lo) {
   lo = f32_to_bf16(v - bf16_to_f32(hi));
 }
 
-template <int NT, int DD>
+// VR: rows of the hi / lo vector images = queries + at least one zero row (the lanes of a tile's padding columns read the last one):
+// 4 for nq <= 3; 8 for nq <= 7 (6 entities: fg99_mvf.yml, BASELINE configs[2]) -- the 8-row images are as large as the token image and lie
+// ON it: they are read into registers once, before tile 0 is stored (C <= 2304 only, where the fragments live in registers)
+template <int NT, int DD, int VR = 4>
 struct LstpShape {
   static constexpr int C = NT * DD;
   static constexpr int KS = C / 256;                 // 32-channel k-steps per wave = 16-byte chunks per thread and tile
@@ -64,20 +67,23 @@ struct LstpShape {
   static constexpr int PITCH = 2 * C + 16;           // bytes per token row of the LDS image
   static constexpr int VP = 2 * C + 16;              // bytes per query row of the hi / lo vector images
   static constexpr int X_BYTES = 16 * PITCH;
-  static constexpr int V_BYTES = 2 * (QP / 4) * VP;  // hi | lo, rows 0 .. 3 (row nq .. 3 zero: the padding columns read row 3)
+  static constexpr int V_BYTES = 2 * VR * VP;        // hi | lo, rows 0 .. VR-1 (rows nq .. VR-1 zero: the padding columns read the last)
+  static constexpr bool ALIAS = VR > 4;              // the vector images share the token image's bytes
+  static_assert(!ALIAS || (V_BYTES <= X_BYTES && KS <= 9), "aliased vector images: as large as the token image at most, fragments in registers");
   static constexpr int RED_BYTES = LW * QP * 16 * 4;
-  static size_t lds_bytes(int nq, int N) { return X_BYTES + V_BYTES + RED_BYTES + (size_t)nq * N * 4 + 2 * QP * 4; }
+  static size_t lds_bytes(int nq, int N) { return X_BYTES + (ALIAS ? 0 : V_BYTES) + RED_BYTES + (size_t)nq * N * 4 + 2 * QP * 4; }
 };
 
-template <bool BWD, int NT, int DD>
+template <bool BWD, int NT, int DD, int VR = 4>
 __global__ __launch_bounds__(512) void lstp_mfma_kernel(LstpMfmaArgs a) {
-  using SH = LstpShape<NT, DD>;
+  using SH = LstpShape<NT, DD, VR>;
+  constexpr bool ALIAS = SH::ALIAS;
   constexpr int C = SH::C, KS = SH::KS, CW = SH::CW, PITCH = SH::PITCH, VP = SH::VP;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   char* xt = sm;                                                   // [16][PITCH]
-  char* svh = sm + SH::X_BYTES;                                    // [4][VP] hi
-  char* svl = svh + (QP / 4) * VP;                                 // [4][VP] lo
-  float* sred = reinterpret_cast<float*>(sm + SH::X_BYTES + SH::V_BYTES);   // [LW][QP][16]
+  char* svh = ALIAS ? sm : sm + SH::X_BYTES;                       // [VR][VP] hi
+  char* svl = svh + VR * VP;                                       // [VR][VP] lo
+  float* sred = reinterpret_cast<float*>(sm + SH::X_BYTES + (ALIAS ? 0 : SH::V_BYTES));   // [LW][QP][16]
   float* ssc = sred + LW * QP * 16;                                // [nq][N]: fwd raw scores, bwd P
   float* sml = ssc + a.nq * a.N;                                   // [2][QP]: fwd (M, L)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,13 +132,13 @@ __global__ __launch_bounds__(512) void lstp_mfma_kernel(LstpMfmaArgs a) {
 #pragma unroll
   for (int ct = 0; ct < 2 * KS; ++ct) acc[ct] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   float m = -1e30f, l = 0.f, gb = 0.f;      // online softmax state of query li (every wave, every g: the same numbers) / gbar
-  const int vrow = min(li, QP / 4 - 1);     // padding columns read the zero row
+  const int vrow = min(li, VR - 1);         // padding columns read the zero row
   const int ntiles = (N + 15) >> 4;
   LSTP_LOAD_TILE(0, stage_a)
   // ---- this frame's small operand as bf16 hi / lo rows (rows nq .. 3 zero).  A compile-time trip count: all of a thread's
   // loads are in flight together (as a run-time loop this prologue was 18 dependent L2 round trips) ----
   {
-    constexpr int NV = (QP / 4) * C / 512;
+    constexpr int NV = VR * C / 512;
     float vv[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(512) void lstp_mfma_kernel(LstpMfmaArgs a) {
   if constexpr (BWD)
     for (int i = tid; i < nq * N; i += 512) ssc[i] = a.P[(size_t)f * nq * N + i];
 
-  LSTP_STORE_TILE(stage_a)
+  if constexpr (!ALIAS) LSTP_STORE_TILE(stage_a)
   __syncthreads();
   bf16x8_t vfh[VREG ? KS : 1], vfl[VREG ? KS : 1];
   if constexpr (VREG) {
@@ -162,6 +168,11 @@ __global__ __launch_bounds__(512) void lstp_mfma_kernel(LstpMfmaArgs a) {
       vfh[ks] = *reinterpret_cast<const bf16x8_t*>(svh + vrow * VP + cb);
       vfl[ks] = *reinterpret_cast<const bf16x8_t*>(svl + vrow * VP + cb);
     }
+  }
+  if constexpr (ALIAS) {      // the vector images are in registers now: tile 0 takes their place
+    __syncthreads();
+    LSTP_STORE_TILE(stage_a)
+    __syncthreads();
   }
   // one tile's arithmetic on the LDS image (both products, the exchange barrier in between)
   auto compute = [&](int tile) __attribute__((always_inline)) {
@@ -280,33 +291,39 @@ __global__ __launch_bounds__(512) void lstp_mfma_kernel(LstpMfmaArgs a) {
   }
 }
 
-template <bool BWD, int NT, int DD>
+template <bool BWD, int NT, int DD, int VR = 4>
 int go(const LstpMfmaArgs& a, int F, hipStream_t st) {
-  using SH = LstpShape<NT, DD>;
+  using SH = LstpShape<NT, DD, VR>;
   const size_t lds = SH::lds_bytes(a.nq, a.N);
   if (lds > 160 * 1024) return MVF_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstp_mfma_kernel<BWD, NT, DD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstp_mfma_kernel<BWD, NT, DD, VR>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return MVF_ERR_ARG;
     attr_set = true;
   }
-  hipLaunchKernelGGL((lstp_mfma_kernel<BWD, NT, DD>), dim3(F), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((lstp_mfma_kernel<BWD, NT, DD, VR>), dim3(F), dim3(512), lds, st, a);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }
 
 }  // namespace
 
-// bf16 taps, 1 or 3 of them, D = 768 or 1024, nq <= 3 (the lanes of a tile's padding columns read a zero row of the 4-row vector
-// image); MVF_ERR_UNSUPPORTED otherwise -- the caller (lstp_pool.hip) then takes the VALU form
+// bf16 taps, 1 or 3 of them, D = 768 or 1024, nq <= 7 (nq <= 3 at 3 x 1 024 channels; the lanes of a tile's padding columns read a zero
+// row of the 4- or 8-row vector image); MVF_ERR_UNSUPPORTED otherwise -- the caller (lstp_pool.hip) then takes the VALU form
 int mvf_lstp_mfma_impl(bool bwd, const void* const* taps, int n_taps, int D, int F, int N, int T, int nq, const float* vec,
                        int per_frame, float inv_sqrt_d, float* P, float* pooled, float* G, hipStream_t st) {
-  if (!(n_taps == 1 || n_taps == 3) || !(D == 768 || D == 1024) || nq < 1 || nq > 3 || N < 1) return MVF_ERR_UNSUPPORTED;
+  if (!(n_taps == 1 || n_taps == 3) || !(D == 768 || D == 1024) || nq < 1 || nq > 7 || N < 1) return MVF_ERR_UNSUPPORTED;
+  if (nq > 3 && n_taps == 3 && D == 1024) return MVF_ERR_UNSUPPORTED;      // (8-row vector images need the fragments in registers: C <= 2304)
   LstpMfmaArgs a{};
   for (int i = 0; i < n_taps; ++i) a.taps[i] = reinterpret_cast<const bf16_t*>(taps[i]);
   a.N = N; a.T = T; a.nq = nq; a.per_frame = per_frame; a.vec = vec; a.P = P; a.pooled = pooled; a.G = G; a.inv_sqrt_d = inv_sqrt_d;
+  if (nq > 3) {       // 4 .. 7 queries: 8-row vector images
+    if (n_taps == 3 && D == 768) return bwd ? go<true, 3, 768, 8>(a, F, st) : go<false, 3, 768, 8>(a, F, st);
+    if (n_taps == 1 && D == 768) return bwd ? go<true, 1, 768, 8>(a, F, st) : go<false, 1, 768, 8>(a, F, st);
+    return bwd ? go<true, 1, 1024, 8>(a, F, st) : go<false, 1, 1024, 8>(a, F, st);
+  }
   if (n_taps == 3 && D == 768) return bwd ? go<true, 3, 768>(a, F, st) : go<false, 3, 768>(a, F, st);
   if (n_taps == 1 && D == 768) return bwd ? go<true, 1, 768>(a, F, st) : go<false, 1, 768>(a, F, st);
   if (n_taps == 3 && D == 1024) return bwd ? go<true, 3, 1024>(a, F, st) : go<false, 3, 1024>(a, F, st);

@@ -290,7 +290,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   const int rl = threadIdx.x >> 6;
   float s = 0.f;
   if (c < cols)
-    for (int r = rl; r < rows; r += 4) s += x[(long)r * ld + c];
+    for (int r0 = rl; r0 < rows; r0 += 32) {      // batches of 8 loads, same addition order (load -> add loops pay a round trip per row)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = x[(long)min(r0 + 4 * u, rows - 1) * ld + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r0 + 4 * u < rows) s += v[u];
+    }
   red[rl][threadIdx.x & 63] = s;
   __syncthreads();
   if (rl == 0 && c < cols) {
@@ -309,7 +316,14 @@ __global__ __launch_bounds__(256) void colsum_split_kernel(const float* __restri
   const int r0 = blockIdx.y * chunk, r1 = min(rows, r0 + chunk);
   float s = 0.f;
   if (c < cols)
-    for (int r = r0 + rl; r < r1; r += 4) s += x[(long)r * ld + c];
+    for (int ra = r0 + rl; ra < r1; ra += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = x[(long)min(ra + 4 * u, r1 - 1) * ld + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (ra + 4 * u < r1) s += v[u];
+    }
   red[rl][threadIdx.x & 63] = s;
   __syncthreads();
   if (rl == 0 && c < cols)

@@ -113,7 +113,15 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   float a = 0.f, b = 0.f;
   if (c < C) {
     const float p = x[c];
-    for (int r = rbeg + rl; r < rend; r += 4) { const float d = x[(size_t)r * C + c] - p; a += d; b += d * d; }
+    // (loads in batches of 8 rows, same addition order: a run-time loop of load -> add pays a memory round trip per row)
+    for (int r0 = rbeg + rl; r0 < rend; r0 += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = x[(size_t)min(r0 + 4 * u, rend - 1) * C + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r0 + 4 * u < rend) { const float d = v[u] - p; a += d; b += d * d; }
+    }
   }
   r1[rl][cl] = a; r2[rl][cl] = b;
   __syncthreads();
@@ -125,7 +133,18 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   if (!last_arriver(&g_bn_ticket[ticket][blockIdx.x], (unsigned)RS)) return;
   if (rl != 0 || c >= C) return;
   a = 0.f; b = 0.f;
-  for (int q = 0; q < RS; ++q) { a += ws[((size_t)q * 2 + 0) * C + c]; b += ws[((size_t)q * 2 + 1) * C + c]; }
+  for (int q0 = 0; q0 < RS; q0 += 8) {
+    float pa[8], pb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = min(q0 + u, RS - 1);
+      pa[u] = ws[((size_t)q * 2 + 0) * C + c];
+      pb[u] = ws[((size_t)q * 2 + 1) * C + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (q0 + u < RS) { a += pa[u]; b += pb[u]; }
+  }
   const float inv = 1.f / rows, d = a * inv;
   const float mu = x[c] + d, v = fmaxf(b * inv - d * d, 0.f);
   mean[c] = mu;
@@ -167,12 +186,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   float a = 0.f, bb = 0.f;
   if (c < C) {
     const float mu = mean[c], rsd = rsqrtf(var[c] + eps), gg = g[c], be = b[c];
-    for (int r = rbeg + rl; r < rend; r += 4) {
-      const float xh = (x[(size_t)r * C + c] - mu) * rsd;
-      float d = dy[(size_t)r * C + c];
-      if (relu && !(xh * gg + be > 0.f)) d = 0.f;
-      a += d;
-      bb += d * xh;
+    for (int r0 = rbeg + rl; r0 < rend; r0 += 16) {      // batches of 4 rows x 2 loads, same addition order
+      float xv[4], dv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t o = (size_t)min(r0 + 4 * u, rend - 1) * C + c;
+        xv[u] = x[o];
+        dv[u] = dy[o];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r0 + 4 * u >= rend) break;
+        const float xh = (xv[u] - mu) * rsd;
+        float d = dv[u];
+        if (relu && !(xh * gg + be > 0.f)) d = 0.f;
+        a += d;
+        bb += d * xh;
+      }
     }
   }
   r1[rl][cl] = a; r2[rl][cl] = bb;
@@ -184,7 +214,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   if (!last_arriver(&g_bn_bwd_ticket[ticket][blockIdx.x], (unsigned)RS)) return;
   if (rl != 0 || c >= C) return;
   float sa = 0.f, sb = 0.f;
-  for (int q = 0; q < RS; ++q) { sa += ws[((size_t)q * 2 + 0) * C + c]; sb += ws[((size_t)q * 2 + 1) * C + c]; }
+  for (int q0 = 0; q0 < RS; q0 += 8) {
+    float pa[8], pb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = min(q0 + u, RS - 1);
+      pa[u] = ws[((size_t)q * 2 + 0) * C + c];
+      pb[u] = ws[((size_t)q * 2 + 1) * C + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (q0 + u < RS) { sa += pa[u]; sb += pb[u]; }
+  }
   s1[c] = sa;
   s2[c] = sb;
   if (dgamma != nullptr) {

@@ -231,7 +231,7 @@ class TransformerModel(nn.Module):
         ops.gemm_spare_mode(self.training and torch.is_grad_enabled())
         cur = torch.cuda.current_stream(x.device)
         if getattr(self, '_side', None) is None or self._side.device != x.device:
-            self._side = torch.cuda.Stream(device=x.device, priority=ops.BACKBONE_STREAM_PRIORITY)
+            self._side = ops.backbone_stream('side', x.device)      # one per process and device (ops.backbone_stream: hardware queues)
         if ready_event is None:            # "x is ready": everything enqueued on the caller's stream so far
             ready_event = torch.cuda.Event()
             ready_event.record(cur)

@@ -1922,11 +1922,7 @@ class PackedViT:
 
     def lane_stream(self, slot, device):
         """Extra HIP stream of concurrent-forward lane `slot` >= 1 (lane 0 is the caller's stream)."""
-        if not hasattr(self, '_lanes'):
-            self._lanes = {}
-        if slot not in self._lanes:
-            self._lanes[slot] = torch.cuda.Stream(device=device, priority=BACKBONE_STREAM_PRIORITY)
-        return self._lanes[slot]
+        return backbone_stream('lane%d' % slot, device)
 
 
 # Rows (frames x tokens) per lane from which a forward is split into concurrent lanes: every GEMM of a lane must still
@@ -1937,6 +1933,23 @@ VIT_LANE_MIN_ROWS = 22000
 # 4 lanes 12.75 ms, 2 lanes 12.13 ms, 1 lane 12.48 ms.
 BACKBONE_STREAM_PRIORITY = int(os.environ.get('MVF_BACKBONE_PRIORITY', '0'))      # (the variable: A/B measurements)
 VIT_LANES = 2
+
+
+_BACKBONE_STREAMS = {}
+
+
+def backbone_stream(role, device):
+    """The process's HIP stream for a backbone role on a device ('side' = the lookahead stream of models/transformer.py, 'lane1', ..):
+    ONE per role and device for every model of the process.  HIP deals streams over four hardware queues in creation order; a second
+    model that created its own (an evaluation copy, a sweep) got queues that the first model's streams or the caller's stream already
+    used, and two streams on one hardware queue run one after the other -- measured: the same backbone forward 10.5 ms in a fresh process,
+    12.5 ms as the second model of a process (tools/order_probe.py)."""
+    device = torch.device(device)
+    key = (role, device.index if device.index is not None else torch.cuda.current_device())
+    st = _BACKBONE_STREAMS.get(key)
+    if st is None:
+        st = _BACKBONE_STREAMS[key] = torch.cuda.Stream(device=device, priority=BACKBONE_STREAM_PRIORITY)
+    return st
 
 
 def vit_forward(frames, packed, frames_per_chunk=0, want_cls=True, attn_variant=0, lanes=None):

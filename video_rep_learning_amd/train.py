@@ -25,6 +25,13 @@ import time
 
 # (the host driver of the MI355X boxes only supports dmabuf IPC: RCCL's buffer exchange needs this before the runtime loads)
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+# Data-parallel runs: HIP deals a process's streams over GPU_MAX_HW_QUEUES (default 4) hardware queues in creation order, and two streams
+# on one queue run one after the other (profiles/r05/order_probe.txt).  One rank owns the caller's stream, the lookahead stream, the second
+# backbone lane and RCCL's communication stream -- four already: leave room so that none of them ever shares a queue (8 / 16 queues measured
+# neutral on one GPU, profiles/r04/head_exposure.txt; with more than one rank unmeasured like everything multi-GPU here).  Read when the
+# runtime loads, hence before `import torch`.
+if int(os.environ.get('WORLD_SIZE', '1') or '1') > 1:
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

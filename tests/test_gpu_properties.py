@@ -122,3 +122,15 @@ def test_training_step_is_repeatable_full_size():
             assert torch.allclose(v, outs[1][1][k], rtol=0, atol=2e-6), k        # Adam step of +-lr on a 1e-6-noise gradient...
         else:
             assert torch.equal(v, outs[1][1][k]), k
+
+
+def test_backbone_streams_are_one_set_per_process():
+    """ops.backbone_stream: the lookahead stream and the lane streams belong to the process and the device, not to a model -- a second
+    model with streams of its own would share hardware queues with the first one's (profiles/r05/order_probe.txt: its backbone forward
+    12.5 instead of 10.5 ms).  Identity only (no timing): the same object for the same role, another one for another role."""
+    from video_rep_learning_amd import ops
+    a, b = ops.backbone_stream('side', 'cuda'), ops.backbone_stream('side', torch.device('cuda', torch.cuda.current_device()))
+    assert a is b
+    l1, l1b, l2 = ops.backbone_stream('lane1', 'cuda'), ops.backbone_stream('lane1', 'cuda'), ops.backbone_stream('lane2', 'cuda')
+    assert l1 is l1b and l1 is not a and l2 is not l1
+    assert a.cuda_stream != torch.cuda.default_stream().cuda_stream

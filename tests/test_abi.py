@@ -101,3 +101,33 @@ def test_struct_layouts_match_the_header(tmp_path):
         assert name == st and int(size) == ctypes.sizeof(cls), (st, size, ctypes.sizeof(cls))
         for f, o in zip(fs, offs):
             assert getattr(cls, f).offset == int(o), (st, f, o, getattr(cls, f).offset)
+
+
+def test_spare_cu_policy_follows_the_heads_rows_and_the_mode(lib, monkeypatch):
+    """ops._spare_cus_for_rows / gemm_spare_mode (host logic only: the setter launches nothing): 32 spare CUs up to 1 024 head rows, the
+    row-chain workgroup count rounded up to 8 beyond, 64 at most; none while the backbone runs on its own (evaluation); MVF_GEMM_SPARE pins."""
+    from video_rep_learning_amd import ops
+    monkeypatch.delenv('MVF_GEMM_SPARE', raising=False)
+    seen = []
+    monkeypatch.setattr(ops, 'call', lambda name, *a: seen.append((name, a)) or 0)
+    monkeypatch.setattr(ops, '_SPARE_SET', [None])
+    monkeypatch.setattr(ops, '_SPARE_MODE', [True])
+    for rows, want in ((96, 32), (768, 32), (1024, 32), (1536, 48), (1537, 56), (4096, 64)):
+        ops._spare_cus_for_rows(rows)
+        assert ops._SPARE_SET[0] == want, (rows, ops._SPARE_SET)
+    n = len(seen)
+    ops._spare_cus_for_rows(4096)                 # unchanged: no call
+    assert len(seen) == n
+    ops.gemm_spare_mode(False)
+    assert ops._SPARE_SET[0] == 0 and seen[-1] == ('mvf_gemm_tc_set_spare', (0,))
+    ops._spare_cus_for_rows(768)                  # evaluation: stays off
+    assert ops._SPARE_SET[0] == 0
+    ops.gemm_spare_mode(True)
+    assert ops._SPARE_SET[0] == 32
+    monkeypatch.setenv('MVF_GEMM_SPARE', '16')    # pinned by the environment: the policy keeps its hands off
+    n = len(seen)
+    ops._spare_cus_for_rows(4096)
+    ops.gemm_spare_mode(False)
+    assert len(seen) == n
+    assert lib.mvf_gemm_tc_set_spare(257) == 10001 and lib.mvf_gemm_tc_set_spare(32) == 0
+    assert lib.mvf_optim_set_width(300) == 10001 and lib.mvf_optim_set_width(64) == 0

@@ -480,7 +480,12 @@ def _attn_ref(qkv, F, N, H):
 # variants: 0 default (two query tiles per wave; streamed 96-key blocks unless N = 193..208), 1 gather reads (cross-check of the
 # transposing LDS read), 2 the earlier kernels (one tile per wave / synchronously staged 224-key blocks: the fallback of odd
 # shapes), 4 streamed 64-key blocks
-@pytest.mark.parametrize('dtype,variant', [('f32', 0), ('bf16', 0), ('bf16', 1), ('bf16', 2), ('bf16', 4), ('bf16', 6)])
+# 7 the streamed 16-query-tile kernel of rounds 2-5; 8 .. 19 the forms of the 32-query-row kernel for any N (8 .. 11: one wave = all
+# of a block's S, softmax, P.V in turn, 64 / 96 / 128-key blocks; 12 .. 15: the pipelined form, row sums on the VALU / on the matrix
+# pipe, 64 / 128-key blocks); 32 + form + 16 * waves: the same with a forced workgroup size (3 and 8 waves: empty wave slots)
+@pytest.mark.parametrize('dtype,variant', [('f32', 0), ('bf16', 0), ('bf16', 1), ('bf16', 2), ('bf16', 4), ('bf16', 6), ('bf16', 7)] +
+                         [('bf16', v) for v in range(8, 16)] + [('bf16', 32 + 16 * 3), ('bf16', 32 + 1 + 16 * 8), ('bf16', 32 + 4 + 16 * 3),
+                                                                 ('bf16', 32 + 7 + 16 * 4), ('bf16', 32 + 5 + 16 * 2)])
 def test_vit_attention(N, dtype, variant):
     code, tdt = ops._dt(dtype)
     F, H, D = 2, 3, 192
@@ -488,6 +493,30 @@ def test_vit_attention(N, dtype, variant):
     out = torch.empty(F * N, D, device=DEV, dtype=tdt)
     _lib.call('mvf_vit_attn_fwd', code, qkv.data_ptr(), out.data_ptr(), F, N, H, D, variant, S())
     check(out, _attn_ref(qkv.cpu(), F, N, H), 2e-5 if dtype == 'f32' else 2e-2, 'vit_attn N=%d %s v%d' % (N, dtype, variant))
+
+
+@pytest.mark.parametrize('N', [65, 257, 577])
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('variant', [0, 8, 12, 13, 14, 15])
+def test_vit_attention_row_maximum_outgrows_the_first_tile(N, dtype, variant):
+    """The streamed 32-query-row kernel takes every exponent against the row maximum of the FIRST 32 keys and only checks that no later
+    score outgrows it by more than the threshold (2^30 / 2^15 in the exponent); a wave that sees one redoes its rows with the textbook
+    online softmax.  Here keys from 40 on are 25 x larger (some frames: from 300 on, so the walk leaves the fast loop in a late tile; one
+    (frame, head) stays tame): every path must agree with fp64 softmax on the same 16-bit inputs."""
+    code, tdt = (_lib.F16, torch.float16) if dtype == 'fp16' else (_lib.BF16, torch.bfloat16)
+    F, H, D = 3, 2, 128
+    g = gen(131)
+    qkv = torch.randn(F, N, 3, H, 64, generator=g)
+    qkv[0, 40:, 1] *= 25.0
+    if N > 320:
+        qkv[1, 300:, 1] *= 25.0
+    else:
+        qkv[1, 40:, 1, 0] *= 25.0
+    qkv = qkv.reshape(F * N, 3 * D).to(DEV).to(tdt)
+    out = torch.full((F * N, D), 7.0, device=DEV, dtype=tdt)
+    _lib.call('mvf_vit_attn_fwd', code, qkv.data_ptr(), out.data_ptr(), F, N, H, D, variant, S())
+    assert torch.isfinite(out.float()).all()
+    check(out, _attn_ref(qkv.cpu(), F, N, H), 2e-2 if dtype == 'bf16' else 4e-3, 'vit_attn outgrown maximum N=%d %s v%d' % (N, dtype, variant))
 
 
 # ------------------------------------------------------------------------------------------------ whole ViT

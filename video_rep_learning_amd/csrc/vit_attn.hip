@@ -597,16 +597,7 @@ __global__ __launch_bounds__(256, 1) void vit_attn_f32_kernel(AttnArgs a) {
 extern "C" int mvf_vit_attn_fwd_lse(const void* qkv, void* out, float* lse, int F, int N, int H, int D, hipStream_t st) {
   MVF_CHECK_ARG(qkv && out && lse && F > 0 && N > 0 && H > 0 && D == H * HD);
   MVF_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0);
-  AttnArgs a;
-  a.qkv = (const char*)qkv; a.out = (char*)out; a.N = N; a.H = H; a.D = D;
-  a.nblk = 0; a.rounds = 0;
-  a.scale_log2 = LOG2E / 8.0f;
-  a.lse = lse;
-  const int ntile = ceil_div(N, 16);
-  a.npad = ntile * 16;
-  hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<6, 3>), dim3(F * H, ceil_div(ntile, 8)), dim3(256), 0, st, a);
-  MVF_LAUNCH_CHECK();
-  return MVF_OK;
+  return mvf_vit_attn32_impl(MVF_BF16, qkv, out, lse, F, N, H, D, 0, 0, st);
 }
 
 // 1 when the default (variant 0) 16-bit kernel for N tokens normalises by the row sum of the ROUNDED probabilities (taken on the
@@ -630,6 +621,12 @@ int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H
   else { a.rounds = 1; chunks = ceil_div(qtiles, 4); }
   a.scale_log2 = LOG2E / 8.0f;  // 64^-0.5 * log2(e)
   dim3 grid(F * H, chunks);
+  // the streamed 32-query-row kernel (vit_attn32.hip): the product path of every N outside the one-block specialisation; variants
+  // 8 .. 23 select its forms for any N, 32 + form + 16 * waves also the workgroup size (A/B runs, tests)
+  if ((dtype == MVF_BF16 || dtype == MVF_F16) && ((variant == 0 && !attn_rowsum_rounded(N)) || (variant >= 8 && variant < 24)))
+    return mvf_vit_attn32_impl(dtype, qkv, out, nullptr, F, N, H, D, variant == 0 ? 0 : variant - 8, 0, st);
+  if ((dtype == MVF_BF16 || dtype == MVF_F16) && variant >= 32 && variant < 32 + 144)
+    return mvf_vit_attn32_impl(dtype, qkv, out, nullptr, F, N, H, D, (variant - 32) & 15, (variant - 32) >> 4, st);
   if (dtype == MVF_BF16) {
     const int ntile = ceil_div(N, 16);
     const dim3 fg(F * H, ceil_div(ntile, 8));   // streamed kernels: 8 query tiles per workgroup
@@ -639,14 +636,14 @@ int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H
     else if (a.nblk == 1 && ntile == 13 && variant == 6)     // row sums on the VALU from the unrounded probabilities (the earlier form)
       hipLaunchKernelGGL((vit_attn_bf16_pair_kernel<13, 3>), grid, dim3(256), 0, st, a);
     else if (a.nblk == 1 && ntile == 13) hipLaunchKernelGGL((vit_attn_bf16_kernel<true, 13>), grid, dim3(256), 0, st, a);
-    else if (variant == 0) hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<6, 3>), fg, dim3(256), 0, st, a);   // 96-key blocks
+    else if (variant == 7) hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<6, 3>), fg, dim3(256), 0, st, a);   // 96-key blocks: the streamed kernel of rounds 2-5
     else if (variant == 4) hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<4, 4>), fg, dim3(256), 0, st, a);   // 64-key blocks
     else hipLaunchKernelGGL((vit_attn_bf16_kernel<true, KT>), grid, dim3(256), 0, st, a);
   } else if (dtype == MVF_F16) {   // fp16 q / k / v / out: the two-tile kernel (N = 193 .. 208) or the streamed kernel (any N)
     const int ntile = ceil_div(N, 16);
     const dim3 fg(F * H, ceil_div(ntile, 8));
     if (attn_rowsum_rounded(N)) hipLaunchKernelGGL((vit_attn_bf16_pair_kernel<13, 3, true, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<6, 3, 4, true>), fg, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<6, 3, 4, true>), fg, dim3(256), 0, st, a);   // variant 7 (variant 0 left above)
   } else if (dtype == MVF_F32) {
     static bool attr = false;
     if (!attr) {

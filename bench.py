@@ -38,8 +38,8 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 # backbone lane and RCCL's communication stream -- four already: leave room so that none of them ever shares a queue (8 / 16 queues measured
 # neutral on one GPU, profiles/r04/head_exposure.txt; with more than one rank unmeasured like everything multi-GPU here).  Read when the
 # runtime loads, hence before `import torch`.
-if int(os.environ.get('WORLD_SIZE', '1') or '1') > 1:
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+if (int(os.environ.get('WORLD_SIZE', '1') or '1') > 1 or os.environ.get('MVF_FORCE_REDUCER') == '1') and os.environ.get('MVF_HW_QUEUES', '8') != '0':
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', os.environ.get('MVF_HW_QUEUES', '8'))     # opt-out / A-B knob: MVF_HW_QUEUES=0 | n
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -200,6 +200,10 @@ def parse():
     p.add_argument('--parity-videos', type=int, default=2,
                    help='videos (x 2 views x 32 frames) of the resident batch pushed through the oracle for the parity block')
     p.add_argument('--profile-steps', type=int, default=3)
+    p.add_argument('--min-sustain-s', type=float, default=2.0,
+                   help='after the K timed steps the same loop keeps running until this many seconds of steps have been timed in all (0 = '
+                        'off): `ms_per_step` stays the K requested steps, `ms_per_step_sustained` is the extension alone -- the chip\'s '
+                        'power management needs a second or two of load to settle (bursts read 10-13 %% slow or fast, DESIGN 4a)')
     p.add_argument('--no-lookahead', action='store_true', help='run backbone and head strictly in sequence')
     p.add_argument('--serial', action='store_true',
                    help='one kernel at a time for the whole run (one backbone lane, no lookahead): the mode the roofline '
@@ -512,17 +516,33 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     comm = None
+    if world > 1:      # always present with more than one rank, also when no collective ran (then it says so)
+        comm = {'allreduce_bytes_per_step': 0, 'buckets': 0, 'exposed_allreduce_ms_per_step': None, 'reducer_active': False}
     if reducer is not None and reducer.active:
         reducer.timing = False
         # the gradient all-reduce as the process group ran it: payload per step and the time the compute stream spent waiting
         # for it between the last backward kernel and the optimizer (device events; what backward did not hide)
         comm = {'allreduce_bytes_per_step': reducer.bytes_per_step(), 'buckets': len(reducer.buckets),
-                'exposed_allreduce_ms_per_step': None if (ex := reducer.exposed_ms()) is None else round(ex, 4)}
-    stage('roofline steps')
+                'exposed_allreduce_ms_per_step': None if (ex := reducer.exposed_ms()) is None else round(ex, 4), 'reducer_active': True}
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
+    # ---- the same loop, extended to a settled state: every rank derives the same step count from the all-reduced time ----
+    sustained = None
+    if a.min_sustain_s > 0 and dt < a.min_sustain_s:
+        stage('sustained region')
+        n2 = max(a.steps, min(20000, int((a.min_sustain_s - dt) / (dt / a.steps)) + 1))
+        t0 = time.perf_counter()
+        for _ in range(n2):
+            loss = step()
+        fence()
+        dt2 = time.perf_counter() - t0
+        t2 = torch.tensor([dt2], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        sustained = {'steps': n2, 'seconds': round(t2.item(), 4), 'ms_per_step': round(t2.item() / n2 * 1e3, 3)}
+    stage('roofline steps')
     last_loss = float(loss.item())
 
     # ---- roofline of the dominant kernel: per-launch HIP-event timing during extra (untimed) steps ----
@@ -583,6 +603,8 @@ def main():
         out = {
             'metric': 'video-clips/sec/node, ViT-B/16 32-frame MV-Former', 'value': round(value, 2), 'unit': 'clips/s',
             'n_gpus': world_seen, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
+            'timed_region_s': round(dt, 4),
+            'ms_per_step_sustained': None if sustained is None else sustained['ms_per_step'], 'sustained_region': sustained,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: PennAction MV-Former (penn_mvf.yml + ViT-B/16), 32 frames, '
                                    'batch 4/GPU = 8 clips/GPU/step, full train step (frozen backbone fwd, head fwd+bwd, SCL, '
@@ -593,12 +615,25 @@ def main():
                        'tflop_per_step_per_gpu': round(cfg.TRAIN.BATCH_SIZE * 2 * TFLOP_PER_CLIP, 2),
                        'head_dtype': model.head_dtype, 'last_loss': round(last_loss, 4),
                        'gemm_cu_budget': gemm_cus or 'all',
+                       # hardware queues the runtime deals this process's streams over (read when it loaded; 8 asked for under data
+                       # parallel unless the environment says otherwise: MVF_HW_QUEUES=0 keeps the runtime's default)
+                       'gpu_max_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'runtime default (4)'),
                        # the process group as it actually ran (None / 1: no group): never the environment's word for it
                        'backend': backend_seen, 'world_size_seen': world_seen, 'ranks': ranks_seen,
                        'distinct_gpus': len({(r['pci'], r['uuid']) for r in ranks_seen}),
                        **({'comm': comm} if comm is not None else {})},
             'roofline': roof,
         }
+        if roof is not None:
+            # whole-step figures beside the dominant kernel's: algorithmic TFLOP of a step over the step time over the peak, for the
+            # K requested steps and for the settled extension of the same loop
+            tf_step = cfg.TRAIN.BATCH_SIZE * 2 * TFLOP_PER_CLIP
+            peak_step = PEAK_BF16_TFLOPS if a.dtype in ('bf16', 'fp16') else PEAK_F32_TFLOPS
+            roof['step_frac'] = round(tf_step / (dt / a.steps) / peak_step, 4)
+            roof['sustained_frac'] = None if sustained is None else round(tf_step / (sustained['ms_per_step'] * 1e-3) / peak_step, 4)
+            roof['frac_note'] = ('frac: the dominant kernel alone, HIP events in one-kernel-at-a-time steps right after the %s; step_frac / '
+                                 'sustained_frac: %.2f algorithmic TFLOP per step over ms_per_step / ms_per_step_sustained'
+                                 % ('settled extension' if sustained else 'timed region', tf_step))
         parity_ok = True
         if world == 1 and not a.no_cpu_baseline:
             try:

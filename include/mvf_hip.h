@@ -200,14 +200,17 @@ int mvf_gemm_tc_debug_ablate(int bits);
 int mvf_patchify(int dtype, const float* frames, void* out, int F, int H, int W, int P, hipStream_t stream);
 int mvf_layernorm_fwd(int out_dtype, const float* x, size_t in_stride, const float* g, const float* b, void* y,
                       size_t out_stride, int rows, int D, float eps, hipStream_t stream);
-/* variant (bf16): 0 = product path (two query tiles per wave; one key block for N = 193..208, else 96-key blocks streamed
- * through a double-buffered LDS-DMA pipeline), 1 = 2-byte gather reads of V (cross-check of the transposing LDS read),
+/* variant (bf16 / fp16): 0 = product path (N = 193..208: one key block, two 16-query tiles per wave; every other N: the streamed kernel
+ * on 32-query-row tiles, csrc/vit_attn32.hip), 1 = 2-byte gather reads of V (cross-check of the transposing LDS read),
  * 2 = the earlier kernels (one tile per wave / synchronously staged 224-key blocks; what other values fall back to),
- * 4 = streamed 64-key blocks */
+ * 4 = streamed 64-key blocks and 7 = streamed 96-key blocks on 16-query tiles (the streamed kernel of rounds 2-5), 6 = the one-block
+ * kernel with VALU row sums, 8 + form = a form of the 32-query-row kernel for any N (mvf_vit_attn32_impl), 32 + form + 16 * waves = the
+ * same with a forced workgroup size */
 int mvf_vit_attn_fwd(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t stream);
-/* softmax normalisation convention of the 16-bit kernels (variant 0 and the fused qkv + attention kernel): 1 = the row sum is taken over
- * the probabilities AFTER their rounding to bf16 / fp16 (N = 193..208: on the matrix pipe beside P.V), 0 = over the fp32 values (every
- * other N).  Both are softmax to within the operand rounding; the emulating oracle follows this function's answer (tests/test_abi.py). */
+/* softmax normalisation convention of the 16-bit product kernels (variant 0 and the fused qkv + attention kernel): 1 = the row sum is taken
+ * over the probabilities AFTER their rounding to bf16 / fp16, on the matrix pipe beside P.V (every N since round 6), 0 = over the fp32
+ * values (the fp32 kernel).  Both are softmax to within the operand rounding; the emulating oracle follows this function's answer
+ * (tests/test_abi.py). */
 int mvf_vit_attn_rowsum_rounded(int dtype, int N);
 /* timm Attention.qkv FUSED into the attention core (reached from models/transformer.py:188): out [F*N, D] = per (frame, head)
  * softmax(q k^T / 8) v with [q | k | v] = A[f] W_h^T + bias (ln_c / ln_mr NULL), or the folded-LayerNorm form
@@ -308,6 +311,11 @@ int mvf_ln_bwd_res(const float* dy, const float* x, const float* g, const float*
 size_t mvf_bn_workspace_floats(int rows, int C);   /* scratch of mvf_bn_stats / mvf_bn_bwd_reduce (two-stage column sums) */
 int mvf_bn_stats(const float* x, int rows, int C, float* mean, float* var, float* running_mean, float* running_var,
                  float momentum, float* ws, size_t ws_floats, hipStream_t stream);
+/* SyncBatchNorm's merge (train.py:283-286): gathered [W][2C + 1] = every rank's (mean [C], biased var [C], row count) -> mean / var [C]
+ * of the rank-concatenated batch (equal row counts: count_per_rank rows on every rank) and, when given, the running buffers updated with
+ * the unbiased variance over all W * count_per_rank rows.  The all-gather itself is the caller's (torch.distributed / RCCL). */
+int mvf_syncbn_merge(const float* gathered, int W, int C, float count_per_rank, float* mean, float* var, float* running_mean,
+                     float* running_var, float momentum, hipStream_t stream);
 int mvf_bn_fwd(const float* x, const float* mean, const float* var, const float* g, const float* b, float* y, int rows,
                int C, float eps, int relu, hipStream_t stream);
 int mvf_bn_bwd_reduce(const float* dy, const float* x, const float* mean, const float* var, const float* g, const float* b,

@@ -173,9 +173,10 @@ def vit_block(x, w, p, heads, eps=1e-6, emulate=None):
 
 def rowsum_rounded(n):
     """Softmax normalisation of the 16-bit emulation for n tokens: True = the row sum runs over the probabilities after their rounding
-    to the operand type (what the device's kernels for 193..208 tokens do, beside P.V on the matrix pipe), False = over the fp32 values.
+    to the operand type (what the device's product kernels do, beside P.V on the matrix pipe: the one-block kernels of 193..208 tokens
+    since round 4, the streamed kernel of every other n since round 6), False = over the fp32 values.
     Mirrors `mvf_vit_attn_rowsum_rounded` (include/mvf_hip.h); tests/test_abi.py holds the two together for every n up to 2 048."""
-    return 193 <= n <= 208
+    return n > 0
 
 
 def ln_linear_bf16(x, g, beta, W, b, eps, fold):

@@ -1585,3 +1585,25 @@ def test_qkv_attention_fused_kernel_repeats_bitwise_beside_other_work():
     torch.cuda.synchronize()
     assert bad == 0, bad
 
+
+
+# ------------------------------------------------------------------------------------------------ SyncBatchNorm merge
+@pytest.mark.parametrize('W,C', [(1, 512), (2, 384), (8, 512), (8, 130)])
+def test_syncbn_merge_vs_chan_formula(W, C):
+    """mvf_syncbn_merge (the ranks' gathered [mean | biased var | count] blocks -> statistics of the rank-concatenated batch + running
+    buffers) against the statistics of the concatenated rows themselves, fp64: W ranks x 96 rows each."""
+    g = gen(140 + W)
+    rows = 96
+    x = torch.randn(W, rows, C, generator=g).double() * 2 + torch.randn(W, 1, C, generator=g).double()
+    blocks = torch.cat([x.mean(1), x.var(1, unbiased=False), torch.full((W, 1), float(rows), dtype=torch.float64)], 1).float().to(DEV)
+    mean, var = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    rm0, rv0 = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    rm, rv = rm0.to(DEV), rv0.to(DEV)
+    _lib.call('mvf_syncbn_merge', blocks.data_ptr(), W, C, float(rows), mean.data_ptr(), var.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, S())
+    allx = x.reshape(W * rows, C)
+    assert relerr(mean, allx.mean(0)) <= 1e-5 and relerr(var, allx.var(0, unbiased=False)) <= 1e-5
+    assert relerr(rm, 0.9 * rm0.double() + 0.1 * allx.mean(0)) <= 1e-5
+    assert relerr(rv, 0.9 * rv0.double() + 0.1 * allx.var(0, unbiased=True)) <= 1e-5
+    mean2, var2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)       # without running buffers
+    _lib.call('mvf_syncbn_merge', blocks.data_ptr(), W, C, float(rows), mean2.data_ptr(), var2.data_ptr(), None, None, 0.1, S())
+    assert torch.equal(mean, mean2) and torch.equal(var, var2)

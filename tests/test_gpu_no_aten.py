@@ -53,6 +53,66 @@ def test_training_step_launches_no_aten_kernels(padded):
     assert names and not foreign, foreign
 
 
+def _forced_reducer_worker(rank, port, ret):
+    """One process, one GPU, a ONE-rank `nccl` (= RCCL) group with MVF_FORCE_REDUCER=1: every collective call site of the data-parallel
+    step runs (bucketed async gradient all-reduce, SyncBatchNorm all-gather + merge, backward column-sum all-reduce)."""
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', MVF_FORCE_REDUCER='1')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        from video_rep_learning_amd.utils import distributed as du
+        assert du.collectives_active()
+        cfg, model = T.make(3, **dict(T.SMALL, dropout=0.1, compute_dtype='bf16', batch_size=2, head_dtype=ret['head']))
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        wrapped = DataParallelModel(model)
+        opt = construct_optimizer(wrapped, cfg)
+        algo = get_algo(cfg)
+        videos, seq_lens, steps, masks = [t.to(DEV) for t in T.batch(cfg, 4)]
+        model.train()
+
+        def step():
+            wrapped.prefetch(videos)
+            opt.zero_grad()
+            loss = algo.compute_loss(wrapped, videos, seq_lens, steps, masks)['loss']
+            ops.backward(loss)
+            opt.step(max_norm=cfg.OPTIMIZER.GRAD_CLIP)
+
+        wrapped.prefetch(videos)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        names = _device_kernels(step, 2)
+        ret['names'] = sorted(set(names))
+        ret['reducer_active'] = bool(opt.reducer is not None and opt.reducer.active)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('head', ['bf16', 'fp32'])
+def test_data_parallel_step_launches_no_aten_kernels_either(head):
+    """The same census with every collective of the data-parallel step live: besides the library's kernels only
+    RCCL's own work may appear (its kernels, and the device-to-device copy a one-rank all-gather degenerates to) -- no at::native
+    kernel from assembling / merging the SyncBatchNorm statistics (mvf_syncbn_merge + a persistent exchange block replaced cat /
+    stack / sum / pow ...), no fill, no host copies."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    ret['head'] = head
+    mp.spawn(_forced_reducer_worker, args=(port, ret), nprocs=1, join=True)
+    names = list(ret['names'])
+    assert ret['reducer_active'] and names
+    foreign = [n for n in names if 'at::native' in n or 'Memset' in n or 'HtoD' in n or 'DtoH' in n or
+               (('Memcpy' in n or 'rocclr' in n) and 'DtoD' not in n)]
+    assert not foreign, foreign
+    assert any('syncbn_merge' in n for n in names), names
+
+
 def test_layer_norm_fork_equals_layer_norm_plus_residual_gradient():
     g = torch.Generator().manual_seed(0)
     x0 = torch.randn(6, 24, 256, generator=g).to(DEV)

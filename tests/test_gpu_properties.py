@@ -124,6 +124,64 @@ def test_training_step_is_repeatable_full_size():
             assert torch.equal(v, outs[1][1][k]), k
 
 
+FULL_BATCHES = {
+    # BASELINE configs[3] at its full per-GPU batch: 4 videos x 2 views x 64 frames = 512 frames, temporal sequence S = 192
+    'configs[3] T=64 B=4 (512 frames)': dict(network='TIMM-vit_base_patch16_224.dino', num_frames=64, batch_size=4, compute_dtype='bf16'),
+    # BASELINE configs[4] at its full per-GPU batch: DINOv2 ViT-L/14 @ 336 px (577 tokens), 4 videos x 2 views x 32 frames = 8 clips
+    'configs[4] ViT-L/14 @ 336 B=4 T=32 (8 clips) bf16': dict(network='TIMM-vit_large_patch14_dinov2.lvd142m', num_frames=32, batch_size=4,
+                                                              image_size=336, compute_dtype='bf16', SMART_FEATS='7,15,23', LAYER=24),
+    'configs[4] ViT-L/14 @ 336 B=4 T=32 (8 clips) fp8': dict(network='TIMM-vit_large_patch14_dinov2.lvd142m', num_frames=32, batch_size=4,
+                                                             image_size=336, compute_dtype='fp8', SMART_FEATS='7,15,23', LAYER=24),
+}
+
+
+@pytest.mark.parametrize('tag', list(FULL_BATCHES))
+def test_full_per_gpu_batches_of_configs_3_and_4_step_finite_and_repeatable(tag):
+    """The parity tests of configs[3] / configs[4] (tests/test_gpu_configs.py) run at sizes the CPU oracle finishes (2 videos / 2 clips);
+    the FULL per-GPU batches run here through the size-independent checks: two training steps from identical states (dropout 0) give
+    a finite loss, bitwise the same loss, the same updated head (LayerNorm gamma / beta to 2e-6: float atomics), and the loss is
+    symmetric in the two views."""
+    from video_rep_learning_amd.train import DataParallelModel
+    from video_rep_learning_amd.utils.optimizer import construct_optimizer
+    kw = dict(FULL_BATCHES[tag])
+    layer = kw.pop('LAYER', None)
+    cfg = presets.make_cfg(dropout=0.0, **kw)
+    if layer is not None:
+        cfg.MODEL.BASE_MODEL.LAYER = layer
+    batch = _batch(cfg, 61)
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(9)
+        model = build_model(cfg, 0).to(DEV)
+        wrapped = DataParallelModel(model)
+        opt = construct_optimizer(wrapped, cfg)
+        model.train()
+        opt.zero_grad()
+        loss = get_algo(cfg).compute_loss(wrapped, *batch)['loss']
+        loss.backward()
+        opt.step(max_norm=cfg.OPTIMIZER.GRAD_CLIP)
+        torch.cuda.synchronize()
+        outs.append((loss.item(), {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith('backbone')}))
+        if len(outs) == 2:
+            model.eval()
+            with torch.no_grad():
+                sw = lambda z: z.flip(1).contiguous()            # noqa: E731
+                l1 = get_algo(cfg).compute_loss(model, *batch)['loss'].item()
+                l2 = get_algo(cfg).compute_loss(model, *[sw(z) for z in batch])['loss'].item()
+            assert abs(l1 - l2) <= 2e-6 * abs(l1), (tag, l1, l2)
+        del model, wrapped, opt
+        torch.cuda.empty_cache()
+    assert outs[0][0] == outs[0][0] and 0.0 < outs[0][0] < 1e2, (tag, outs[0][0])
+    assert outs[0][0] == outs[1][0], (tag, outs[0][0], outs[1][0])
+    for k, v in outs[0][1].items():
+        if not v.dtype.is_floating_point:
+            assert torch.equal(v, outs[1][1][k]), k
+        elif '.norm.' in k or 'norm.weight' in k or 'norm.bias' in k:
+            assert torch.allclose(v, outs[1][1][k], rtol=0, atol=2e-6), k
+        else:
+            assert torch.equal(v, outs[1][1][k]), k
+
+
 def test_backbone_streams_are_one_set_per_process():
     """ops.backbone_stream: the lookahead stream and the lane streams belong to the process and the device, not to a model -- a second
     model with streams of its own would share hardware queues with the first one's (profiles/r05/order_probe.txt: its backbone forward

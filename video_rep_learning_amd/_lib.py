@@ -77,6 +77,7 @@ SIGNATURES = {
     'mvf_ln_bwd_res': 'pppppppppiiip',
     'mvf_bn_workspace_floats': 'ii',
     'mvf_bn_stats': 'piippppfpzp',
+    'mvf_syncbn_merge': 'piifppppfp',
     'mvf_bn_fwd': 'ppppppiifip',
     'mvf_bn_bwd_reduce': 'ppppppppppiiifipzp',
     'mvf_bn_bwd_apply': 'pppppppppiififp',

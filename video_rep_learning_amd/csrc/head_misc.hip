@@ -446,6 +446,43 @@ extern "C" int mvf_bn_stats(const float* x, int rows, int C, float* mean, float*
   return MVF_OK;
 }
 
+// SyncBatchNorm (CARL_MVF/train.py:283-286 -> nn.SyncBatchNorm): the ranks' statistics, gathered as rows [mean C | biased var C |
+// row count] of `gathered` [W][2C + 1], merged into the statistics of the rank-concatenated batch (Chan; every rank holds
+// `count_per_rank` rows in the data-parallel step, so the weights are equal) and the running buffers updated like nn.BatchNorm1d
+// does in training (unbiased variance over all W * count rows).  One thread per channel, the ranks summed in rank order: every rank
+// computes the same bits from the same gathered block.  Replaces ~10 ATen kernels per BatchNorm and step (cat / stack / sum / pow ...).
+__global__ void syncbn_merge_kernel(const float* __restrict__ g, int W, int C, float total, float* __restrict__ mean,
+                                    float* __restrict__ var, float* __restrict__ rmean, float* __restrict__ rvar, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const size_t ld = (size_t)2 * C + 1;
+  float sm = 0.f;
+  for (int r = 0; r < W; ++r) sm += g[r * ld + c];
+  const float gm = sm / (float)W;
+  float sv = 0.f;
+  for (int r = 0; r < W; ++r) {
+    const float d = g[r * ld + c] - gm;
+    sv += g[r * ld + C + c] + d * d;
+  }
+  const float gv = sv / (float)W;
+  mean[c] = gm;
+  var[c] = gv;
+  if (rmean != nullptr) {
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * gm;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * gv * (total / fmaxf(total - 1.f, 1.f));
+  }
+}
+
+extern "C" int mvf_syncbn_merge(const float* gathered, int W, int C, float count_per_rank, float* mean, float* var,
+                                float* running_mean, float* running_var, float momentum, hipStream_t st) {
+  MVF_CHECK_ARG(gathered && mean && var && W > 0 && C > 0 && count_per_rank > 0.f &&
+                ((running_mean == nullptr) == (running_var == nullptr)));
+  hipLaunchKernelGGL(syncbn_merge_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, st, gathered, W, C, count_per_rank * (float)W, mean, var,
+                     running_mean, running_var, momentum);
+  MVF_LAUNCH_CHECK();
+  return MVF_OK;
+}
+
 extern "C" int mvf_bn_fwd(const float* x, const float* mean, const float* var, const float* g, const float* b, float* y,
                           int rows, int C, float eps, int relu, hipStream_t st) {
   MVF_CHECK_ARG(x && mean && var && g && b && y && rows > 0 && C > 0);

@@ -597,16 +597,17 @@ __global__ __launch_bounds__(256, 1) void vit_attn_f32_kernel(AttnArgs a) {
 extern "C" int mvf_vit_attn_fwd_lse(const void* qkv, void* out, float* lse, int F, int N, int H, int D, hipStream_t st) {
   MVF_CHECK_ARG(qkv && out && lse && F > 0 && N > 0 && H > 0 && D == H * HD);
   MVF_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0);
-  return mvf_vit_attn32_impl(MVF_BF16, qkv, out, lse, F, N, H, D, 0, 0, st);
+  return mvf_vit_attn32_impl(MVF_BF16, qkv, out, lse, F, N, H, D, 5, 0, st);
 }
 
 // 1 when the default (variant 0) 16-bit kernel for N tokens normalises by the row sum of the ROUNDED probabilities (taken on the
 // matrix pipe with the P.V product), 0 when by the fp32 sum of the unrounded ones.  The one statement of that convention: the
 // dispatch below and vit_qkv_attn.hip's fused kernel follow it, the emulating oracle is tested against it (tests/test_abi.py).
-static bool attn_rowsum_rounded(int N) { return ceil_div(N, KB) == 1 && ceil_div(N, 16) == 13; }
-extern "C" int mvf_vit_attn_rowsum_rounded(int dtype, int N) {
-  return (dtype == MVF_BF16 || dtype == MVF_F16) && N > 0 && attn_rowsum_rounded(N) ? 1 : 0;
-}
+// (Round 6: every 16-bit product kernel takes the row sums on the matrix pipe -- the one-block kernels of N = 193 .. 208 since round 4,
+// the streamed 32-query-row kernel of every other N now -- so the answer no longer depends on N.)
+extern "C" int mvf_vit_attn_rowsum_rounded(int dtype, int N) { return (dtype == MVF_BF16 || dtype == MVF_F16) && N > 0 ? 1 : 0; }
+// N served by the one-key-block kernels (13 key tiles of 16: ViT-B/16 at 224 px and its neighbours)
+static bool attn_one_block(int N) { return ceil_div(N, KB) == 1 && ceil_div(N, 16) == 13; }
 
 int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t st) {
   MVF_CHECK_ARG(qkv && out && F > 0 && N > 0 && H > 0 && D == H * HD);
@@ -623,15 +624,15 @@ int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H
   dim3 grid(F * H, chunks);
   // the streamed 32-query-row kernel (vit_attn32.hip): the product path of every N outside the one-block specialisation; variants
   // 8 .. 23 select its forms for any N, 32 + form + 16 * waves also the workgroup size (A/B runs, tests)
-  if ((dtype == MVF_BF16 || dtype == MVF_F16) && ((variant == 0 && !attn_rowsum_rounded(N)) || (variant >= 8 && variant < 24)))
-    return mvf_vit_attn32_impl(dtype, qkv, out, nullptr, F, N, H, D, variant == 0 ? 0 : variant - 8, 0, st);
+  if ((dtype == MVF_BF16 || dtype == MVF_F16) && ((variant == 0 && !attn_one_block(N)) || (variant >= 8 && variant < 24)))
+    return mvf_vit_attn32_impl(dtype, qkv, out, nullptr, F, N, H, D, variant == 0 ? 5 : variant - 8, 0, st);
   if ((dtype == MVF_BF16 || dtype == MVF_F16) && variant >= 32 && variant < 32 + 144)
     return mvf_vit_attn32_impl(dtype, qkv, out, nullptr, F, N, H, D, (variant - 32) & 15, (variant - 32) >> 4, st);
   if (dtype == MVF_BF16) {
     const int ntile = ceil_div(N, 16);
     const dim3 fg(F * H, ceil_div(ntile, 8));   // streamed kernels: 8 query tiles per workgroup
     if (variant == 1) hipLaunchKernelGGL((vit_attn_bf16_kernel<false, KT>), grid, dim3(256), 0, st, a);
-    else if (attn_rowsum_rounded(N) && variant == 0)          // row sums on the matrix pipe: 73.8 -> 72.3 us, 1 358 -> 1 325 W sustained
+    else if (attn_one_block(N) && variant == 0)          // row sums on the matrix pipe: 73.8 -> 72.3 us, 1 358 -> 1 325 W sustained
       hipLaunchKernelGGL((vit_attn_bf16_pair_kernel<13, 3, false, true>), grid, dim3(256), 0, st, a);
     else if (a.nblk == 1 && ntile == 13 && variant == 6)     // row sums on the VALU from the unrounded probabilities (the earlier form)
       hipLaunchKernelGGL((vit_attn_bf16_pair_kernel<13, 3>), grid, dim3(256), 0, st, a);
@@ -642,7 +643,7 @@ int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H
   } else if (dtype == MVF_F16) {   // fp16 q / k / v / out: the two-tile kernel (N = 193 .. 208) or the streamed kernel (any N)
     const int ntile = ceil_div(N, 16);
     const dim3 fg(F * H, ceil_div(ntile, 8));
-    if (attn_rowsum_rounded(N)) hipLaunchKernelGGL((vit_attn_bf16_pair_kernel<13, 3, true, true>), grid, dim3(256), 0, st, a);
+    if (attn_one_block(N)) hipLaunchKernelGGL((vit_attn_bf16_pair_kernel<13, 3, true, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((vit_attn_bf16_flash_kernel<6, 3, 4, true>), fg, dim3(256), 0, st, a);   // variant 7 (variant 0 left above)
   } else if (dtype == MVF_F32) {
     static bool attr = false;

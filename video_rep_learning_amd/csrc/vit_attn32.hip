@@ -626,8 +626,9 @@ int launch32(const Attn32Args& g, int nw, hipStream_t st) {
 
 }  // namespace
 
-// form: 0 = 64-key blocks at 2 waves per SIMD (default), 1 = 96-key blocks, 2 = 128-key blocks, 3 = 64-key blocks at 3 waves per SIMD;
-// nw_force > 0: waves per workgroup
+// form: 5 = the product path (pipelined walk, 64-key blocks, row sums on the matrix pipe); 4 = the same with VALU row sums; 6 / 7 = 128-key
+// blocks (8 waves); 0 .. 3 = the unpipelined walk (64 / 96 / 128-key blocks, 64-key at 3 waves per SIMD), kept for A/B runs and as an
+// independent implementation the tests compare with.  nw_force > 0: waves per workgroup
 int mvf_vit_attn32_impl(int dtype, const void* qkv, void* out, float* lse, int F, int N, int H, int D, int form, int nw_force,
                         hipStream_t st) {
   MVF_CHECK_ARG(qkv && out && F > 0 && N > 0 && H > 0 && D == H * vit_attn::HD);
@@ -649,7 +650,7 @@ int mvf_vit_attn32_impl(int dtype, const void* qkv, void* out, float* lse, int F
   const bool f16 = dtype == MVF_F16;
   if (lse) {
     if (f16) return MVF_ERR_ARG;
-    return launch32<2, 2, false, true>(g, nw, st);
+    return launch32p<2, 2, false, true, true>(g, nw, st);
   }
   switch (form) {
     case 1: return f16 ? launch32<3, 2, true, false>(g, nw, st) : launch32<3, 2, false, false>(g, nw, st);

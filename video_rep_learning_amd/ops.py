@@ -480,17 +480,48 @@ def _sync_world(group):
     return dist.get_world_size(group) if collectives_active() else 0
 
 
-def sync_bn_stats(mean, var, count, group=None, equal_counts=False):
+_SYNCBN_BUFS = {}
+
+
+def syncbn_local_buffer(C, count, dev):
+    """The block a rank contributes to SyncBatchNorm's exchange, [mean C | biased var C | row count]: one persistent buffer per
+    (C, count, device) whose last word is written ONCE -- the statistics kernels write mean / var straight into its first 2C words
+    (views `[:C]`, `[C:2C]`), so the step needs no cat / fill kernel to assemble it."""
+    key = (int(C), float(count), str(dev))
+    b = _SYNCBN_BUFS.get(key)
+    if b is None:
+        b = torch.zeros(2 * C + 1, device=dev, dtype=torch.float32)
+        b[2 * C] = float(count)
+        _SYNCBN_BUFS[key] = b
+    return b
+
+
+def sync_bn_stats(mean, var, count, group=None, equal_counts=False, running=None, local=None):
     """Cross-rank batch statistics for SyncBatchNorm (train.py:283): every rank contributes (mean, biased var, row
     count) of its local rows -- 2C+1 floats, collective C2 of SURVEY.md -- and all ranks merge them with Chan's
     parallel-variance formula, which equals BatchNorm statistics over the rank-concatenated batch.
-    Plain torch + torch.distributed (no kernel): runs on gloo/CPU in the tests and on RCCL in training.
     `equal_counts`: every rank holds `count` rows (the data-parallel step: B x V x T x entities rows per rank, fixed by the
     config), so the global count is count x world ON THE HOST -- no device-to-host read, which would stall the host until
     the side-stream backbone forward the head waits for has finished and so undo the one-batch lookahead on every BatchNorm
-    of every step.  Ragged counts (equal_counts=False) read the gathered total back (one sync)."""
+    of every step.  Ragged counts (equal_counts=False) read the gathered total back (one sync).
+    running = (running_mean, running_var, momentum) or None: updated from the merged statistics like nn.BatchNorm1d in training.
+    On the device with equal counts (the training step): ONE all-gather into a [W, 2C+1] block + ONE kernel (mvf_syncbn_merge:
+    merge + running update) -- `local` is the rank's block from syncbn_local_buffer() when the caller had its statistics kernel write
+    there (else it is assembled here).  On CPU tensors (gloo tests, --plumbing) and for ragged counts: plain torch."""
     C = mean.numel()
     world = dist.get_world_size(group)
+    if mean.is_cuda and equal_counts:
+        if local is None:
+            local = syncbn_local_buffer(C, count, mean.device)
+            local[:C].copy_(mean)
+            local[C:2 * C].copy_(var)
+        gathered = torch.empty(world * (2 * C + 1), device=mean.device, dtype=torch.float32)   # flat: gloo's form of the call takes no 2-D output
+        dist.all_gather_into_tensor(gathered, local, group=group)
+        gm = torch.empty(C, device=mean.device, dtype=torch.float32)
+        gv = torch.empty_like(gm)
+        rm, rv, mom = running if running is not None else (None, None, 0.0)
+        call('mvf_syncbn_merge', ptr(gathered), world, C, float(count), ptr(gm), ptr(gv), ptr(rm), ptr(rv), float(mom), stream())
+        return gm, gv, float(count) * world
     local = torch.cat([mean, var, mean.new_tensor([float(count)])])
     gathered = [torch.empty_like(local) for _ in range(world)]
     dist.all_gather(gathered, local, group=group)
@@ -507,6 +538,11 @@ def sync_bn_stats(mean, var, count, group=None, equal_counts=False):
         total = float(n.sum())
         gm = (st[:, :C] * n).sum(0) / total
         gv = ((st[:, C:2 * C] + (st[:, :C] - gm) ** 2) * n).sum(0) / total
+    if running is not None and running[0] is not None:
+        rm, rv, mom = running
+        with torch.no_grad():
+            rm.mul_(1 - mom).add_(gm, alpha=mom)
+            rv.mul_(1 - mom).add_(gv, alpha=mom * total / max(total - 1.0, 1.0))
     return gm.contiguous(), gv.contiguous(), total
 
 
@@ -519,20 +555,24 @@ class _BatchNormTrain(torch.autograd.Function):
     def forward(ctx, x, g, b, running_mean, running_var, momentum, eps, relu, sync, group):
         x = x.contiguous()
         R, C = x.shape
-        mean = torch.empty(C, device=x.device, dtype=torch.float32)
-        var = torch.empty_like(mean)
         count = float(R)
         world = _sync_world(group) if sync else 0
+        local = None
+        if world > 0:                    # SyncBatchNorm: the statistics land in this rank's block of the exchange
+            local = syncbn_local_buffer(C, count, x.device)
+            mean, var = local[:C], local[C:2 * C]
+        else:
+            mean = torch.empty(C, device=x.device, dtype=torch.float32)
+            var = torch.empty_like(mean)
         ws = _bn_ws(R, C, x.device)
         local_running = world == 0       # the statistics kernel updates the running buffers itself
         call('mvf_bn_stats', ptr(x), R, C, ptr(mean), ptr(var), ptr(running_mean) if local_running else None,
              ptr(running_var) if local_running else None, float(momentum), ptr(ws), ws.numel(), stream())
         if world > 0:
-            # exchange (mean, biased var, count) and merge (Chan); 2C+1 floats per rank -- collective C2 of SURVEY.md
-            mean, var, count = sync_bn_stats(mean, var, count, group, equal_counts=True)
-            with torch.no_grad():
-                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                running_var.mul_(1 - momentum).add_(var, alpha=momentum * count / max(count - 1.0, 1.0))
+            # exchange (mean, biased var, count) and merge (Chan); 2C+1 floats per rank -- collective C2 of SURVEY.md; the merge kernel
+            # also moves the running buffers
+            mean, var, count = sync_bn_stats(mean, var, count, group, equal_counts=True,
+                                             running=(running_mean, running_var, momentum), local=local)
         y = torch.empty_like(x)
         call('mvf_bn_fwd', ptr(x), ptr(mean), ptr(var), ptr(g), ptr(b), ptr(y), R, C, eps, int(relu), stream())
         ctx.save_for_backward(x, g, b, mean, var)
@@ -1168,7 +1208,11 @@ class _RowLinChain(torch.autograd.Function):
             synced = st.sync is not None and st.bn_out is not None and training
             if st.bn_out is not None and training:
                 part = torch.empty(2 * G * N, device=dev, dtype=torch.float32)
-                mean, var = torch.empty(N, device=dev, dtype=torch.float32), torch.empty(N, device=dev, dtype=torch.float32)
+                sync_local = syncbn_local_buffer(N, float(M), dev) if synced else None   # SyncBatchNorm: this rank's block of the exchange
+                if synced:
+                    mean, var = sync_local[:N], sync_local[N:2 * N]
+                else:
+                    mean, var = torch.empty(N, device=dev, dtype=torch.float32), torch.empty(N, device=dev, dtype=torch.float32)
                 a.st_part, a.st_mean, a.st_var = ptr(part), ptr(mean), ptr(var)
                 rm, rv, mom = st.bn_out
                 if rm is not None and not synced:      # (SyncBatchNorm: the running buffers take the merged statistics, below)
@@ -1178,12 +1222,9 @@ class _RowLinChain(torch.autograd.Function):
             if synced:
                 # SyncBatchNorm: (mean, biased var, count) of every rank merged (Chan) between this launch and the next -- collective
                 # C2 of SURVEY.md, 2N + 1 floats per rank
-                mean, var, out_count = sync_bn_stats(stats[0], stats[1], float(M), st.sync[0], equal_counts=True)
                 rm, rv, mom = st.bn_out
-                if rm is not None:
-                    with torch.no_grad():
-                        rm.mul_(1 - mom).add_(mean, alpha=mom)
-                        rv.mul_(1 - mom).add_(var, alpha=mom * out_count / max(out_count - 1.0, 1.0))
+                mean, var, out_count = sync_bn_stats(stats[0], stats[1], float(M), st.sync[0], equal_counts=True,
+                                                     running=(rm, rv, mom) if rm is not None else None, local=sync_local)
                 stats = (mean, var)
             rec.append(dict(X=cur, Y=Y, bn=bn_stats, bn_count=in_count, xT=xT, nrm=nrm, g_arg=g_arg, M=M, Mp=Mp, Cin=Cin, Kin=Kin, N=N))
             in_count = out_count

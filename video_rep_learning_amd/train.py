@@ -30,8 +30,8 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 # backbone lane and RCCL's communication stream -- four already: leave room so that none of them ever shares a queue (8 / 16 queues measured
 # neutral on one GPU, profiles/r04/head_exposure.txt; with more than one rank unmeasured like everything multi-GPU here).  Read when the
 # runtime loads, hence before `import torch`.
-if int(os.environ.get('WORLD_SIZE', '1') or '1') > 1:
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+if (int(os.environ.get('WORLD_SIZE', '1') or '1') > 1 or os.environ.get('MVF_FORCE_REDUCER') == '1') and os.environ.get('MVF_HW_QUEUES', '8') != '0':
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', os.environ.get('MVF_HW_QUEUES', '8'))     # opt-out / A-B knob: MVF_HW_QUEUES=0 | n
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -33,13 +33,15 @@ sys.path.insert(0, ROOT)
 # the host driver only supports dmabuf IPC: without this RCCL's buffer exchange fails with `hipIpcGetMemHandle: invalid argument`
 # (exported on the GPU boxes already; set here too so that a bare launcher environment cannot lose it)
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-# Data-parallel runs: HIP deals a process's streams over GPU_MAX_HW_QUEUES (default 4) hardware queues in creation order, and two streams
-# on one queue run one after the other (profiles/r05/order_probe.txt).  One rank owns the caller's stream, the lookahead stream, the second
-# backbone lane and RCCL's communication stream -- four already: leave room so that none of them ever shares a queue (8 / 16 queues measured
-# neutral on one GPU, profiles/r04/head_exposure.txt; with more than one rank unmeasured like everything multi-GPU here).  Read when the
-# runtime loads, hence before `import torch`.
-if (int(os.environ.get('WORLD_SIZE', '1') or '1') > 1 or os.environ.get('MVF_FORCE_REDUCER') == '1') and os.environ.get('MVF_HW_QUEUES', '8') != '0':
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', os.environ.get('MVF_HW_QUEUES', '8'))     # opt-out / A-B knob: MVF_HW_QUEUES=0 | n
+# Hardware queues: HIP deals a process's streams over GPU_MAX_HW_QUEUES (default 4) hardware queues, and two streams on one queue run one
+# after the other (profiles/r05/order_probe.txt).  A data-parallel rank owns the caller's stream, the lookahead stream, the second backbone
+# lane and RCCL's communication stream.  Round 5 asked for 8 queues here, unmeasured; round 6 measured it on the forced one-rank RCCL step
+# (profiles/r06/rccl_forced_1rank.txt, three alternations on one box): plain step 10.67-10.73 ms, with the collectives live and the runtime's
+# 4 queues 10.85-10.87, with 8 or 16 queues 11.61-11.66 -- the all-reduce then completes at once (0.19 ms exposed instead of 7 ms of queueing
+# behind a backbone lane, which the one-batch lookahead hides anyway) but every step pays 0.76 ms for the extra queues.  So the runtime's
+# default stays; MVF_HW_QUEUES=<n> asks for n queues (A/B knob).  Read when the runtime loads, hence before torch is imported.
+if os.environ.get('MVF_HW_QUEUES', '0') not in ('', '0'):
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', os.environ['MVF_HW_QUEUES'])
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -166,6 +168,7 @@ def pmc_traffic(name):
 
 
 STAGE = {'name': 'start'}
+_KEEP_STREAMS = []
 
 
 def stage(name):
@@ -424,6 +427,18 @@ def main():
     stage('set_device %d' % local)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    if os.environ.get('MVF_STREAMS_FIRST', '0') != '0':
+        # experiment knob (tools/r6_rccl.sh): create the backbone's streams BEFORE the process group creates RCCL's, so that the
+        # hardware queues are dealt in that order
+        from video_rep_learning_amd import ops as _ops
+        for role in os.environ['MVF_STREAMS_FIRST'].split(','):
+            if role == 'dummy':
+                _KEEP_STREAMS.append(torch.cuda.Stream(device=dev))
+            elif role not in ('0', '1'):
+                _ops.backbone_stream(role, dev)
+        if os.environ['MVF_STREAMS_FIRST'] == '1':
+            for role in ('side', 'lane1'):
+                _ops.backbone_stream(role, dev)
     if world > 1 or os.environ.get('MVF_FORCE_REDUCER') == '1':
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')

@@ -206,6 +206,10 @@ int mvf_layernorm_fwd(int out_dtype, const float* x, size_t in_stride, const flo
  * 4 = streamed 64-key blocks and 7 = streamed 96-key blocks on 16-query tiles (the streamed kernel of rounds 2-5), 6 = the one-block
  * kernel with VALU row sums, 8 + form = a form of the 32-query-row kernel for any N (mvf_vit_attn32_impl), 32 + form + 16 * waves = the
  * same with a forced workgroup size */
+/* variant | MVF_ATTN_Q_PRESCALED (bf16 / fp16, variants 0, 6 and 13): the q columns of qkv already carry the factor log2(e) / 8 (the frozen
+ * backbone folds it into the q rows of the packed qkv weights and bias, in fp32 before their one rounding): scores are base-2 exponents,
+ * out = softmax2(q k^T) v with softmax2(s) = 2^s / sum 2^s */
+#define MVF_ATTN_Q_PRESCALED 0x1000
 int mvf_vit_attn_fwd(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t stream);
 /* softmax normalisation convention of the 16-bit product kernels (variant 0 and the fused qkv + attention kernel): 1 = the row sum is taken
  * over the probabilities AFTER their rounding to bf16 / fp16, on the matrix pipe beside P.V (every N since round 6), 0 = over the fp32

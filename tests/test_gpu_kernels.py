@@ -495,6 +495,31 @@ def test_vit_attention(N, dtype, variant):
     check(out, _attn_ref(qkv.cpu(), F, N, H), 2e-5 if dtype == 'f32' else 2e-2, 'vit_attn N=%d %s v%d' % (N, dtype, variant))
 
 
+@pytest.mark.parametrize('N', [197, 5, 33, 64, 65, 257, 577, 785])
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('variant', [0, 13, 6])
+@pytest.mark.parametrize('outgrow', [False, True])
+def test_vit_attention_with_prescaled_q(N, dtype, variant, outgrow):
+    """variant | MVF_ATTN_Q_PRESCALED: q carries log2(e) / 8 already (the frozen backbone folds it into the packed qkv weights), the
+    kernels compute softmax2(q k^T) v = softmax(ln 2 . q k^T) v.  The streamed kernel then feeds the reference maximum to the score
+    tiles as the MFMA's initial accumulator; outgrow: keys from 40 on 25 x larger -- its careful walk."""
+    if variant == 6 and not 193 <= N <= 208:
+        pytest.skip('the one-block kernel serves 193..208 tokens')
+    code, tdt = (_lib.F16, torch.float16) if dtype == 'fp16' else (_lib.BF16, torch.bfloat16)
+    F, H, D = 2, 3, 192
+    qkv = torch.randn(F, N, 3, H, 64, generator=gen(150)) * 1.5
+    qkv[:, :, 0] *= 0.18
+    if outgrow:
+        qkv[0, 40:, 1] *= 25.0
+    qkv = qkv.reshape(F * N, 3 * D).to(DEV).to(tdt)
+    out = torch.full((F * N, D), 7.0, device=DEV, dtype=tdt)
+    _lib.call('mvf_vit_attn_fwd', code, qkv.data_ptr(), out.data_ptr(), F, N, H, D, variant | 0x1000, S())
+    q, k, v = qkv.double().cpu().view(F, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * math.log(2.0), -1) @ v).transpose(1, 2).reshape(F * N, D)
+    assert torch.isfinite(out.float()).all()
+    check(out, ref, 2e-2 if dtype == 'bf16' else 4e-3, 'vit_attn prescaled q N=%d %s v%d' % (N, dtype, variant))
+
+
 @pytest.mark.parametrize('N', [65, 257, 577])
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
 @pytest.mark.parametrize('variant', [0, 8, 12, 13, 14, 15])

@@ -624,6 +624,16 @@ int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H
   dim3 grid(F * H, chunks);
   // the streamed 32-query-row kernel (vit_attn32.hip): the product path of every N outside the one-block specialisation; variants
   // 8 .. 23 select its forms for any N, 32 + form + 16 * waves also the workgroup size (A/B runs, tests)
+  // + 0x1000: the q columns are pre-scaled by log2(e) / 8 (MVF_ATTN_Q_PRESCALED: the frozen backbone's packed weights carry the factor)
+  const bool qs = (variant & MVF_ATTN_Q_PRESCALED) != 0;
+  variant &= ~MVF_ATTN_Q_PRESCALED;
+  if (qs) {
+    MVF_CHECK_ARG(dtype == MVF_BF16 || dtype == MVF_F16);
+    a.scale_log2 = 1.0f;       // the one-block kernels: the same arithmetic with the factor already in q
+    if (variant == 0 && !attn_one_block(N)) return mvf_vit_attn32_impl(dtype, qkv, out, nullptr, F, N, H, D, 5 + 16, 0, st);
+    if (variant == 8 + 5) return mvf_vit_attn32_impl(dtype, qkv, out, nullptr, F, N, H, D, 5 + 16, 0, st);
+    MVF_CHECK_ARG(variant == 0 || variant == 6);
+  }
   if ((dtype == MVF_BF16 || dtype == MVF_F16) && ((variant == 0 && !attn_one_block(N)) || (variant >= 8 && variant < 24)))
     return mvf_vit_attn32_impl(dtype, qkv, out, nullptr, F, N, H, D, variant == 0 ? 5 : variant - 8, 0, st);
   if ((dtype == MVF_BF16 || dtype == MVF_F16) && variant >= 32 && variant < 32 + 144)

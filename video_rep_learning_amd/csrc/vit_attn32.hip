@@ -299,7 +299,10 @@ __global__ __launch_bounds__(512, OCC) void vit_attn32_kernel(Attn32Args g) {
 // compile-time constant (the tile loop is unrolled over the 3 * NKT slots): every LDS offset is an immediate.
 // MSUM: the row sums as two more MFMAs per tile against an all-ones V^T fragment (sum of the ROUNDED probabilities, every lane of a
 // query gets it whole) instead of 16 v_add per tile and lane.
-template <int NKT, int OCC, bool F16, bool LSE, bool MSUM>
+// QS: the q columns arrive PRE-SCALED by log2(e) / 8 (the frozen backbone's packed qkv weights carry the factor, applied in fp32 before
+// their one rounding: ops.PackedViT), so a score is already the exponent.  The reference maximum then enters the score tiles as the
+// MFMA's initial accumulator (-m in every register: S' = K Q^T - m) and a probability is exp2(S') -- no v_fma per score.
+template <int NKT, int OCC, bool F16, bool LSE, bool MSUM, bool QS = false>
 __global__ __launch_bounds__(512, OCC) void vit_attn32p_kernel(Attn32Args g) {
   const AttnArgs& a = g.a;
   constexpr int KROWS = NKT * 32;
@@ -390,10 +393,17 @@ __global__ __launch_bounds__(512, OCC) void vit_attn32p_kernel(Attn32Args g) {
   union { bf16x8_t v; uint32_t u[4]; } ones;
   ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = F16 ? 0x3C003C00u : 0x3F803F80u;
 
+  f32x16_t negm;                     // QS: -m_use in every register, the score tiles' initial accumulator (zero until tile 0 is known)
+#pragma unroll
+  for (int e = 0; e < 16; ++e) negm[e] = 0.f;
   auto qk = [&](int soff) __attribute__((always_inline)) {
     f32x16_t s;
+    if constexpr (QS) {
+      s = negm;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+      for (int e = 0; e < 16; ++e) s[e] = 0.f;
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(smem + koff[ks] + soff);
@@ -454,8 +464,8 @@ __global__ __launch_bounds__(512, OCC) void vit_attn32p_kernel(Attn32Args g) {
     float ls[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 16; e += 2) {
-      const float p0 = __builtin_amdgcn_exp2f(fmaf(sc[e], a.scale_log2, nm));
-      const float p1 = __builtin_amdgcn_exp2f(fmaf(sc[e + 1], a.scale_log2, nm));
+      const float p0 = __builtin_amdgcn_exp2f(QS ? sc[e] : fmaf(sc[e], a.scale_log2, nm));
+      const float p1 = __builtin_amdgcn_exp2f(QS ? sc[e + 1] : fmaf(sc[e + 1], a.scale_log2, nm));
       pp[e >> 1] = pack16x2<F16>(p0, p1);
       if constexpr (!MSUM) { ls[e & 3] += p0; ls[(e + 1) & 3] += p1; }
     }
@@ -489,18 +499,19 @@ __global__ __launch_bounds__(512, OCC) void vit_attn32p_kernel(Attn32Args g) {
         mx = fmaxf(mx, s[e]);
       }
       mx = pair_max(mx);
+      const float csc = QS ? 1.0f : a.scale_log2;
       const float m_new = fmaxf(m_use, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_use - m_new) * a.scale_log2);   // 0 on the first tile
+      const float alpha = __builtin_amdgcn_exp2f((m_use - m_new) * csc);   // 0 on the first tile
       m_use = m_new;
-      const float nmc = -m_new * a.scale_log2;
+      const float nmc = -m_new * csc;
       l_part *= alpha;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; lacc[e] *= alpha; }
       uint32_t pq[8];
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[e], a.scale_log2, nmc));
-        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[e + 1], a.scale_log2, nmc));
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[e], csc, nmc));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[e + 1], csc, nmc));
         pq[e >> 1] = pack16x2<F16>(p0, p1);
         l_part += p0 + p1;
       }
@@ -537,8 +548,15 @@ __global__ __launch_bounds__(512, OCC) void vit_attn32p_kernel(Attn32Args g) {
     for (int e = 3; e + 1 < 16; e += 2) mx = max3f(mx, sA[e], sA[e + 1]);
     mx = pair_max3(max3f(mx, sA[15], sA[15]));
     m_use = mx;
-    m_lim = mx + g.thr;
-    nm = -mx * a.scale_log2;
+    if constexpr (QS) {
+      // from here on every score tile is born relative to the reference (tile 0 itself: one subtraction per score, once)
+      m_lim = g.thr;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { negm[e] = -mx; sA[e] -= mx; }
+    } else {
+      m_lim = mx + g.thr;
+      nm = -mx * a.scale_log2;
+    }
   }
   static_assert(NS % 2 == 0, "the score tiles alternate between two register blocks with the tile's parity");
   int i0 = 0;
@@ -578,7 +596,7 @@ __global__ __launch_bounds__(512, OCC) void vit_attn32p_kernel(Attn32Args g) {
   const float inv = 1.0f / l_run;
   if constexpr (LSE) {
     if (q < a.N && hh == 0)   // p = exp2(s * scale_log2 - lse) reproduces the normalised probability
-      a.lse[((size_t)f * a.H + h) * a.npad + q] = fmaf(m_use, a.scale_log2, __builtin_amdgcn_logf(l_run));
+      a.lse[((size_t)f * a.H + h) * a.npad + q] = fmaf(m_use, QS ? 1.0f : a.scale_log2, __builtin_amdgcn_logf(l_run));
   }
   bf16_t* orow = reinterpret_cast<bf16_t*>(a.out) + ((size_t)f * a.N + min(q, a.N - 1)) * a.D + h * HD;
 #pragma unroll
@@ -594,17 +612,17 @@ __global__ __launch_bounds__(512, OCC) void vit_attn32p_kernel(Attn32Args g) {
     }
 }
 
-template <int NKT, int OCC, bool F16, bool LSE, bool MSUM>
+template <int NKT, int OCC, bool F16, bool LSE, bool MSUM, bool QS = false>
 int launch32p(const Attn32Args& g, int nw, hipStream_t st) {
   constexpr size_t LDS = (size_t)6 * NKT * 32 * 128;
   static uint64_t done = 0;
-  const void* fn = reinterpret_cast<const void*>(vit_attn32p_kernel<NKT, OCC, F16, LSE, MSUM>);
+  const void* fn = reinterpret_cast<const void*>(vit_attn32p_kernel<NKT, OCC, F16, LSE, MSUM, QS>);
   if (LDS > 48 * 1024) {
     const int rc = mvf_ensure_lds(fn, LDS, done);
     if (rc != MVF_OK) return rc;
   }
   const int grid = ceil_div(g.nunits, 8) * 8 * g.nchunk;
-  hipLaunchKernelGGL((vit_attn32p_kernel<NKT, OCC, F16, LSE, MSUM>), dim3(grid), dim3(nw * 64), LDS, st, g);
+  hipLaunchKernelGGL((vit_attn32p_kernel<NKT, OCC, F16, LSE, MSUM, QS>), dim3(grid), dim3(nw * 64), LDS, st, g);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }
@@ -634,7 +652,7 @@ int mvf_vit_attn32_impl(int dtype, const void* qkv, void* out, float* lse, int F
   MVF_CHECK_ARG(qkv && out && F > 0 && N > 0 && H > 0 && D == H * vit_attn::HD);
   MVF_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0);
   MVF_CHECK_ARG(dtype == MVF_BF16 || dtype == MVF_F16);
-  MVF_CHECK_ARG(nw_force >= 0 && nw_force <= 8);
+  MVF_CHECK_ARG(nw_force >= 0 && nw_force <= 8 && (lse == nullptr || form < 16));
   Attn32Args g;
   g.a.qkv = (const char*)qkv; g.a.out = (char*)out; g.a.N = N; g.a.H = H; g.a.D = D;
   g.a.nblk = 0; g.a.rounds = 0;
@@ -651,6 +669,10 @@ int mvf_vit_attn32_impl(int dtype, const void* qkv, void* out, float* lse, int F
   if (lse) {
     if (f16) return MVF_ERR_ARG;
     return launch32p<2, 2, false, true, true>(g, nw, st);
+  }
+  if (form == 5 + 16) {   // the product path of a backbone whose q columns are pre-scaled by log2(e) / 8: scores are exponents
+    g.thr = dtype == MVF_F16 ? 15.0f : 30.0f;
+    return f16 ? launch32p<2, 2, true, false, true, true>(g, nw, st) : launch32p<2, 2, false, false, true, true>(g, nw, st);
   }
   switch (form) {
     case 1: return f16 ? launch32<3, 2, true, false>(g, nw, st) : launch32<3, 2, false, false>(g, nw, st);

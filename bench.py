@@ -282,9 +282,10 @@ def parity_block(model, batch, nv, dev, reduced='bf16'):
     params = T.cpu_params(m0)
     t0 = time.time()
     ref = {}
-    # the benchmarked run's head dtype (MI355X.HEAD_DTYPE, bf16 beside a bf16 backbone): the reduced mode of this block runs the
-    # same head, and the oracle rounds the operands of the Linears the device runs on the bf16 matrix cores (oracle/head.py)
-    head_red = model.head_dtype if reduced != 'fp16' else 'fp32'
+    # the benchmarked run's head dtype (MI355X.HEAD_DTYPE: bf16 beside a bf16 backbone, fp16 beside an fp16 one): the reduced mode of this
+    # block runs the same head, and the oracle rounds the operands of the Linears the device runs on the 16-bit matrix cores the same way
+    # (oracle/head.py: 'bf16' everywhere, or 'fp16' = forward operands fp16 / gradient operands bf16)
+    head_red = model.head_dtype
     m0.set_head_dtype(head_red)
     head_pre = m0.head_bf16_linears()
     head_pre = tuple('embed.' + q for q in head_pre) + head_pre
@@ -293,7 +294,7 @@ def parity_block(model, batch, nv, dev, reduced='bf16'):
         for mode in ('fp32', reduced):
             vcfg = dict(vit_cfg, emulate=reduced) if mode == reduced else vit_cfg
             feat, cls = OM.backbone_features(vc.reshape(b * v * t, *vc.shape[3:]), params, vcfg)
-            with T.OH.emulating(head_pre if mode == reduced else ()):
+            with T.OH.emulating(head_pre if mode == reduced else (), 'fp16' if head_red == 'fp16' else 'bf16'):
                 ref[mode] = (OM.forward_from_backbone(feat, cls, b * v, t, params, vcfg, head_cfg, mc.reshape(b * v, 1, t),
                                                       project=False, training=False),
                              OM.loss_from_backbone(feat, cls, sc, stc, mc, params, vcfg, head_cfg, scl_cfg, training=True))
@@ -336,6 +337,8 @@ def parity_block(model, batch, nv, dev, reduced='bf16'):
     loss_err_red = abs(out['hip_loss_' + reduced] - lemu) / max(abs(lemu), 0.25)
     out['ok'] = bool(out['loss_rel_fp32'] <= 1e-3 and out['emb_maxrel_fp32'] <= 1e-3 and
                      loss_err_red <= BF16_GATES[0] and out['emb_maxrel_' + reduced] <= BF16_GATES[1])
+    if reduced == 'fp16':     # the accuracy mode: fp16 backbone + fp16-forward head must itself sit inside the north star's tolerance
+        out['north_star_1e-3_met_by_fp16_mode'] = bool(out['emb_maxrel_fp16_vs_fp32_oracle'] <= 1e-3)
     return out
 
 

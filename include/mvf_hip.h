@@ -408,6 +408,7 @@ typedef struct MvfPackEntry {
   int N, K;
   void* w16;
   void* w16t;
+  int f16;                     /* != 0: w16 (the FORWARD operand) is written as IEEE fp16 (MI355X.HEAD_DTYPE fp16); w16t stays bf16 */
 } MvfPackEntry;
 int mvf_head_pack_weights(const MvfPackEntry* entries_host, int n, hipStream_t stream);
 /* measurement knob of tools/chain_probe.py (0 = product behaviour): see csrc/head_chain.hip g_chain_dbg */
@@ -443,6 +444,8 @@ typedef struct MvfEncFwd {
   const float *bqkv, *ln0_g, *ln0_b;
   float *qkv, *mean0, *rstd0;
   void* h0T;
+  int f16;                     /* != 0: wo / w1 / w2 / wqkv are IEEE fp16 images and the four GEMMs run on fp16 operands (the saved a and the
+                                * transposed images oT / h1T / aT / h0T stay what the bf16 backward reads: a's sign / zero bits, bf16 values) */
 } MvfEncFwd;
 int mvf_enc_layer_fwd(const MvfEncFwd* args_host, hipStream_t stream);
 
@@ -509,6 +512,7 @@ typedef struct MvfRowLinFwd {
   void* xT;
   float *st_part, *st_mean, *st_var, *st_rmean, *st_rvar;
   float st_momentum;
+  int f16;                     /* != 0: w16 is an IEEE fp16 image (MvfPackEntry.f16) and the GEMM runs on fp16 operands; xT stays bf16 */
 } MvfRowLinFwd;
 int mvf_rowlin_fwd(const MvfRowLinFwd* args_host, hipStream_t stream);
 

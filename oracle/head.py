@@ -82,29 +82,34 @@ class HeadCfg:
 # ----------------------------------------------------------------------------
 # primitives
 # ----------------------------------------------------------------------------
-# Emulation of the 16-bit head (csrc/head_chain.hip; MI355X.HEAD_DTYPE bf16): the SAME restatement with a round-to-nearest-even
-# bf16 rounding of both GEMM operands of the Linears the device runs on the bf16 matrix cores -- forward (x, W), input gradient
+# Emulation of the 16-bit head (csrc/head_chain.hip; MI355X.HEAD_DTYPE bf16 / fp16): the SAME restatement with a round-to-nearest-even
+# rounding of both GEMM operands of the Linears the device runs on the 16-bit matrix cores -- forward (x, W), input gradient
 # (dy, W) and weight gradient (dy, x); the bias gradient sums the rounded dy (the device sums the operand it has).  Everything
-# else (accumulation, bias, LayerNorm, BatchNorm, softmax, residual stream) stays in the oracle's precision.  `prefixes`: the
-# parameter-name prefixes of the Linears concerned (None: all).  Off by default: plain matmul.
+# else (accumulation, bias, LayerNorm, BatchNorm, softmax, residual stream) stays in the oracle's precision.
+#   mode 'bf16': every operand rounded to bf16.
+#   mode 'fp16': the FORWARD operands rounded to IEEE fp16; the gradient products as in bf16 mode -- dy and W rounded to bf16, and the
+#                saved activation x is the forward's fp16 value rounded once more to bf16 (the forward kernel writes its transposed
+#                operand image that way).
+# `prefixes`: the parameter-name prefixes of the Linears concerned (None: all).  Off by default: plain matmul.
 EMU = {'mode': None, 'prefixes': None}
 
 
 def emulate_head(mode=None, prefixes=None):
-    assert mode in (None, 'bf16'), mode
+    assert mode in (None, 'bf16', 'fp16'), mode
     EMU.update(mode=mode, prefixes=None if prefixes is None else tuple(prefixes))
 
 
 class emulating:
-    """with emulating(prefixes): ...  -- bf16 emulation of the Linears under these name prefixes (empty / None: plain oracle)."""
+    """with emulating(prefixes[, mode]): ...  -- 16-bit emulation of the Linears under these name prefixes (empty / None: plain oracle)."""
 
-    def __init__(self, prefixes):
+    def __init__(self, prefixes, mode='bf16'):
         self.prefixes = tuple(prefixes) if prefixes else None
+        self.mode = mode
 
     def __enter__(self):
         self.saved = dict(EMU)
         if self.prefixes:
-            emulate_head('bf16', self.prefixes)
+            emulate_head(self.mode, self.prefixes)
         else:
             emulate_head(None)
 
@@ -117,13 +122,21 @@ def bf16r(t):
     return t.to(torch.bfloat16).to(t.dtype)
 
 
+def f16r(t):
+    return t.to(torch.float16).to(t.dtype)
+
+
 class _EmuLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b):
-        xr, wr = bf16r(x), bf16r(w)
-        ctx.save_for_backward(xr, wr)
+    def forward(ctx, x, w, b, f16):
+        if f16:
+            xf, wf = f16r(x), f16r(w)
+            ctx.save_for_backward(bf16r(xf), bf16r(w))
+        else:
+            xf, wf = bf16r(x), bf16r(w)
+            ctx.save_for_backward(xf, wf)
         ctx.has_b = b is not None
-        y = xr @ wr.t()
+        y = xf @ wf.t()
         return y + b if b is not None else y
 
     @staticmethod
@@ -131,12 +144,12 @@ class _EmuLinear(torch.autograd.Function):
         xr, wr = ctx.saved_tensors
         g = bf16r(dy)
         g2, x2 = g.reshape(-1, g.shape[-1]), xr.reshape(-1, xr.shape[-1])
-        return g @ wr, g2.t() @ x2, (g2.sum(0) if ctx.has_b else None)
+        return g @ wr, g2.t() @ x2, (g2.sum(0) if ctx.has_b else None), None
 
 
 def linear(x, p, name):
     if EMU['mode'] is not None and (EMU['prefixes'] is None or name.startswith(EMU['prefixes'])):
-        return _EmuLinear.apply(x, p[name + '.weight'], p.get(name + '.bias'))
+        return _EmuLinear.apply(x, p[name + '.weight'], p.get(name + '.bias'), EMU['mode'] == 'fp16')
     y = x @ p[name + '.weight'].t()
     if name + '.bias' in p:
         y = y + p[name + '.bias']
@@ -219,6 +232,10 @@ def encoder(x, mask, p, pre, n_layers, heads, eps=1e-5):
         x = x + mha(h, mask, p, lp + 'self_att.', heads)
         h = layer_norm(x, p[lp + 'res_layer1.norm.weight'], p[lp + 'res_layer1.norm.bias'], eps)
         h = relu(linear(h, p, lp + 'feed_forward.fc1'))
+        if EMU['mode'] == 'fp16' and (EMU['prefixes'] is None or (lp + 'feed_forward.fc1').startswith(EMU['prefixes'])):
+            # the device keeps this activation (and takes the ReLU mask of the backward from it) as IEEE fp16 with subnormals flushed:
+            # a positive pre-activation below 2^-14 is a zero there, value and mask (measured: tools/head_fp16_debug2.py)
+            h = h * (h.detach() >= 2.0 ** -14).to(h.dtype)
         x = x + linear(h, p, lp + 'feed_forward.fc2')
     return x
 

@@ -199,6 +199,13 @@ def test_full_size_fp32_and_bf16_vs_oracle(tag):
         # flips: tests/test_gpu_head_chain.py); bounds = about 2x what was measured
         assert rh['loss_emu'] <= 2e-3 and rh['grad_cos'] >= 0.995 and rh['grad_all'] <= 0.1, rh
         assert rh['grad_all'] <= 1.5 * rh['grad_all_dtype'] + 1e-2 and rh['grad_dev'] <= 1.5 * rh['grad_dtype'] + 2e-2, rh
+        # ---- the fp16 HEAD (round 6: the default beside a reduced-precision backbone, the benchmarked path): forward GEMMs on fp16
+        # operands, gradient GEMMs on bf16 -- the loss (a forward quantity) sits 8 x closer to the plain oracle head, the gradients where
+        # the bf16 head's are
+        rf = T.bf16_head_report(cfg, model, videos, seq_lens, steps, masks, head='fp16')
+        record_parity('%s HIP %s' % (tag, rf['text']))
+        assert rf['loss_emu'] <= 1e-3 and rf['loss_fp'] <= 1e-3 and rf['grad_cos'] >= 0.995 and rf['grad_all'] <= 0.1, rf
+        assert rf['grad_all'] <= 1.5 * rf['grad_all_dtype'] + 1e-2 and rf['grad_dev'] <= 1.5 * rf['grad_dtype'] + 2e-2, rf
         model.set_head_dtype('fp32')
 
 

@@ -414,8 +414,8 @@ def bf16_mode_report(cfg, model, videos, seq_lens, steps, masks, ref_emb_fp32=No
     return out
 
 
-def bf16_head_report(cfg, model, videos, seq_lens, steps, masks):
-    """MI355X.HEAD_DTYPE bf16 (row-chain kernels, csrc/head_chain.hip) on one batch, dropout 0: the oracle HEAD fed with the device's
+def bf16_head_report(cfg, model, videos, seq_lens, steps, masks, head='bf16'):
+    """MI355X.HEAD_DTYPE bf16 | fp16 (`head`; row-chain kernels, csrc/head_chain.hip) on one batch, dropout 0: the oracle HEAD fed with the device's
     own taps, once with the bf16 emulation of the Linears the device runs in bf16 (oracle/head.py emulating) and once plain.
     Returns loss deviations and, per parameter tensor, the rel-L2 of the gradients: device vs emulating oracle, and emulating vs
     plain oracle (= what the dtype itself costs: the device must sit inside that)."""
@@ -423,9 +423,9 @@ def bf16_head_report(cfg, model, videos, seq_lens, steps, masks):
     b, t = cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.NUM_FRAMES
     x = videos.view(b * 2, t, *videos.shape[3:])
     params = cpu_params(model)
-    model.set_head_dtype('bf16')
+    model.set_head_dtype(head)
     prefixes = model.head_bf16_linears()
-    assert prefixes, 'the bf16 head does not cover this configuration'
+    assert prefixes, 'the 16-bit head does not cover this configuration'
     model.eval()
     with torch.no_grad():
         taps, cls_dev = model.features(x.to(DEV))
@@ -436,7 +436,7 @@ def bf16_head_report(cfg, model, videos, seq_lens, steps, masks):
         leaves = {k: params[k].clone().requires_grad_(True) for k in OM.trainable_names(params)}
         p = dict(params)
         p.update(leaves)
-        with OH.emulating(pre):
+        with OH.emulating(pre, head):
             vc = vit_cfg if model.compute_dtype in ('fp32', 'f32') else dict(vit_cfg, emulate=model.compute_dtype)
             loss = OM.loss_from_backbone(feat_dev, cls_c, seq_lens, steps, masks, p, vc, head_cfg, scl_cfg, training=True)
             loss.backward()
@@ -468,7 +468,7 @@ def bf16_head_report(cfg, model, videos, seq_lens, steps, masks):
     out = dict(loss_emu=relerr(loss, l_emu), loss_fp=relerr(loss, l_fp), grad_dev=dev[0], grad_dev_name=dev[1], grad_dtype=dt[0],
                grad_dtype_name=dt[1], grad_cos=cos, grad_cos_dtype=cos_dt, grad_all=((va - vb).norm() / vb.norm()).item(),
                grad_all_dtype=((vb - vc).norm() / vc.norm()).item(), prefixes=prefixes)
-    out['text'] = ('bf16 head (%s) on the DEVICE taps: loss %.6f, rel %.3e vs emulating oracle head, %.3e vs plain oracle head; head gradient '
+    out['text'] = (head + ' head (%s) on the DEVICE taps: loss %.6f, rel %.3e vs emulating oracle head, %.3e vs plain oracle head; head gradient '
                    '(all tensors) rel-L2 %.3e / cosine %.5f vs emulating oracle -- the dtype itself (emulating vs plain oracle): %.3e / '
                    '%.5f; worst tensor (error over max(own norm, 3e-3 of the whole gradient)): device vs emulating %.3e (%s), emulating '
                    'vs plain %.3e (%s)' % (', '.join(prefixes), loss.item(), out['loss_emu'], out['loss_fp'], out['grad_all'], cos,

@@ -147,7 +147,7 @@ class MvfDrop(ctypes.Structure):
 
 class MvfPackEntry(ctypes.Structure):
     """Mirror of `struct MvfPackEntry`."""
-    _fields_ = [('w', _P), ('ld', _L), ('N', _I), ('K', _I), ('w16', _P), ('w16t', _P)]
+    _fields_ = [('w', _P), ('ld', _L), ('N', _I), ('K', _I), ('w16', _P), ('w16t', _P), ('f16', _I)]
 
 
 class MvfEncFwd(ctypes.Structure):
@@ -156,7 +156,8 @@ class MvfEncFwd(ctypes.Structure):
                 + [(n, _P) for n in ('o', 'x_in', 'wo', 'w1', 'w2', 'bo', 'b1', 'b2', 'ln1_g', 'ln1_b')]
                 + [('drop_attn', MvfDrop), ('drop_ffn', MvfDrop)]
                 + [(n, _P) for n in ('x1', 'mean1', 'rstd1', 'a', 'x2', 'oT', 'h1T', 'aT', 'wqkv', 'bqkv', 'ln0_g', 'ln0_b',
-                                     'qkv', 'mean0', 'rstd0', 'h0T')])
+                                     'qkv', 'mean0', 'rstd0', 'h0T')]
+                + [('f16', _I)])
 
 
 class MvfEncBwd(ctypes.Structure):
@@ -175,7 +176,7 @@ class MvfRowLinFwd(ctypes.Structure):
                 ('g_arg', _P), ('bn_mean', _P), ('bn_var', _P), ('bn_g', _P), ('bn_b', _P), ('bn_eps', _F), ('bn_relu', _I),
                 ('oh_ntok', _I), ('oh_div', _I), ('drop_in', MvfDrop), ('drop_out', MvfDrop), ('w16', _P), ('bias', _P), ('table', _P),
                 ('tab_mod', _I), ('l2norm', _I), ('l2_eps', _F), ('Y', _P), ('nrm', _P), ('xT', _P), ('st_part', _P), ('st_mean', _P),
-                ('st_var', _P), ('st_rmean', _P), ('st_rvar', _P), ('st_momentum', _F)]
+                ('st_var', _P), ('st_rmean', _P), ('st_rvar', _P), ('st_momentum', _F), ('f16', _I)]
 
 
 class MvfRowLinBwd(ctypes.Structure):

@@ -64,7 +64,8 @@ __host__ __device__ inline int fm_steps(int red) { return ((red + 127) & ~127) >
 // out[m][n .. n+3] (bias, residual), requested BEFORE the k loop of the chunk (loads inside the epilogue serialise behind the
 // epilogue's own global stores -- the compiler must assume they alias).  epi(m, n, v, aux): the lane's four results.
 // NT: 16-column tiles per wave and chunk; PF: k-steps in flight (NT * PF fragment loads per wave); steps % PF == 0 (PF <= 4).
-template <int NT, int PF, typename Pre, typename Epi>
+// F16: both operands IEEE fp16 (the FORWARD GEMMs of MI355X.HEAD_DTYPE fp16; the backward GEMMs stay bf16: head_chain.hip header)
+template <int NT, int PF, bool F16 = false, typename Pre, typename Epi>
 __device__ __forceinline__ void chain_gemm(const bf16_t* A, int lda, int K, const bf16_t* __restrict__ W, int N, Pre pre, Epi epi) {
   // Software pipeline: the W fragments of PF k-steps are in flight in a ring of registers that is refilled in place right after
   // the MFMAs that consumed a slot -- straight-line code, no branch around a load (a conditional refill made hipcc load into
@@ -104,8 +105,8 @@ __device__ __forceinline__ void chain_gemm(const bf16_t* A, int lda, int K, cons
         __builtin_amdgcn_sched_barrier(0);     // the next step's A fragments are requested BEFORE this step's MFMAs
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[p][nt], a0, acc[0][nt], 0, 0, 0);
-          acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[p][nt], a1, acc[1][nt], 0, 0, 0);
+          acc[0][nt] = mfma16x16x32<F16>(bq[p][nt], a0, acc[0][nt]);
+          acc[1][nt] = mfma16x16x32<F16>(bq[p][nt], a1, acc[1][nt]);
         }
         const int sr = min(st + PF, nsteps - 1);
 #pragma unroll
@@ -121,11 +122,25 @@ __device__ __forceinline__ void chain_gemm(const bf16_t* A, int lda, int K, cons
   }
 }
 
+// one fp32 -> the panel's 16-bit format (bf16, or IEEE fp16 in the forward kernels of the fp16 head)
+template <bool F16>
+__device__ __forceinline__ bf16_t f32_to_16(float v) {
+  if constexpr (F16) return f32_to_f16(v);
+  else return f32_to_bf16(v);
+}
+// a 16-bit panel value as the bf16 the weight-gradient launch multiplies (identity for a bf16 panel)
+template <bool F16>
+__device__ __forceinline__ unsigned to_bf16_bits(unsigned h) {
+  if constexpr (F16) return f32_to_bf16(f16_to_f32((uint16_t)h));
+  else return h;
+}
+
 // ---- panel helpers (all 256 threads; the caller places the barriers) ----
 
 // fp32 global rows [m0, m0 + 32) x [0, C) (row stride ld) -> bf16 panel; rows >= M read as 0.  C % 4 == 0.
 // (batches of 8 loads per thread are issued before the first is used: a run-time loop of load -> convert -> store pays one
 // memory round trip per iteration)
+template <bool F16 = false>
 __device__ __forceinline__ void load_rows_bf16(const float* __restrict__ src, long ld, int m0, int M, int C, bf16_t* P, int ldp) {
   const int c4 = C >> 2, total = TM * c4;
   constexpr int U = 8;
@@ -140,7 +155,7 @@ __device__ __forceinline__ void load_rows_bf16(const float* __restrict__ src, lo
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = i0 + u * NTH, r = i / c4, q = i - r * c4;
-      if (i < total) *reinterpret_cast<u32x2_t*>(P + r * ldp + 4 * q) = (u32x2_t){pack_bf16x2(v[u][0], v[u][1]), pack_bf16x2(v[u][2], v[u][3])};
+      if (i < total) *reinterpret_cast<u32x2_t*>(P + r * ldp + 4 * q) = (u32x2_t){pack16x2<F16>(v[u][0], v[u][1]), pack16x2<F16>(v[u][2], v[u][3])};
     }
   }
 }
@@ -170,6 +185,8 @@ __device__ __forceinline__ void load_rows_f32(const float* __restrict__ src, lon
 // lanes c + 16 g of that fragment.  Rows >= M are written as 0 (they would otherwise carry bias / LayerNorm-beta values into the
 // weight gradients); the last row block also clears the steps up to the padded Mp.  Features >= C up to the padded 64 are never
 // read (the gradient kernel clamps its tile rows).
+// F16: the panel holds fp16 (forward of the fp16 head); the image is written as bf16, the weight-gradient launch's operand format
+template <bool F16 = false>
 __device__ __forceinline__ void store_T(const bf16_t* P, int ldp, int C, bf16_t* __restrict__ dst, int Mp, int m0, int M) {
   if (dst == nullptr) return;
   const int valid = min(TM, M - m0);
@@ -178,7 +195,7 @@ __device__ __forceinline__ void store_T(const bf16_t* P, int ldp, int C, bf16_t*
     unsigned w[TM / 2];
 #pragma unroll
     for (int r = 0; r < TM; r += 2) {
-      const unsigned lo = r < valid ? P[r * ldp + cc] : 0u, hi = r + 1 < valid ? P[(r + 1) * ldp + cc] : 0u;
+      const unsigned lo = r < valid ? to_bf16_bits<F16>(P[r * ldp + cc]) : 0u, hi = r + 1 < valid ? to_bf16_bits<F16>(P[(r + 1) * ldp + cc]) : 0u;
       w[r >> 1] = lo | (hi << 16);
     }
     bf16_t* o = dst + (((size_t)(cc >> 4) * msteps + ms) * 64 + (cc & 15)) * 8;
@@ -212,6 +229,7 @@ __device__ __forceinline__ float sum16(float v) {
   v += __shfl_xor(v, 8, 64);
   return v;
 }
+template <bool F16 = false>
 __device__ __forceinline__ void ln_panel(const float* X, int ldx, int D, const float* __restrict__ gam, const float* __restrict__ bet,
                                          float eps, bf16_t* H, int ldh, float* __restrict__ mean, float* __restrict__ rstd, int m0,
                                          int M) {
@@ -236,7 +254,7 @@ __device__ __forceinline__ void ln_panel(const float* X, int ldx, int D, const f
   const float rs = rsqrtf(sum16(ss) / D + eps);
 #pragma unroll
   for (int q = 0; q < NC; ++q)
-    if (q < nc) H[r * ldh + sub + 16 * q] = f32_to_bf16((xv[q] - mu) * rs * gv[q] + bv[q]);
+    if (q < nc) H[r * ldh + sub + 16 * q] = f32_to_16<F16>((xv[q] - mu) * rs * gv[q] + bv[q]);
   if (sub == 0 && m0 + r < M) {
     if (mean) mean[m0 + r] = mu;
     if (rstd) rstd[m0 + r] = rs;

@@ -17,7 +17,9 @@
 //   mvf_head_pack_weights  fp32 master weights -> bf16 [N, K] and bf16 transposed [K, N] copies (once per optimizer step)
 //
 // Numerics: GEMM operands bf16 (what fp16 autocast does to these layers in the reference, train.py:113-117, with bf16's
-// range instead of a loss scaler), fp32 accumulation; LayerNorm, bias, dropout, residual stream and every saved
+// range instead of a loss scaler), fp32 accumulation; MI355X.HEAD_DTYPE fp16 (round 6): the FORWARD GEMMs take IEEE fp16 operands
+// (11 significant bits: per-frame embeddings within the north star's 1e-3 of the fp32 path) while every gradient GEMM keeps bf16
+// operands -- the forward's saved activations are written as bf16 for the weight-gradient launch -- so no loss scaler is needed; LayerNorm, bias, dropout, residual stream and every saved
 // statistic fp32.  oracle/head.py `emulate='bf16'` rounds at the same points.  MI355X.COMPUTE_DTYPE fp32 keeps the fp32
 // kernels of head_gemm.hip / head_misc.hip.
 //
@@ -70,6 +72,7 @@ struct EncFwdK {
   long long* stamps;
 };
 
+template <bool F16>
 __global__ __launch_bounds__(NTH) void enc_fwd_kernel(EncFwdK k) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   const EncLds L = enc_lds(k.D, k.DFF, false);
@@ -83,12 +86,12 @@ __global__ __launch_bounds__(NTH) void enc_fwd_kernel(EncFwdK k) {
   STAMP(0);
   if (k.o != nullptr) {
     // ---- x1 = x + drop(o Wo^T + bo) ----
-    load_rows_bf16(k.o, D, m0, M, D, Pb0, L.ldb0);
+    load_rows_bf16<F16>(k.o, D, m0, M, D, Pb0, L.ldb0);
     LDS_BARRIER();
     STAMP(1);
-    store_T(Pb0, L.ldb0, D, k.oT, k.Mp, m0, M);
+    store_T<F16>(Pb0, L.ldb0, D, k.oT, k.Mp, m0, M);
     STAMP(2);
-    chain_gemm<2, 4>(Pb0, L.ldb0, KD, k.wo, D, [&](int m, int n) {
+    chain_gemm<2, 4, F16>(Pb0, L.ldb0, KD, k.wo, D, [&](int m, int n) {
       Aux2 a;
       a.b = *reinterpret_cast<const float4*>(k.bo + n);
       a.r = *reinterpret_cast<const float4*>(k.x_in + (size_t)min(m0 + m, M - 1) * D + n);
@@ -110,27 +113,27 @@ __global__ __launch_bounds__(NTH) void enc_fwd_kernel(EncFwdK k) {
     LDS_BARRIER();
     STAMP(3);
     // ---- h1 = LN(x1);  a = relu(h1 W1^T + b1) ----
-    ln_panel(Pf, L.ldf, D, k.g1, k.be1, k.eps, Pb0, L.ldb0, k.mean1, k.rstd1, m0, M);
+    ln_panel<F16>(Pf, L.ldf, D, k.g1, k.be1, k.eps, Pb0, L.ldb0, k.mean1, k.rstd1, m0, M);
     LDS_BARRIER();
     STAMP(4);
-    store_T(Pb0, L.ldb0, D, k.h1T, k.Mp, m0, M);
+    store_T<F16>(Pb0, L.ldb0, D, k.h1T, k.Mp, m0, M);
     STAMP(5);
-    chain_gemm<4, 4>(Pb0, L.ldb0, KD, k.w1, DFF, [&](int, int n) {
+    chain_gemm<4, 4, F16>(Pb0, L.ldb0, KD, k.w1, DFF, [&](int, int n) {
       Aux1 a;
       a.b = *reinterpret_cast<const float4*>(k.b1 + n);
       return a;
     }, [&](int m, int n, const f32x4_t& v, const Aux1& ax) {
       const float4 bb = ax.b;
       *reinterpret_cast<u32x2_t*>(Pb1 + m * L.ldb1 + n) =
-          (u32x2_t){pack_bf16x2(fmaxf(v[0] + bb.x, 0.f), fmaxf(v[1] + bb.y, 0.f)), pack_bf16x2(fmaxf(v[2] + bb.z, 0.f), fmaxf(v[3] + bb.w, 0.f))};
+          (u32x2_t){pack16x2<F16>(fmaxf(v[0] + bb.x, 0.f), fmaxf(v[1] + bb.y, 0.f)), pack16x2<F16>(fmaxf(v[2] + bb.z, 0.f), fmaxf(v[3] + bb.w, 0.f))};
     });
     LDS_BARRIER();
     STAMP(6);
     store_rows_bf16(Pb1, L.ldb1, DFF, k.a, m0, M);
-    store_T(Pb1, L.ldb1, DFF, k.aT, k.Mp, m0, M);
+    store_T<F16>(Pb1, L.ldb1, DFF, k.aT, k.Mp, m0, M);
     STAMP(7);
     // ---- x2 = x1 + drop(a W2^T + b2) ----
-    chain_gemm<2, 4>(Pb1, L.ldb1, KF, k.w2, D, [&](int, int n) {
+    chain_gemm<2, 4, F16>(Pb1, L.ldb1, KF, k.w2, D, [&](int, int n) {
       Aux1 a;
       a.b = *reinterpret_cast<const float4*>(k.b2 + n);
       return a;
@@ -156,12 +159,12 @@ __global__ __launch_bounds__(NTH) void enc_fwd_kernel(EncFwdK k) {
   }
   if (k.wqkv != nullptr) {
     // ---- the next layer's h0 = LN(x);  qkv = h0 Wqkv^T + bqkv ----
-    ln_panel(Pf, L.ldf, D, k.g0, k.be0, k.eps, Pb0, L.ldb0, k.mean0, k.rstd0, m0, M);
+    ln_panel<F16>(Pf, L.ldf, D, k.g0, k.be0, k.eps, Pb0, L.ldb0, k.mean0, k.rstd0, m0, M);
     LDS_BARRIER();
     STAMP(9);
-    store_T(Pb0, L.ldb0, D, k.h0T, k.Mp, m0, M);
+    store_T<F16>(Pb0, L.ldb0, D, k.h0T, k.Mp, m0, M);
     STAMP(10);
-    chain_gemm<2, 4>(Pb0, L.ldb0, KD, k.wqkv, 3 * D, [&](int, int n) {
+    chain_gemm<2, 4, F16>(Pb0, L.ldb0, KD, k.wqkv, 3 * D, [&](int, int n) {
       Aux1 a;
       a.b = *reinterpret_cast<const float4*>(k.bqkv + n);
       return a;
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(NTH2) void head_dw_kernel(DwArgs a) {
 // forward operand) and w16t = FM image of W^T (rows k, reduction n: the input-gradient operand).  One thread per 16-byte piece.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int PACK_MAX = 32;
-struct PackEnt { const float* w; long ld; int N, K; unsigned piece0, pieces16; bf16_t* w16; bf16_t* w16t; };
+struct PackEnt { const float* w; long ld; int N, K; unsigned piece0, pieces16; bf16_t* w16; bf16_t* w16t; int f16; };
 struct PackArgs { PackEnt e[PACK_MAX]; int n; };
 
 __global__ __launch_bounds__(NTH2) void head_pack_kernel(PackArgs a, unsigned total) {
@@ -388,8 +391,10 @@ __global__ __launch_bounds__(NTH2) void head_pack_kernel(PackArgs a, unsigned to
       const bool in = r < rows && cc < red;
       v[e] = in ? (tr ? E.w[(size_t)cc * E.ld + r] : E.w[(size_t)r * E.ld + cc]) : 0.f;
     }
-    *reinterpret_cast<u32x4_t*>(dst + (size_t)q * 8) =
-        (u32x4_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    // the forward operand (w16) of an fp16-head entry is IEEE fp16; the input-gradient operand (w16t) is bf16 in every mode
+    *reinterpret_cast<u32x4_t*>(dst + (size_t)q * 8) = (E.f16 && !tr)
+        ? (u32x4_t){pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3]), pack_f16x2(v[4], v[5]), pack_f16x2(v[6], v[7])}
+        : (u32x4_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
   }
 }
 
@@ -432,7 +437,7 @@ extern "C" int mvf_head_pack_weights(const MvfPackEntry* entries_host, int n, hi
     const MvfPackEntry& s = entries_host[i];
     MVF_CHECK_ARG(s.w && s.N > 0 && s.K > 0 && s.ld >= s.K && (s.w16 || s.w16t) && al16(s.w16) && al16(s.w16t));
     PackEnt& e = a.e[i];
-    e.w = s.w; e.ld = s.ld; e.N = s.N; e.K = s.K; e.w16 = (bf16_t*)s.w16; e.w16t = (bf16_t*)s.w16t;
+    e.w = s.w; e.ld = s.ld; e.N = s.N; e.K = s.K; e.w16 = (bf16_t*)s.w16; e.w16t = (bf16_t*)s.w16t; e.f16 = s.f16 != 0;
     e.piece0 = (unsigned)pieces;
     e.pieces16 = (unsigned)(fm_elems(s.N, s.K) / 8);
     pieces += fm_elems(s.N, s.K) / 8 + fm_elems(s.K, s.N) / 8;
@@ -465,9 +470,14 @@ extern "C" int mvf_enc_layer_fwd(const MvfEncFwd* s, hipStream_t st) {
   k.da = make_drop(s->drop_attn); k.df = make_drop(s->drop_ffn);
   k.x1 = s->x1; k.mean1 = s->mean1; k.rstd1 = s->rstd1; k.x2 = s->x2; k.qkv = s->qkv; k.mean0 = s->mean0; k.rstd0 = s->rstd0;
   k.a = (bf16_t*)s->a; k.oT = (bf16_t*)s->oT; k.h1T = (bf16_t*)s->h1T; k.aT = (bf16_t*)s->aT; k.h0T = (bf16_t*)s->h0T;
-  static uint64_t attr = 0;
-  if (mvf_ensure_lds(reinterpret_cast<const void*>(enc_fwd_kernel), 160 * 1024, attr) != MVF_OK) return MVF_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(enc_fwd_kernel, dim3(ceil_div(s->M, TM)), dim3(NTH), L.total, st, k);
+  static uint64_t attr[2] = {0, 0};
+  if (s->f16) {
+    if (mvf_ensure_lds(reinterpret_cast<const void*>(enc_fwd_kernel<true>), 160 * 1024, attr[1]) != MVF_OK) return MVF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(enc_fwd_kernel<true>, dim3(ceil_div(s->M, TM)), dim3(NTH), L.total, st, k);
+  } else {
+    if (mvf_ensure_lds(reinterpret_cast<const void*>(enc_fwd_kernel<false>), 160 * 1024, attr[0]) != MVF_OK) return MVF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(enc_fwd_kernel<false>, dim3(ceil_div(s->M, TM)), dim3(NTH), L.total, st, k);
+  }
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }

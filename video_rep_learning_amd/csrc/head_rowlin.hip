@@ -60,7 +60,8 @@ __host__ __device__ inline RlLds rl_lds_fwd(int Kin, int N, int Cin) {
   return l;
 }
 
-template <int NT>
+// F16: IEEE fp16 GEMM operands (MI355X.HEAD_DTYPE fp16: the forward only, head_chain.hip header); xT is written as bf16 either way
+template <int NT, bool F16 = false>
 __global__ __launch_bounds__(NTH) void rowlin_fwd_kernel(RowLinFwdK k) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   const RlLds L = rl_lds_fwd(k.Kin, k.N, k.Cin);
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(NTH) void rowlin_fwd_kernel(RowLinFwdK k) {
             x[e] = drop_apply(k.drop_in, x[e], (uint64_t)m * Kin + c);
           }
         }
-        *reinterpret_cast<u32x2_t*>(Pa + r * L.lda + 4 * q) = (u32x2_t){pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
+        *reinterpret_cast<u32x2_t*>(Pa + r * L.lda + 4 * q) = (u32x2_t){pack16x2<F16>(x[0], x[1]), pack16x2<F16>(x[2], x[3])};
       }
     }
     // one-hot of the row's entity + zero padding up to the image's K
@@ -144,15 +145,15 @@ __global__ __launch_bounds__(NTH) void rowlin_fwd_kernel(RowLinFwdK k) {
         x = (m / k.oh_div) % k.oh_ntok == c - Cin ? 1.f : 0.f;
         x = drop_apply(k.drop_in, x, (uint64_t)m * Kin + c);
       }
-      Pa[r * L.lda + c] = f32_to_bf16(x);
+      Pa[r * L.lda + c] = f32_to_16<F16>(x);
     }
   }
   LDS_BARRIER();
   RSTAMP(2);
-  store_T(Pa, L.lda, Kin, k.xT, k.Mp, m0, M);
+  store_T<F16>(Pa, L.lda, Kin, k.xT, k.Mp, m0, M);
   RSTAMP(3);
   // ---- Y = pro(X) W^T + b [+ table] [dropout] ----
-  chain_gemm<NT, 4>(Pa, L.lda, Kin, k.w, N, [&](int m, int n) {
+  chain_gemm<NT, 4, F16>(Pa, L.lda, Kin, k.w, N, [&](int m, int n) {
     Aux2 a;
     a.b = k.bias != nullptr ? *reinterpret_cast<const float4*>(k.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     a.r = k.table != nullptr ? *reinterpret_cast<const float4*>(k.table + (size_t)((m0 + m) % k.tab_mod) * N + n) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -496,9 +497,13 @@ extern "C" int mvf_rowlin_fwd(const MvfRowLinFwd* s, hipStream_t st) {
   k.st_part = s->st_part; k.st_mean = s->st_mean; k.st_var = s->st_var; k.st_rmean = s->st_rmean; k.st_rvar = s->st_rvar; k.st_momentum = s->st_momentum;
   k.stamps = next_stamps();
   k.ticket = g_rl_ring_f.take();
-  static uint64_t a1 = 0, a2 = 0, a4 = 0;
+  static uint64_t a1 = 0, a2 = 0, a4 = 0, h1 = 0, h2 = 0, h4 = 0;
   int rc;
-  if (s->N >= 512) rc = launch_fwd(rowlin_fwd_kernel<4>, k, L.total, st, a4);
+  if (s->f16) {
+    if (s->N >= 512) rc = launch_fwd(rowlin_fwd_kernel<4, true>, k, L.total, st, h4);
+    else if (s->N >= 256) rc = launch_fwd(rowlin_fwd_kernel<2, true>, k, L.total, st, h2);
+    else rc = launch_fwd(rowlin_fwd_kernel<1, true>, k, L.total, st, h1);
+  } else if (s->N >= 512) rc = launch_fwd(rowlin_fwd_kernel<4>, k, L.total, st, a4);
   else if (s->N >= 256) rc = launch_fwd(rowlin_fwd_kernel<2>, k, L.total, st, a2);
   else rc = launch_fwd(rowlin_fwd_kernel<1>, k, L.total, st, a1);
   if (rc != MVF_OK) return rc;

@@ -253,7 +253,7 @@ class MultiEntityTransformerEmbModel(nn.Module):
     def trunk_chain_active(self, c_in=None):
         """The FC stack + video_emb run as row chains (one launch per Linear each way): bf16 head, the one-hot (if any) appended
         before the stack, every width within the kernels' panels (a SyncBatchNorm's exchange happens between the launches)."""
-        if self.head_dtype != 'bf16' or isinstance(self.fc_layers, nn.Identity) or self.one_hot_pos == 'enc':
+        if not ops.chain_dtype(self.head_dtype) or isinstance(self.fc_layers, nn.Identity) or self.one_hot_pos == 'enc':
             return False
         mods = list(self.fc_layers)
         lins = [mods[i + 1] for i in range(0, len(mods), 4)] + [self.video_emb]
@@ -266,7 +266,7 @@ class MultiEntityTransformerEmbModel(nn.Module):
                                    for j, l in enumerate(lins))
 
     def tail_chain_active(self):
-        return self.head_dtype == 'bf16' and self.smart_final in ('one', 'avg', 'max') and \
+        return ops.chain_dtype(self.head_dtype) and self.smart_final in ('one', 'avg', 'max') and \
             ops.rowlin_supported(self.embedding_layer.weight.shape[1], self.embedding_layer.weight.shape[0])
 
     def _trunk_chain(self, x, ntok, T):
@@ -298,6 +298,7 @@ class MultiEntityTransformerEmbModel(nn.Module):
                                       drop_out=ops.drop_args(self.video_pos_enc.dout_p, self.training, self.drop_state,
                                                              x.shape[0] * self.video_emb.weight.shape[0])))
         eval_stats.append((last_bn.running_mean, last_bn.running_var))
+        self._pack_trunk.set_f16(self.head_dtype == 'fp16')
         return ops.rowlin_chain(x, stages, params, self.training, self._pack_trunk, tuple(eval_stats), tag='trunk.')
 
     def _bn(self, x, bn, relu):
@@ -341,6 +342,7 @@ class MultiEntityTransformerEmbModel(nn.Module):
         if x.is_cuda and self.tail_chain_active():
             # entity reduction + embedding layer (mvformer.py:181-199) as one launch each way
             st = ops.RowLinStage(0, 1, gather=(ntok, T, {'one': 0, 'avg': 1, 'max': 2}[self.smart_final]))
+            self._pack_tail.set_f16(self.head_dtype == 'fp16')
             x = ops.rowlin_chain(x.reshape(Bc * ntok * T, -1), [st], [self.embedding_layer.weight, self.embedding_layer.bias],
                                  self.training, self._pack_tail, tag='tail.')
             return x.view(Bc, T, self.embedding_size)

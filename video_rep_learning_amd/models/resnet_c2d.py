@@ -22,7 +22,7 @@ class MLPHead(nn.Module):
 
     def chain_active(self):
         lin0, bn, _, lin1 = self.net
-        return self.head_dtype == 'bf16' and bn.momentum is not None and bn.affine and bn.track_running_stats and \
+        return ops.chain_dtype(self.head_dtype) and bn.momentum is not None and bn.affine and bn.track_running_stats and \
             ops.rowlin_supported(lin0.weight.shape[1], lin0.weight.shape[0]) and ops.rowlin_supported(lin1.weight.shape[1], lin1.weight.shape[0])
 
     def forward(self, x, normalize=False):
@@ -36,6 +36,7 @@ class MLPHead(nn.Module):
             sync = (self.sync_group,) if isinstance(bn, nn.SyncBatchNorm) and collectives_active() else None
             stages = [ops.RowLinStage(0, 1, bn_out=(bn.running_mean, bn.running_var, bn.momentum), sync=sync),
                       ops.RowLinStage(4, 5, bn_in=(2, 3, bn.eps, True), l2norm=1e-12 if normalize else None)]
+            self._pack.set_f16(self.head_dtype == 'fp16')
             y = ops.rowlin_chain(x.reshape(-1, c), stages, [lin0.weight, lin0.bias, bn.weight, bn.bias, lin1.weight, lin1.bias], self.training,
                                  self._pack, (None, (bn.running_mean, bn.running_var)), tag='proj.')
             return y.view(b, l, -1)

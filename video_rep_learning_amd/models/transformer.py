@@ -191,17 +191,19 @@ class TransformerModel(nn.Module):
         return self
 
     def set_head_dtype(self, dt):
-        """'bf16': the trainable head's Linears on the bf16 matrix cores (row-chain kernels, csrc/head_chain.hip) where their
-        shapes allow it; 'fp32': the fp32 kernels.  (The frozen backbone's dtype is `compute_dtype`.)"""
-        assert dt in ('bf16', 'fp32'), dt
+        """'bf16' / 'fp16': the trainable head's Linears on the 16-bit matrix cores (row-chain kernels, csrc/head_chain.hip) where their
+        shapes allow it -- 'fp16': IEEE fp16 operands in the forward GEMMs, bf16 in the gradient GEMMs --; 'fp32': the fp32 kernels.
+        (The frozen backbone's dtype is `compute_dtype`.)"""
+        assert dt in ('bf16', 'fp16', 'fp32'), dt
         self.head_dtype = dt
         for m in self.modules():
             if m is not self and hasattr(m, 'head_dtype'):
                 m.head_dtype = dt
 
     def head_bf16_linears(self):
-        """Name prefixes (relative to `embed.`) of the Linears that run with bf16 operands in the current mode -- what an
-        emulating checker has to round (oracle/head.py emulate_head)."""
+        """Name prefixes (relative to `embed.`) of the Linears that run with 16-bit operands in the current mode (bf16, or with
+        HEAD_DTYPE fp16: fp16 in the forward and bf16 in the two gradient products) -- what an emulating checker has to round
+        (oracle/head.py emulating)."""
         pre = []
         enc = getattr(self.embed, 'video_encoder', None)
         if enc is not None and enc.chain_active():

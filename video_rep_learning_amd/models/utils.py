@@ -167,7 +167,7 @@ class Encoder(nn.Module):
     def chain_active(self):
         """True when forward() takes the row-chain kernels (bf16 operands) for this module's shapes."""
         l0 = self.enc_layers[0] if len(self.enc_layers) > 0 else None
-        if self.head_dtype != 'bf16' or l0 is None:
+        if not ops.chain_dtype(self.head_dtype) or l0 is None:
             return False
         att = l0.self_att
         return att.d_model == att.linear_Q2d.weight.shape[1] and att.d_out == att.d_model and \
@@ -182,6 +182,7 @@ class Encoder(nn.Module):
                 for ly in self.enc_layers:
                     drops.append(ops.drop_args(ly.res_layer0.dout_p, self.training, drop_state, x.numel()))
                     drops.append(ops.drop_args(ly.res_layer1.dout_p, self.training, drop_state, x.numel()))
+                self._pack.set_f16(self.head_dtype == 'fp16')
                 return ops.encoder_chain(x, src_mask, layers, l0.self_att.H, l0.res_layer0.norm.eps, drops, self._pack)
         for layer in self.enc_layers:
             x = layer(x, src_mask, drop_state)

@@ -892,18 +892,26 @@ HEAD_CHAIN = os.environ.get('MVF_HEAD_CHAIN', '1') != '0'
 
 
 def head_dtype_of(cfg):
-    """'bf16' | 'fp32': the trainable head's GEMM operand dtype.  cfg.MI355X.HEAD_DTYPE when given; else bf16 when the backbone
-    runs in bf16 or MX-fp8 (or USE_AMP without a COMPUTE_DTYPE) -- the reference's head runs under fp16 autocast then
-    (train.py:113-117) -- and fp32 in parity mode (COMPUTE_DTYPE fp32) and in fp16 mode."""
+    """'fp16' | 'bf16' | 'fp32': the trainable head's GEMM operand dtype.  cfg.MI355X.HEAD_DTYPE when given; else fp16 when the backbone
+    runs in a reduced precision (bf16, MX-fp8, fp16, or USE_AMP without a COMPUTE_DTYPE) -- the reference's head runs under fp16
+    autocast then (train.py:113-117) -- and fp32 in parity mode (COMPUTE_DTYPE fp32).
+    'fp16' (round 6): the row-chain kernels with IEEE fp16 operands in the FORWARD GEMMs and bf16 operands in every gradient GEMM (no
+    loss scaler needed: csrc/head_chain.hip).  Measured at configs[1] size (tools/fp16_error_budget.py, profiles/r06): per-frame
+    embeddings 5e-4 of the fp32 oracle whatever the backbone's dtype, against 4e-3 with bf16 forward operands, at the same speed.
+    'bf16': every head GEMM on bf16 operands (rounds 5's head)."""
     mi = cfg.MI355X if 'MI355X' in cfg else {}
     if 'HEAD_DTYPE' in mi:
         hd = str(mi['HEAD_DTYPE']).lower()
-        if hd not in ('bf16', 'fp32'):
-            raise ValueError("MI355X.HEAD_DTYPE must be 'bf16' or 'fp32' (got %r)" % (mi['HEAD_DTYPE'],))
+        if hd not in ('bf16', 'fp16', 'fp32'):
+            raise ValueError("MI355X.HEAD_DTYPE must be 'bf16', 'fp16' or 'fp32' (got %r)" % (mi['HEAD_DTYPE'],))
         return hd
-    cd = mi['COMPUTE_DTYPE'] if 'COMPUTE_DTYPE' in mi else ('bf16' if ('USE_AMP' in cfg and cfg.USE_AMP) else 'fp32')
-    # fp16 is the accuracy mode (embeddings within 1e-3 of the fp32 oracle): its head stays on the fp32 kernels
-    return 'bf16' if str(cd).lower() in ('bf16', 'fp8', 'mxfp8') else 'fp32'
+    cd = str(mi['COMPUTE_DTYPE'] if 'COMPUTE_DTYPE' in mi else ('bf16' if ('USE_AMP' in cfg and cfg.USE_AMP) else 'fp32')).lower()
+    return 'fp16' if cd in ('bf16', 'fp8', 'mxfp8', 'fp16', 'f16') else 'fp32'
+
+
+def chain_dtype(hd):
+    """True when head dtype `hd` runs the row-chain kernels ('bf16' | 'fp16')."""
+    return hd in ('bf16', 'fp16')
 
 
 class HeadPack:
@@ -919,6 +927,11 @@ class HeadPack:
         self.views = {}
         self.stale = True
         self.registry = {}            # tag -> [(name, weight)] as last seen
+        self.f16 = False              # MI355X.HEAD_DTYPE fp16: the FORWARD images (W) are IEEE fp16, the transposed ones stay bf16
+
+    def set_f16(self, on):
+        if bool(on) != self.f16:
+            self.f16, self.stale = bool(on), True
 
     def invalidate(self):
         self.stale = True
@@ -956,7 +969,7 @@ class HeadPack:
             p16, off = base + 2 * off, off + (a + 63) // 64 * 64
             p16t, off = base + 2 * off, off + (b + 63) // 64 * 64
             e = ents[i]
-            e.w, e.ld, e.N, e.K, e.w16, e.w16t = w.data_ptr(), w.stride(0), w.shape[0], w.shape[1], p16, p16t
+            e.w, e.ld, e.N, e.K, e.w16, e.w16t, e.f16 = w.data_ptr(), w.stride(0), w.shape[0], w.shape[1], p16, p16t, int(self.f16)
             views[n] = (p16, p16t)
         for i0 in range(0, len(named), 32):
             n = min(32, len(named) - i0)
@@ -1018,7 +1031,7 @@ class _EncoderChain(torch.autograd.Function):
         saved = []
         xs = [x]
         a = _lib.MvfEncFwd()
-        a.M, a.D, a.DFF, a.Mp, a.ln_eps = M, D, DFF, Mp, eps
+        a.M, a.D, a.DFF, a.Mp, a.ln_eps, a.f16 = M, D, DFF, Mp, eps, int(pack.f16)
         P0 = params[0:12]
         qkv, mean0, rstd0, h0T = f32(M, 3 * D), f32(M), f32(M), b16(D, Mp)
         a.x_in, a.wqkv, a.bqkv, a.ln0_g, a.ln0_b = ptr(x), W['qkv0'][0], ptr(P0[3]), ptr(P0[0]), ptr(P0[1])
@@ -1031,7 +1044,7 @@ class _EncoderChain(torch.autograd.Function):
             x1, mean1, rstd1, x2 = f32(M, D), f32(M), f32(M), f32(M, D)
             act, oT, h1T, aT = b16(M, DFF), b16(D, Mp), b16(D, Mp), b16(DFF, Mp)
             a = _lib.MvfEncFwd()
-            a.M, a.D, a.DFF, a.Mp, a.ln_eps = M, D, DFF, Mp, eps
+            a.M, a.D, a.DFF, a.Mp, a.ln_eps, a.f16 = M, D, DFF, Mp, eps, int(pack.f16)
             a.o, a.x_in = ptr(o), ptr(xs[-1])
             a.wo, a.w1, a.w2 = W['o%d' % l][0], W['f1%d' % l][0], W['f2%d' % l][0]
             a.bo, a.b1, a.b2, a.ln1_g, a.ln1_b = ptr(P[5]), ptr(P[9]), ptr(P[11]), ptr(P[6]), ptr(P[7])
@@ -1193,7 +1206,7 @@ class _RowLinChain(torch.autograd.Function):
                 a.oh_ntok, a.oh_div = st.onehot
             assert Cin + (st.onehot[0] if st.onehot else 0) == Kin, (Cin, Kin)
             a.drop_in, a.drop_out = _drop_c(st.drop_in), _drop_c(st.drop_out)
-            a.w16, a.bias = W['s%d' % i][0], ptr(params[st.b]) if st.b is not None else None
+            a.w16, a.bias, a.f16 = W['s%d' % i][0], ptr(params[st.b]) if st.b is not None else None, int(pack.f16)
             if st.table is not None:
                 a.table, a.tab_mod = ptr(st.table[0]), st.table[1]
             Y = torch.empty(M, N, device=dev, dtype=torch.float32)

@@ -149,6 +149,10 @@ int mvf_quant_mxfp8(int in_dtype, const void* x, size_t ldx, void* q, size_t ldq
                     hipStream_t stream);
 int mvf_layernorm_mxfp8(const float* x, size_t in_stride, const float* g, const float* b, void* q, size_t ldq, unsigned* scales,
                         int rows, int D, float eps, hipStream_t stream);
+/* timm Attention core (as mvf_vit_attn_fwd, bf16 qkv, any N, H even) with the MX-fp8 quantisation of its output in the kernel's
+ * epilogue: q [F*N, D] e4m3 bytes + scales [D/128][F*N] -- bit for bit mvf_quant_mxfp8(mvf_vit_attn_fwd(qkv)), the A operand of
+ * the fp8 proj GEMM, without the bf16 [F*N, D] tensor's round trip through HBM (reached from models/transformer.py:188 in fp8 mode) */
+int mvf_vit_attn_fwd_mxfp8(const void* qkv, void* q, unsigned* scales, int F, int N, int H, int D, hipStream_t stream);
 int mvf_gemm_fp8(int epi, const void* A, int lda, const unsigned* sa, const void* W, int ldw, const unsigned* sw,
                  const float* bias, void* C, int ldc, unsigned* c_scales, float* resid, int ldr, void* tap, int ldt,
                  const float* ls, int tokens_per_frame, int M, int N, int K, hipStream_t stream);

@@ -544,6 +544,35 @@ def test_vit_attention_row_maximum_outgrows_the_first_tile(N, dtype, variant):
     check(out, _attn_ref(qkv.cpu(), F, N, H), 2e-2 if dtype == 'bf16' else 4e-3, 'vit_attn outgrown maximum N=%d %s v%d' % (N, dtype, variant))
 
 
+@pytest.mark.parametrize('N', [5, 33, 197, 257, 577, 785])
+@pytest.mark.parametrize('F,H', [(3, 2), (2, 6)])
+@pytest.mark.parametrize('spiky', [False, True])
+def test_vit_attention_with_mxfp8_output_equals_attention_then_quantiser(N, F, H, spiky):
+    """fp8 mode (BASELINE configs[4]): the streamed attention kernel writes the proj GEMM's MX-fp8 operand in its epilogue.  Bytes and
+    block scales must be exactly what mvf_quant_mxfp8 makes of the same kernel's bf16 output (form 5 = variant 13 at any N), every
+    scale dword whole (two heads share one); spiky: some V channels 300 x larger, keys from 40 on 25 x larger in one frame (the careful
+    walk ends in the same epilogue)."""
+    D = 64 * H
+    g = gen(171 + N)
+    qkv = torch.randn(F, N, 3, H, 64, generator=g)
+    if spiky:
+        qkv[:, :, 2, :, 5::17] *= 300.0
+        qkv[0, 40:, 1] *= 25.0
+    qkv = qkv.reshape(F * N, 3 * D).to(DEV).to(torch.bfloat16)
+    rows = F * N
+    out = torch.empty(rows, D, device=DEV, dtype=torch.bfloat16)
+    _lib.call('mvf_vit_attn_fwd', _lib.BF16, qkv.data_ptr(), out.data_ptr(), F, N, H, D, 13, S())
+    q_ref = torch.zeros(rows, D, device=DEV, dtype=torch.uint8)
+    s_ref = torch.zeros(D // 128, rows, device=DEV, dtype=torch.int32)
+    _lib.call('mvf_quant_mxfp8', _lib.BF16, out.data_ptr(), D, q_ref.data_ptr(), D, s_ref.data_ptr(), rows, D, S())
+    q = torch.full((rows, D), 0x5a, device=DEV, dtype=torch.uint8)
+    sc = torch.full((D // 128, rows), 0x5a5a5a5a, device=DEV, dtype=torch.int32)
+    _lib.call('mvf_vit_attn_fwd_mxfp8', qkv.data_ptr(), q.data_ptr(), sc.data_ptr(), F, N, H, D, S())
+    torch.cuda.synchronize()
+    assert torch.equal(sc, s_ref), 'block scales differ in %d dwords' % (sc != s_ref).sum().item()
+    assert torch.equal(q, q_ref), 'fp8 bytes differ in %d places' % (q != q_ref).sum().item()
+
+
 # ------------------------------------------------------------------------------------------------ whole ViT
 def _pack(w, depth, dim, heads, patch, img, taps, dtype):
     return ops.PackedViT({k: v.to(DEV) for k, v in w.items()}, depth, dim, heads, patch, img, taps, dtype)

@@ -57,6 +57,7 @@ SIGNATURES = {
     'mvf_cast_f32_f16': 'ppzp',
     'mvf_cast_bf16_f32': 'ppzp',
     'mvf_vit_attn_fwd_lse': 'pppiiiip',
+    'mvf_vit_attn_fwd_mxfp8': 'pppiiiip',
     'mvf_vit_attn_bwd': 'ppppppiiiiip',
     'mvf_static_query_fwd': 'ppplpiiip',
     'mvf_static_query_bwd': 'plppplppplIIIp'.replace('I', 'i'),

@@ -69,8 +69,10 @@ int mvf_layernorm_impl(int out_dtype, const float* x, size_t in_stride, const fl
 int mvf_cast_bf16_impl(const float* in, void* out, size_t n, hipStream_t st);
 int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t st);
 // vit_attn32.hip: the streamed kernel on 32-query-row tiles (any N; bf16 / fp16); lse != NULL: also the per-query log-sum-exp (bf16)
+// q8_scales != NULL: `out` receives MX-fp8 bytes [F*N, D] and q8_scales their block scales [D/128][F*N] (mxfp8.hip's layout) -- bit for bit
+// what mvf_quant_mxfp8 makes of the bf16 output (H even; bf16 only)
 int mvf_vit_attn32_impl(int dtype, const void* qkv, void* out, float* lse, int F, int N, int H, int D, int form, int nw_force,
-                        hipStream_t st);
+                        hipStream_t st, unsigned* q8_scales = nullptr);
 // vit_qkv_attn.hip: the qkv projection fused into the attention kernel (N = 193 .. 208); MVF_ERR_UNSUPPORTED outside its shapes
 // (folded form: the rows' statistics as ln_mr pairs, or as the producer's partial sums ln_part [ln_ns][F*N][2] finalized in the kernel)
 int mvf_qkv_attn_impl(int dtype, const void* A, int lda, const void* W, const float* bias, const float* ln_c, const float* ln_mr,

@@ -600,6 +600,11 @@ extern "C" int mvf_vit_attn_fwd_lse(const void* qkv, void* out, float* lse, int 
   return mvf_vit_attn32_impl(MVF_BF16, qkv, out, lse, F, N, H, D, 5, 0, st);
 }
 
+extern "C" int mvf_vit_attn_fwd_mxfp8(const void* qkv, void* q, unsigned* scales, int F, int N, int H, int D, hipStream_t st) {
+  MVF_CHECK_ARG(qkv && q && scales && F > 0 && N > 0 && H > 0 && H % 2 == 0 && D == H * HD);
+  return mvf_vit_attn32_impl(MVF_BF16, qkv, q, nullptr, F, N, H, D, 5, 0, st, scales);
+}
+
 // 1 when the default (variant 0) 16-bit kernel for N tokens normalises by the row sum of the ROUNDED probabilities (taken on the
 // matrix pipe with the P.V product), 0 when by the fp32 sum of the unrounded ones.  The one statement of that convention: the
 // dispatch below and vit_qkv_attn.hip's fused kernel follow it, the emulating oracle is tested against it (tests/test_abi.py).

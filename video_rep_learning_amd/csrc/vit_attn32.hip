@@ -26,6 +26,7 @@
 #include "common.h"
 #include "mvf_hip_internal.h"
 #include "vit_attn_tiles.h"
+#include "mxfp8.h"
 
 namespace {
 using namespace vit_attn;
@@ -95,6 +96,8 @@ struct Attn32Args {
   int nchunk;   // workgroups per (frame, head)
   int nunits;   // F * H
   float thr;    // deferred-maximum threshold in raw-score units (2^8 in the exponent: 8 / scale_log2)
+  unsigned* q8_scales;   // Q8 form: a.out is MX-fp8 [F*N, D] bytes, these its block scales [D/128][rows] (mxfp8.hip's layout)
+  size_t rows;           // F * N
 };
 
 // NKT: 32-key tiles per streamed block.  OCC: waves per SIMD the register budget is cut for.
@@ -302,7 +305,10 @@ __global__ __launch_bounds__(512, OCC) void vit_attn32_kernel(Attn32Args g) {
 // QS: the q columns arrive PRE-SCALED by log2(e) / 8 (the frozen backbone's packed qkv weights carry the factor, applied in fp32 before
 // their one rounding: ops.PackedViT), so a score is already the exponent.  The reference maximum then enters the score tiles as the
 // MFMA's initial accumulator (-m in every register: S' = K Q^T - m) and a probability is exp2(S') -- no v_fma per score.
-template <int NKT, int OCC, bool F16, bool LSE, bool MSUM, bool QS = false>
+// Q8: the output leaves as MX-fp8 (e4m3 bytes + one E8M0 scale per 32 channels = per 32-row half of this head's O^T) instead of 16-bit
+// rows -- what mvf_quant_mxfp8 would make of the 16-bit output, bit for bit (the values are rounded to bf16 first), without the
+// [F*N, D] bf16 tensor's round trip through HBM in front of the fp8 proj GEMM (BASELINE configs[4]).
+template <int NKT, int OCC, bool F16, bool LSE, bool MSUM, bool QS = false, bool Q8 = false>
 __global__ __launch_bounds__(512, OCC) void vit_attn32p_kernel(Attn32Args g) {
   const AttnArgs& a = g.a;
   constexpr int KROWS = NKT * 32;
@@ -598,6 +604,41 @@ __global__ __launch_bounds__(512, OCC) void vit_attn32p_kernel(Attn32Args g) {
     if (q < a.N && hh == 0)   // p = exp2(s * scale_log2 - lse) reproduces the normalised probability
       a.lse[((size_t)f * a.H + h) * a.npad + q] = fmaf(m_use, QS ? 1.0f : a.scale_log2, __builtin_amdgcn_logf(l_run));
   }
+  if constexpr (Q8) {
+    // The 32 channels of d-tile dt (one MX block) are this lane's 16 registers and its partner's: block maximum = in-lane chain + one
+    // swap.  Values are rounded to bf16 FIRST (what the 16-bit form stores and mvf_quant_mxfp8 reads), then scaled and converted.
+    static_assert(!F16 && !LSE, "MX-fp8 output: bf16 rounding, frozen path");
+    unsigned char* qrow = reinterpret_cast<unsigned char*>(a.out) + ((size_t)f * a.N + min(q, a.N - 1)) * a.D + h * HD;
+    unsigned sb2 = 0;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      float v[16];
+      float amax = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const uint32_t w = pack16x2<false>(o[dt][e] * inv, o[dt][e + 1] * inv);
+        v[e] = __uint_as_float(w << 16);
+        v[e + 1] = __uint_as_float(w & 0xffff0000u);
+        amax = max3f(amax, fabsf(v[e]), fabsf(v[e + 1]));
+      }
+      amax = pair_max(amax);
+      const unsigned sb = mx_scale_byte(amax);
+      const float is = mx_inv_scale(sb);
+      sb2 |= sb << (8 * dt);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const uint32_t A = pack_fp8x4(v[8 * k + 0] * is, v[8 * k + 1] * is, v[8 * k + 2] * is, v[8 * k + 3] * is);
+        const uint32_t B = pack_fp8x4(v[8 * k + 4] * is, v[8 * k + 5] * is, v[8 * k + 6] * is, v[8 * k + 7] * is);
+        const auto rr = __builtin_amdgcn_permlane32_swap(A, B, false, false);
+        if (q < a.N) *reinterpret_cast<uint2*>(qrow + dt * 32 + k * 16 + hh * 8) = make_uint2(rr[0], rr[1]);
+      }
+    }
+    // the head's two block scales: bytes 2 (h & 1), 2 (h & 1) + 1 of the row's dword of K tile h / 2
+    if (q < a.N && hh == 0)
+      *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(g.q8_scales + (size_t)(h >> 1) * g.rows + (size_t)f * a.N + q) + (h & 1) * 2) =
+          (unsigned short)sb2;
+    return;
+  }
   bf16_t* orow = reinterpret_cast<bf16_t*>(a.out) + ((size_t)f * a.N + min(q, a.N - 1)) * a.D + h * HD;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -612,17 +653,17 @@ __global__ __launch_bounds__(512, OCC) void vit_attn32p_kernel(Attn32Args g) {
     }
 }
 
-template <int NKT, int OCC, bool F16, bool LSE, bool MSUM, bool QS = false>
+template <int NKT, int OCC, bool F16, bool LSE, bool MSUM, bool QS = false, bool Q8 = false>
 int launch32p(const Attn32Args& g, int nw, hipStream_t st) {
   constexpr size_t LDS = (size_t)6 * NKT * 32 * 128;
   static uint64_t done = 0;
-  const void* fn = reinterpret_cast<const void*>(vit_attn32p_kernel<NKT, OCC, F16, LSE, MSUM, QS>);
+  const void* fn = reinterpret_cast<const void*>(vit_attn32p_kernel<NKT, OCC, F16, LSE, MSUM, QS, Q8>);
   if (LDS > 48 * 1024) {
     const int rc = mvf_ensure_lds(fn, LDS, done);
     if (rc != MVF_OK) return rc;
   }
   const int grid = ceil_div(g.nunits, 8) * 8 * g.nchunk;
-  hipLaunchKernelGGL((vit_attn32p_kernel<NKT, OCC, F16, LSE, MSUM, QS>), dim3(grid), dim3(nw * 64), LDS, st, g);
+  hipLaunchKernelGGL((vit_attn32p_kernel<NKT, OCC, F16, LSE, MSUM, QS, Q8>), dim3(grid), dim3(nw * 64), LDS, st, g);
   MVF_LAUNCH_CHECK();
   return MVF_OK;
 }
@@ -648,7 +689,7 @@ int launch32(const Attn32Args& g, int nw, hipStream_t st) {
 // blocks (8 waves); 0 .. 3 = the unpipelined walk (64 / 96 / 128-key blocks, 64-key at 3 waves per SIMD), kept for A/B runs and as an
 // independent implementation the tests compare with.  nw_force > 0: waves per workgroup
 int mvf_vit_attn32_impl(int dtype, const void* qkv, void* out, float* lse, int F, int N, int H, int D, int form, int nw_force,
-                        hipStream_t st) {
+                        hipStream_t st, unsigned* q8_scales) {
   MVF_CHECK_ARG(qkv && out && F > 0 && N > 0 && H > 0 && D == H * vit_attn::HD);
   MVF_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0);
   MVF_CHECK_ARG(dtype == MVF_BF16 || dtype == MVF_F16);
@@ -666,6 +707,12 @@ int mvf_vit_attn32_impl(int dtype, const void* qkv, void* out, float* lse, int F
   g.nchunk = ceil_div(nqb, nw);
   g.nunits = F * H;
   const bool f16 = dtype == MVF_F16;
+  g.q8_scales = q8_scales;
+  g.rows = (size_t)F * N;
+  if (q8_scales != nullptr) {   // MX-fp8 output (out: [F*N, D] bytes): the product form only, bf16 arithmetic, head pairs share a scale dword
+    MVF_CHECK_ARG(!f16 && lse == nullptr && H % 2 == 0 && ((uintptr_t)out % 8) == 0 && ((uintptr_t)q8_scales % 4) == 0);
+    return launch32p<2, 2, false, false, true, false, true>(g, nw, st);
+  }
   if (lse) {
     if (f16) return MVF_ERR_ARG;
     return launch32p<2, 2, false, true, true>(g, nw, st);

@@ -16,6 +16,8 @@ enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
 const bool g_ln_inkernel = []{ const char* e = getenv("MVF_LN_INKERNEL"); return e == nullptr || e[0] != '0'; }();
 // MVF_PROJ_DEFER=0: keep the proj GEMM's read-modify epilogue (A/B measurements)
 const bool g_proj_defer = []{ const char* e = getenv("MVF_PROJ_DEFER"); return e == nullptr || e[0] != '0'; }();
+// fp8 mode: the attention kernel writes the proj GEMM's MX-fp8 operand itself (MVF_ATTN_Q8=0: bf16 output + mvf_quant_mxfp8, for A/B runs)
+const bool g_attn_q8 = []{ const char* e = getenv("MVF_ATTN_Q8"); return e == nullptr || e[0] != '0'; }();
 
 struct Ws {
   float* x;     // residual stream  [Mc, D] fp32
@@ -195,7 +197,7 @@ int run_blocks(const MvfVitWeights* w, int dtype, bool fp8, const Ws& ws, int fc
       if (w->taps[j] == l) tap = j;
     if (fp8) {
       // MX-fp8 block: every GEMM operand is quantised by its producer (LayerNorm and the fc1+GELU epilogue write fp8
-      // directly; the attention output is bf16 and goes through mvf_quant_mxfp8)
+      // directly; the attention kernel quantises its output in its epilogue -- the streamed 32-row kernel at any token count)
       void* tap_ptr = nullptr;
       if (tap >= 0 && taps_out && taps_out[tap]) tap_ptr = (char*)taps_out[tap] + (size_t)f0 * np * D * 2;
       // deferred residual as in the bf16 path below (LayerScale models: the packer folds gamma_1 into proj's weights and bias
@@ -207,8 +209,13 @@ int run_blocks(const MvfVitWeights* w, int dtype, bool fp8, const Ws& ws, int fc
       RUN(mvf_layernorm_mxfp8_impl(ws.x, D, w->ln1_w[l], w->ln1_b[l], ws.hq, D, ws.hs, Mc, D, w->ln_eps, st));
       RUN(timed_gemm(dtype, EPI_STORE, ws.hq, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0, nullptr,
                      nullptr, N, Mc, 3 * D, D, st, nullptr, &sq));
-      RUN(mvf_vit_attn_impl(dtype, ws.qkv, ws.h, fc, N, H, D, attn_variant, st));
-      RUN(mvf_quant_mxfp8_impl(MVF_BF16, ws.h, D, ws.hq, D, ws.hs, Mc, D, st));
+      if (attn_variant == 0 && H % 2 == 0 && g_attn_q8) {
+        // the attention kernel quantises its own output (bit for bit the two launches below; the qkv GEMM is done with hq / hs)
+        RUN(mvf_vit_attn32_impl(MVF_BF16, ws.qkv, ws.hq, nullptr, fc, N, H, D, 5, 0, st, ws.hs));
+      } else {
+        RUN(mvf_vit_attn_impl(dtype, ws.qkv, ws.h, fc, N, H, D, attn_variant, st));
+        RUN(mvf_quant_mxfp8_impl(MVF_BF16, ws.h, D, ws.hq, D, ws.hs, Mc, D, st));
+      }
       if (defer8)
         RUN(timed_gemm(dtype, EPI_STORE, ws.hq, D, w->proj_w[l], D, w->proj_b[l], ws.delta, D, nullptr, 0, nullptr, 0, nullptr,
                        nullptr, N, Mc, D, D, st, nullptr, &sp));

@@ -70,7 +70,10 @@ typedef struct MvfVitWeights {
    * norm1 follows the patch embedding). */
   const float* const* qkv_c; const float* const* fc1_c;
   /* dtype MVF_FP8: qkv_w / proj_w / fc1_w / fc2_w hold e4m3 bytes [N, K] and these tables their block scales [K/128][N]
-   * dwords (mvf_quant_mxfp8's layout); patch_w stays bf16, qkv_c / fc1_c must be NULL (no LN fold). */
+   * dwords (mvf_quant_mxfp8's layout); patch_w stays bf16.  LN fold in fp8 mode: norm1 only -- where qkv_c[l] != NULL (l > 0), qkv_w[l]
+   * holds MX-fp8(gamma1 (.) W_qkv), qkv_b[l] = b + W beta1, qkv_c[l][n] = sum_k of the DEQUANTISED qkv_w[l][n, k]; block l - 1's fc2
+   * epilogue then leaves MX-fp8(x) and the rows' partial sums for it (mvf_gemm_fp8_ln) and no LayerNorm pass runs for norm1 of block l.
+   * fc1_c must be NULL. */
   const unsigned* const* qkv_s; const unsigned* const* proj_s; const unsigned* const* fc1_s; const unsigned* const* fc2_s;
 } MvfVitWeights;
 
@@ -149,6 +152,16 @@ int mvf_quant_mxfp8(int in_dtype, const void* x, size_t ldx, void* q, size_t ldq
                     hipStream_t stream);
 int mvf_layernorm_mxfp8(const float* x, size_t in_stride, const float* g, const float* b, void* q, size_t ldq, unsigned* scales,
                         int rows, int D, float eps, hipStream_t stream);
+/* mvf_gemm_fp8 with LayerNorm 1 folded into the qkv GEMM (fp8 mode's form of mvf_gemm_tc_ln; timm Block.forward `attn(norm1(x))`):
+ *   epi 2 (producer, the previous block's fc2): besides the fp32 residual update also xq [M, ldxq] = MX-fp8 of the NEW residual row
+ *          (quantised from fp32, un-normalised), xq_scales [N/128][M] and stats [N/64][M][2] = per row and 64-column slice (sum, sum
+ *          of squares) -- mvf_ln_stats_finalize turns them into (mean, rstd); N % 128 == 0; addend2 as mvf_gemm_tc_resid2 (or NULL)
+ *   epi 0 (consumer, qkv): A = that xq, W = MX-fp8(gamma (.) W_qkv), bias = b + W beta, ln_c[n] = sum_k dequantised W'[n, k]:
+ *          C = bf16(rstd * (A W'^T - mean * ln_c) + bias) with (mean, rstd) = ln_mr [M][2] */
+int mvf_gemm_fp8_ln(int epi, const void* A, int lda, const unsigned* sa, const void* W, int ldw, const unsigned* sw, const float* bias,
+                    void* C, int ldc, float* resid, int ldr, void* tap, int ldt, const float* ls, int tokens_per_frame,
+                    const void* addend2, int ld2, void* xq, int ldxq, unsigned* xq_scales, float* stats, const float* ln_mr,
+                    const float* ln_c, int M, int N, int K, hipStream_t stream);
 /* timm Attention core (as mvf_vit_attn_fwd, bf16 qkv, any N, H even) with the MX-fp8 quantisation of its output in the kernel's
  * epilogue: q [F*N, D] e4m3 bytes + scales [D/128][F*N] -- bit for bit mvf_quant_mxfp8(mvf_vit_attn_fwd(qkv)), the A operand of
  * the fp8 proj GEMM, without the bf16 [F*N, D] tensor's round trip through HBM (reached from models/transformer.py:188 in fp8 mode) */

@@ -25,7 +25,10 @@ ROUNDED W').  Everywhere else (block 0's norm1, every norm2) the LayerNorm outpu
 output (proj + bias, LayerScale gamma_1 folded into proj's weights and bias BEFORE their rounding / quantisation) is rounded to
 bf16 before the residual add (the product stores it with the plain GEMM epilogue and adds it in LayerNorm 2 and in the fc2
 epilogue: csrc/vit_fwd.hip `defer`; D % 128 == 0; also in fp8 mode).  The product's other
-settings: `emulate='bf16_fold12'` (MVF_LN_FOLD=1: norm2 folded too), `'bf16_nofold'` (MVF_LN_FOLD=0).  It is the checker for the benchmarked dtype (tests/test_gpu_*: tight gates instead of "bf16 is somewhere
+settings: `emulate='bf16_fold12'` (MVF_LN_FOLD=1: norm2 folded too), `'bf16_nofold'` (MVF_LN_FOLD=0).
+`emulate='fp8'`: the four GEMMs of a block on MX-fp8 operands (mx_quant), norm1 of blocks > 0 folded into the qkv GEMM on the MX-fp8
+UN-normalised residual row (quantised from fp32 by the previous block's fc2 epilogue; W' = MX-fp8(gamma (.) W), c its row sums);
+`'fp8_nofold'` (MVF_FP8_LN_FOLD=0): the LayerNorm output quantised in front of every GEMM.  It is the checker for the benchmarked dtype (tests/test_gpu_*: tight gates instead of "bf16 is somewhere
 near fp32").
 
 Weights are a flat dict keyed with timm's state-dict names.  PARITY UNPINNED by
@@ -143,8 +146,10 @@ def mx_quant(t):
 
 
 def vit_block(x, w, p, heads, eps=1e-6, emulate=None):
-    if emulate == 'fp8':
-        return vit_block_bf16(x, w, p, heads, eps, mx=True, defer_proj=True)   # (fp8 mode needs D % 256 == 0 anyway)
+    if emulate in ('fp8', 'fp8_nofold'):
+        # (fp8 mode needs D % 256 == 0 anyway.)  'fp8': the product's default -- norm1 of every block but the first folded into the
+        # MX-fp8 qkv GEMM (MVF_FP8_LN_FOLD); 'fp8_nofold': a LayerNorm + quantiser pass in front of every GEMM (per-block runs)
+        return vit_block_bf16(x, w, p, heads, eps, mx=True, defer_proj=True, fold1=emulate == 'fp8' and p != 'blocks.0.')
     if emulate in ('bf16', 'bf16_fold12', 'bf16_nofold'):
         fold = emulate != 'bf16_nofold' and x.shape[-1] % 128 == 0
         # the product defers the attention branch's residual add (bf16-rounded proj output) unless norm2 is folded / LayerScale
@@ -197,7 +202,8 @@ def ln_linear_bf16(x, g, beta, W, b, eps, fold):
 def vit_block_bf16(x, w, p, heads, eps=1e-6, fold1=False, fold2=False, mx=False, defer_proj=False):
     """vit_block with the bf16 mode's rounding points (module docstring); x is the fp32 residual stream.
     mx: the product's fp8 mode -- both operands of the four GEMMs quantised to MX-fp8 (mx_quant along k: LayerNorm outputs,
-    attention output and fc1+GELU output after their bf16 rounding, weights once), everything else as in bf16 mode, no fold."""
+    attention output and fc1+GELU output after their bf16 rounding, weights once), everything else as in bf16 mode; fold1: norm1 folded
+    into the qkv GEMM on the MX-fp8 un-normalised residual row (below), never fold2."""
     r = bf16_round
     f, n, d = x.shape
     hd = d // heads
@@ -209,7 +215,17 @@ def vit_block_bf16(x, w, p, heads, eps=1e-6, fold1=False, fold2=False, mx=False,
         if mx:
             return mx_quant(a) @ mx_quant(W).t() + b
         return a @ r(W).t() + b
-    if mx:
+    if mx and fold1:
+        # the fold of ln_linear_bf16 on MX-fp8 operands: the previous block's fc2 epilogue quantised the fp32 residual row itself
+        # (un-normalised), the weights are MX-fp8(gamma (.) W), c the row sums of exactly those
+        g, beta, W, b = w[p + 'norm1.weight'], w[p + 'norm1.bias'], w[p + 'attn.qkv.weight'], w[p + 'attn.qkv.bias']
+        mean = x.mean(-1, keepdim=True)
+        rstd = 1.0 / torch.sqrt(((x * x).mean(-1, keepdim=True) - mean * mean).clamp_min(0.0) + eps)
+        Wp = mx_quant(W * g[None, :])
+        c = Wp.double().sum(1).to(x.dtype)
+        dvec = (b.double() + W.double() @ beta.double()).to(x.dtype)
+        qkv = r(rstd * (mx_quant(x) @ Wp.t() - mean * c) + dvec)
+    elif mx:
         qkv = r(lin(layer_norm(x, w[p + 'norm1.weight'], w[p + 'norm1.bias'], eps), 'attn.qkv.weight', 'attn.qkv.bias'))
     else:
         qkv = r(ln_linear_bf16(x, w[p + 'norm1.weight'], w[p + 'norm1.bias'], w[p + 'attn.qkv.weight'],
@@ -277,7 +293,7 @@ def vit_forward(img, w, heads, patch, taps=(3, 7, 11), eps=1e-6, first_block=0, 
             return vit_forward(img, w, heads, patch, taps, eps, first_block, last_block, x_in, emulate='bf16')
         finally:
             bf16_round = saved
-    assert emulate in (None, 'bf16', 'bf16_fold12', 'bf16_nofold', 'fp8'), emulate
+    assert emulate in (None, 'bf16', 'bf16_fold12', 'bf16_nofold', 'fp8', 'fp8_nofold'), emulate
     x = vit_embed(img, w, patch, emulate) if x_in is None else x_in
     feats = {}
     for i in range(first_block, last_block):

@@ -224,6 +224,7 @@ def test_config4_dinov2_vitl14_336_backbone_vs_oracle():
     # v_mfma_scale_f32_16x16x128_f8f6f4).  Bounds: rel-L2 against the oracle that quantises the same operands, and -- the
     # dtype's own error -- against the fp32 oracle (measured values in profiles/r02/parity.txt)
     pk8 = ops.PackedViT(sd, depth, dim, heads, patch, img, taps, 'fp8')
+    assert pk8.ln_fold == 2        # the product's default at dim 1024: norm1 of blocks > 0 folded (what emulate='fp8' restates)
     got8, gcls8 = ops.vit_forward(x.to(DEV), pk8)
     l8 = [rel_l2(got8[j].float(), feats8[:, 1:, j * dim:(j + 1) * dim].reshape(-1, dim)) for j in range(len(taps))]
     l8_32 = [rel_l2(got8[j].float(), feats[:, 1:, j * dim:(j + 1) * dim].reshape(-1, dim)) for j in range(len(taps))]
@@ -265,7 +266,7 @@ def test_config4_per_block_teacher_forced_fp8_and_bf16():
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     for mode, gate in (('fp8', 3e-2), ('bf16', 5e-3)):      # measured 1.1e-2 .. 1.8e-2 / 1.4e-3 .. 1.7e-3
         pk = ops.PackedViT(sd, depth, dim, heads, patch, img, (), mode, ln_fold=0)
-        emul = 'fp8' if mode == 'fp8' else 'bf16_nofold'      # a block on its own cannot consume a folded LayerNorm
+        emul = 'fp8_nofold' if mode == 'fp8' else 'bf16_nofold'      # a block on its own cannot consume a folded LayerNorm
         worst = (0.0, -1)
         errs = []
         with torch.no_grad():

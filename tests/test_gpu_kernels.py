@@ -347,9 +347,93 @@ def test_gemm_fp8_vs_fp64_on_the_dequantised_operands(M, N, K, epi):
                 assert frac < 5e-3 and rel_l2(got, want) < 3e-3, (frac, rel_l2(got, want))
 
 
-def test_vit_forward_fp8_vs_emulating_oracle():
+@pytest.mark.parametrize('M,N,K,add2', [(577 * 8, 1024, 4096, True), (577 * 8, 1024, 4096, False), (25216, 768, 3072, True),
+                                         (1000, 256, 512, True)])
+def test_gemm_fp8_ln_fold_producer_epilogue(M, N, K, add2):
+    """fp8 mode, LayerNorm 1 folded into the next block's qkv GEMM -- producer side (mvf_gemm_fp8_ln epi 2, the fc2 GEMM): the fp32
+    residual stream and the tap must be BITWISE what the plain residual epilogue writes; xq / xq_scales must decode to exactly
+    oracle.vit.mx_quant of that fp32 row (every scale dword whole: two waves share one); the partial sums per 64-column slice against
+    fp64 of the same values."""
+    g = gen(75)
+    A = torch.randn(M, K, generator=g) * torch.exp(1.0 * torch.randn(M, 1, generator=g))
+    W = torch.randn(N, K, generator=g) * 0.03
+    b = torch.randn(N, generator=g).to(DEV)
+    Aq, As = _mx_quant_dev(A.to(DEV), _lib.F32)
+    Wq, Ws = _mx_quant_dev(W.to(DEV), _lib.F32)
+    tpf = 577 if M % 577 == 0 else (197 if M % 197 == 0 else 100)
+    x0 = (torch.randn(M, N, generator=g) * torch.exp(1.5 * torch.randn(M, 1, generator=g))).to(DEV)
+    x0[:, 37] *= 200.0                                 # an outlier channel inside one MX block
+    delta = (torch.randn(M, N, generator=g)).to(DEV).to(torch.bfloat16) if add2 else None
+    ls = (1.0 + 0.1 * torch.randn(N, generator=gen(76))).to(DEV)
+    tap_rows = (M // tpf) * (tpf - 1)
+    outs = []
+    for fold in (False, True):
+        x = x0.clone()
+        tap = torch.zeros(tap_rows, N, device=DEV, dtype=torch.bfloat16)
+        xq = torch.full((M, N), 0x5a, device=DEV, dtype=torch.uint8)
+        xs = torch.full((N // 128, M), 0x5a5a5a5a, device=DEV, dtype=torch.int32)
+        stats = torch.full((N // 64, M, 2), 7.0, device=DEV)
+        if fold:
+            _lib.call('mvf_gemm_fp8_ln', 2, Aq.data_ptr(), K, As.data_ptr(), Wq.data_ptr(), K, Ws.data_ptr(), b.data_ptr(), None, 0,
+                      x.data_ptr(), N, tap.data_ptr(), N, ls.data_ptr(), tpf, _lib.ptr(delta), N, xq.data_ptr(), N, xs.data_ptr(),
+                      stats.data_ptr(), None, None, M, N, K, S())
+        elif not add2:      # (mvf_gemm_fp8 has no second addend: that form is checked against fp64 below)
+            _lib.call('mvf_gemm_fp8', 2, Aq.data_ptr(), K, As.data_ptr(), Wq.data_ptr(), K, Ws.data_ptr(), b.data_ptr(), None, 0,
+                      None, x.data_ptr(), N, tap.data_ptr(), N, ls.data_ptr(), tpf, M, N, K, S())
+        torch.cuda.synchronize()
+        outs.append((x, tap, xq, xs, stats))
+    (xp, tapp, _, _, _), (xf, tapf, xq, xs, stats) = outs
+    if not add2:
+        assert torch.equal(xp, xf) and torch.equal(tapp, tapf)
+    else:
+        # reference for the addend form: fp64 on the dequantised operands ((x0 + delta) first, as the kernel associates them)
+        Ad, Wd = _mx_decode(Aq, As, M, K).double(), _mx_decode(Wq, Ws, N, K).double()
+        want = (x0.double().cpu() + delta.double().cpu()) + ls.double().cpu() * (Ad @ Wd.t() + b.double().cpu())
+        check(xf, want, 2e-5, 'fp8 fold producer residual (with the deferred addend)')
+        assert torch.equal(tapf, xf.to(torch.bfloat16).view(M // tpf, tpf, N)[:, 1:].reshape(-1, N))
+    got = _mx_decode(xq, xs, M, N)
+    ref = OV.mx_quant(xf.cpu())
+    assert torch.equal(got, ref), 'MX-fp8 of the new residual row differs in %d of %d elements' % ((got != ref).sum().item(), got.numel())
+    xs64 = xf.double().cpu().view(M, N // 64, 64)
+    check(stats[:, :, 0].t(), xs64.sum(-1), 1e-5, 'fp8 fold producer row sums')
+    check(stats[:, :, 1].t(), (xs64 * xs64).sum(-1), 1e-5, 'fp8 fold producer row sums of squares')
+
+
+@pytest.mark.parametrize('M,N,K', [(577 * 8, 3072, 1024), (25216, 2304, 768), (1000, 768, 256)])
+def test_gemm_fp8_ln_fold_consumer_epilogue(M, N, K):
+    """Consumer side (mvf_gemm_fp8_ln epi 0, the qkv GEMM): C = bf16(rstd * (xq W'^T - mean * c) + d) on MX-fp8 operands against fp64
+    on the dequantised operands, with c the row sums of the dequantised W' -- and, reported against the unfolded form it stands for
+    (LayerNorm of the unquantised row), the dtype's own error."""
+    g = gen(77)
+    x = torch.randn(M, K, generator=g) * torch.exp(0.5 * torch.randn(M, 1, generator=g)) + 0.3 * torch.randn(M, 1, generator=g)
+    x[:, 70] *= 60.0
+    gam, beta = 1.0 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.03
+    b = torch.randn(N, generator=g)
+    xq, xs = _mx_quant_dev(x.to(DEV), _lib.F32)
+    Wq, Ws = _mx_quant_dev((W * gam[None, :]).to(DEV), _lib.F32)
+    xd, Wd = _mx_decode(xq, xs, M, K).double(), _mx_decode(Wq, Ws, N, K).double()
+    c = Wd.sum(1)
+    d = b.double() + W.double() @ beta.double()
+    mean = x.double().mean(-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt((x.double() ** 2).mean(-1, keepdim=True) - mean * mean + 1e-6)
+    mr = torch.cat([mean, rstd], 1).float().contiguous().to(DEV)
+    C = torch.full((M, N), 7.0, device=DEV, dtype=torch.bfloat16)
+    cd, dd = c.float().to(DEV), d.float().to(DEV)
+    for rep in range(2):
+        _lib.call('mvf_gemm_fp8_ln', 0, xq.data_ptr(), K, xs.data_ptr(), Wq.data_ptr(), K, Ws.data_ptr(), dd.data_ptr(), C.data_ptr(), N,
+                  None, 0, None, 0, None, 197, None, 0, None, 0, None, None, mr.data_ptr(), cd.data_ptr(), M, N, K, S())
+    want = rstd * (xd @ Wd.t() - mean * c) + d
+    check(C.float(), want, 4.5e-3, 'fp8 fold consumer')
+    plain = OV.layer_norm(x, gam, beta, 1e-6).double() @ W.double().t() + b.double()
+    assert rel_l2(C.float(), plain) < 6e-2, rel_l2(C.float(), plain)
+
+
+@pytest.mark.parametrize('fold', [1, 0])
+def test_vit_forward_fp8_vs_emulating_oracle(fold):
     """The whole backbone in MX-fp8 mode (small ViT, dim 256) against the oracle that quantises the same operands
-    (oracle/vit.py emulate='fp8'), and -- reported -- against the fp32 oracle."""
+    (oracle/vit.py emulate='fp8' / 'fp8_nofold': norm1 of blocks > 0 folded into the qkv GEMM -- the product's default from dim 1024
+    on -- or a LayerNorm + quantiser pass in front of every GEMM), and -- reported -- against the fp32 oracle."""
     from conftest import record_parity
     dim, depth, heads, patch, img, F = 256, 4, 4, 16, 64, 6
     w = OV.init_vit_weights(dim, depth, patch, img, seed=81, layerscale=True)
@@ -357,13 +441,16 @@ def test_vit_forward_fp8_vs_emulating_oracle():
     taps = (1, 3)
     with torch.no_grad():
         feats, cls = OV.vit_forward(x, w, heads, patch, taps)
-        feats8, cls8 = OV.vit_forward(x, w, heads, patch, taps, emulate='fp8')
-    got, gcls = ops.vit_forward(x.to(DEV), _pack(w, depth, dim, heads, patch, img, taps, 'fp8'))
+        feats8, cls8 = OV.vit_forward(x, w, heads, patch, taps, emulate='fp8' if fold else 'fp8_nofold')
+    pk = ops.PackedViT({k: v.to(DEV) for k, v in w.items()}, depth, dim, heads, patch, img, taps, 'fp8', ln_fold=fold)
+    assert pk.ln_fold == (2 if fold else 0)
+    got, gcls = ops.vit_forward(x.to(DEV), pk)
     for j in range(len(taps)):
         r32 = feats[:, 1:, j * dim:(j + 1) * dim].reshape(-1, dim)
         r8 = feats8[:, 1:, j * dim:(j + 1) * dim].reshape(-1, dim)
         l8, l32 = rel_l2(got[j].float(), r8), rel_l2(got[j].float(), r32)
-        record_parity('fp8 ViT (dim 256, depth 4) tap %d: rel-L2 %.3e vs fp8-emulating oracle, %.3e vs fp32 oracle' % (taps[j], l8, l32))
+        record_parity('fp8 ViT (dim 256, depth 4, norm1 %s) tap %d: rel-L2 %.3e vs fp8-emulating oracle, %.3e vs fp32 oracle' % (
+            'folded' if fold else 'as a pass', taps[j], l8, l32))
         assert l8 < 1e-2 and l32 < 6e-2, (l8, l32)
     lc = rel_l2(gcls, cls8)
     record_parity('fp8 ViT (dim 256, depth 4) final-norm CLS: rel-L2 %.3e vs fp8-emulating oracle' % lc)

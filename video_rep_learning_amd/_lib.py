@@ -38,6 +38,7 @@ SIGNATURES = {
     'mvf_quant_mxfp8': 'ipzpzpiip',
     'mvf_layernorm_mxfp8': 'pzpppzpiifp',
     'mvf_gemm_fp8': 'ipippipppippipipiiiip',
+    'mvf_gemm_fp8_ln': 'ipippipppipipipipipippppiiip',
     'mvf_gemm_tc_select': 'i',
     'mvf_gemm_tc_debug_stamps': 'p',
     'mvf_gemm_tc_debug_rowmask': 'i',

@@ -287,7 +287,8 @@ int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, 
 // MX-fp8 operands: the 256x256 kernel's FP8 variants only (no 128x128 fallback: sizes beyond its 32-bit offsets are refused)
 int mvf_gemm_fp8_impl(int epi, const void* A, int lda, const unsigned* sa, const void* W, int ldw, const unsigned* sw,
                       const float* bias, void* C, int ldc, unsigned* c_scales, float* resid, int ldr, void* tap, int ldt,
-                      const float* ls, int tpf, int M, int N, int K, hipStream_t st, const void* addend2, int ld2) {
+                      const float* ls, int tpf, int M, int N, int K, hipStream_t st, const void* addend2, int ld2,
+                      const MvfGemmLn* ln) {
   MVF_CHECK_ARG(A && W && sa && sw && M > 0 && N > 0 && K > 0 && K % 256 == 0 && N % 32 == 0);
   if (c_scales != nullptr) {   // epi 1 with an MX-fp8 result: C = e4m3 bytes, c_scales [N/128][M]
     MVF_CHECK_ARG(epi == EPI_GELU && C && N % 128 == 0 && ldc % 8 == 0 && ((uintptr_t)C % 8) == 0 && ((uintptr_t)c_scales % 4) == 0);
@@ -308,6 +309,17 @@ int mvf_gemm_fp8_impl(int epi, const void* A, int lda, const unsigned* sa, const
   if (addend2 != nullptr) {
     MVF_CHECK_ARG(epi == EPI_RESID && ((uintptr_t)addend2 % 8) == 0 && ld2 % 4 == 0 && ld2 >= N);
     a.radd2 = (const bf16_t*)addend2; a.ldr2 = ld2;
+  }
+  if (ln != nullptr) {   // LayerNorm folded into the fp8 GEMMs (include/mvf_hip.h: qkv_c in fp8 mode)
+    if (ln->ln_mr != nullptr) {          // consumer: A = MX-fp8 of the UN-normalised residual stream, W = MX-fp8(gamma (.) W)
+      MVF_CHECK_ARG(epi == EPI_STORE && ln->ln_c != nullptr && ((uintptr_t)ln->ln_mr % 8) == 0 && ((uintptr_t)ln->ln_c % 16) == 0);
+      a.ln_mr = ln->ln_mr; a.ln_c = ln->ln_c;
+    } else {                             // producer: the new residual row also as MX-fp8 + its row sums
+      MVF_CHECK_ARG(epi == EPI_RESID && ln->xb != nullptr && ln->stats != nullptr && ln->xb_scales != nullptr && N % 128 == 0 &&
+                    ln->ldxb % 8 == 0 && ln->ldxb >= N && ((uintptr_t)ln->xb % 8) == 0 && ((uintptr_t)ln->xb_scales % 4) == 0 &&
+                    ((uintptr_t)ln->stats % 8) == 0);
+      a.xb = (char*)ln->xb; a.ldxb = ln->ldxb; a.stats = ln->stats; a.csc = ln->xb_scales;
+    }
   }
   return mvf_gemm_tc256_launch(epi, a, /*persistent=*/true, st);
 }

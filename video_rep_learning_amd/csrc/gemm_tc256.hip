@@ -651,6 +651,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
         } else {
           const float2 mr = make_float2(0.f, 1.f);   // producer side (EPI_RESID): xb + row sums
           float s1 = 0.f, s2 = 0.f;
+          if constexpr (FP8) {
+            // fp8: xb = MX-fp8(x_new), the wave's 64 columns = two blocks; one 2-byte store of both scales as in EPI_GELU_Q
+            const int nbw = n0 + wc * 64;
+            const bool okw = m < a.M && nbw < a.N;
+            const unsigned q0 = epilogue_pair_resid_q(a, m, okw, nbw, fgrp, acc[i][0], acc[i][1], bj[0], bj[1], addb[ii][0], addb[ii][1],
+                                                      gj[0], gj[1], s1, s2);
+            const unsigned q1 = epilogue_pair_resid_q(a, m, okw, nbw + 32, fgrp, acc[i][2], acc[i][3], bj[2], bj[3], addb[ii][2],
+                                                      addb[ii][3], gj[2], gj[3], s1, s2);
+            if (okw && fgrp == 0)
+              *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(a.csc + (size_t)(nbw >> 7) * a.M + m) + (wc & 1) * 2) =
+                  (unsigned short)(q0 | (q1 << 8));
+          } else {
 #pragma unroll
           for (int jp = 0; jp < 2; ++jp) {
             const int nb = n0 + wc * 64 + jp * 32;
@@ -658,6 +670,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
             epilogue_pair_bf16_ln<EPI, F16>(a, m, m < a.M && nb < a.N, nb, fgrp, acc[i][2 * jp], acc[i][2 * jp + 1], bj[2 * jp],
                                        bj[2 * jp + 1], kReadModify ? addb[ii][2 * jp] : z4,
                                        kReadModify ? addb[ii][2 * jp + 1] : z4, gj[2 * jp], gj[2 * jp + 1], mr, c0, c1, s1, s2);
+          }
           }
           if constexpr (kLnProducer) {
             if (a.stats != nullptr) {   // kernel argument: every lane runs the cross-lane sums
@@ -896,10 +909,17 @@ int mvf_gemm_tc256_launch(int epi, const gemm_tc::GemmTcArgs& a, bool persistent
   if ((size_t)a.M * a.lda * 2 >= (1ull << 32) || wrows * a.ldw * 2 >= (1ull << 32) || a.M >= (1 << 24) ||
       wrows >= (1u << 24) || a.lda >= (1 << 23) || a.ldw >= (1 << 23))
     return MVF_ERR_UNSUPPORTED;
-  if (fp8) {   // MX-fp8 operands (validated by mvf_gemm_fp8): no LN fold, no stacked batches, no stamps
-    if (a.sw == nullptr || a.batch_rows != 0 || a.dbg != nullptr || a.ln_mr != nullptr || a.ln_part != nullptr || a.xb != nullptr ||
-        a.stats != nullptr)
-      return MVF_ERR_ARG;
+  if (fp8) {   // MX-fp8 operands (validated by mvf_gemm_fp8): no stacked batches, no stamps
+    if (a.sw == nullptr || a.batch_rows != 0 || a.dbg != nullptr || a.ln_part != nullptr) return MVF_ERR_ARG;
+    // LN fold, consumer side (qkv on the un-normalised MX-fp8 residual stream; (mean, rstd) from the finalize launch: the in-kernel
+    // form's LDS region is where this kernel keeps its operand scales) and producer side (fc2: xb = MX-fp8(x_new) + csc + row sums)
+    if (a.ln_mr != nullptr)
+      return epi == EPI_STORE && a.ln_c != nullptr ? launch<EPI_STORE, false, true, true>(a, persistent, st) : MVF_ERR_ARG;
+    if (a.xb != nullptr || a.stats != nullptr) {
+      if (epi != EPI_RESID || a.xb == nullptr || a.stats == nullptr || a.csc == nullptr || a.N % 128 != 0) return MVF_ERR_ARG;
+      return a.radd2 != nullptr ? launch<EPI_RESID, false, true, true, 0, true>(a, persistent, st)
+                                : launch<EPI_RESID, false, true, true>(a, persistent, st);
+    }
     switch (epi) {
       case EPI_STORE: return launch<EPI_STORE, false, false, true>(a, persistent, st);
       case EPI_GELU: return launch<EPI_GELU, false, false, true>(a, persistent, st);

@@ -59,6 +59,7 @@ struct GemmTcArgs {
   const bf16_t* radd2;
   int ldr2;
   // EPI_GELU_Q: C holds e4m3 bytes [M, ldc] and csc [N/128][M] the output's block scales (same layout as sa)
+  // fp8 EPI_RESID with the LN-fold producer extras: xb holds e4m3 bytes [M, ldxb] of the new residual row, csc their block scales
   unsigned* csc;
   // gemm_tc256: > 0 = tile-list order grouped by weight panels (speed only): the list runs through groups of `ngroup` column
   // tiles, all row panels inside a group, so that an XCD's contiguous chunk of it needs only ngroup W panels (L2-resident)
@@ -415,6 +416,53 @@ __device__ __forceinline__ unsigned epilogue_pair_gelu_q(const GemmTcArgs& a, in
   const uint32_t y = pack_fp8x4(v1[0] * inv, v1[1] * inv, v1[2] * inv, v1[3] * inv);
   const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
   if (ok) *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + nb + (fgrp & 1) * 16 + (fgrp >> 1) * 8) = make_uint2(r[0], r[1]);
+  return sb;
+}
+
+// EPI_RESID of the fp8 kernel's LN-fold PRODUCER: the residual update of epilogue_pair_bf16 (LayerScale, addends, fp32 store,
+// tap), then the two tiles = one 32-column MX block of the row's NEW residual values -> e4m3 bytes into a.xb [M, ldxb] (the next
+// block's qkv GEMM reads the un-normalised stream and applies the LayerNorm in its epilogue) and their (sum, sum of squares) into
+// s1 / s2.  Quantised straight from the fp32 values.  Returns the block's E8M0 byte.  Every lane runs the cross-lane steps.
+__device__ __forceinline__ unsigned epilogue_pair_resid_q(const GemmTcArgs& a, int m, bool ok, int nb, int fgrp,
+                                                          const f32x4_t& acc0, const f32x4_t& acc1, const float4& b0,
+                                                          const float4& b1, const float4& add0, const float4& add1,
+                                                          const float4& g0, const float4& g1, float& s1, float& s2) {
+  float v0[4] = {acc0[0] + b0.x, acc0[1] + b0.y, acc0[2] + b0.z, acc0[3] + b0.w};
+  float v1[4] = {acc1[0] + b1.x, acc1[1] + b1.y, acc1[2] + b1.z, acc1[3] + b1.w};
+  const int n0 = nb + fgrp * 4, n1 = nb + 16 + fgrp * 4;
+  bool tap_ok = false;
+  size_t tap_off = 0;
+  if (a.ls != nullptr) {
+    v0[0] *= g0.x; v0[1] *= g0.y; v0[2] *= g0.z; v0[3] *= g0.w;
+    v1[0] *= g1.x; v1[1] *= g1.y; v1[2] *= g1.z; v1[3] *= g1.w;
+  }
+  v0[0] += add0.x; v0[1] += add0.y; v0[2] += add0.z; v0[3] += add0.w;
+  v1[0] += add1.x; v1[1] += add1.y; v1[2] += add1.z; v1[3] += add1.w;
+  if (ok) {
+    float* rp = a.resid + (size_t)m * a.ldr;
+    *reinterpret_cast<float4*>(rp + n0) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+    *reinterpret_cast<float4*>(rp + n1) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+    if (a.tap != nullptr) {
+      const int f = m / a.tpf, t = m - f * a.tpf;
+      tap_ok = t > 0;
+      tap_off = (size_t)(f * (a.tpf - 1) + t - 1) * a.ldt;
+    }
+  }
+  if (a.tap != nullptr) swap_store_bf16x8(a.tap, tap_off, nb, fgrp, tap_ok, v0, v1);   // wave-uniform branch
+  float amax = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    amax = fmaxf(amax, fmaxf(fabsf(v0[r]), fabsf(v1[r])));
+    s1 += v0[r] + v1[r];
+    s2 = fmaf(v0[r], v0[r], fmaf(v1[r], v1[r], s2));
+  }
+  amax = row_quad_max(amax);
+  const unsigned sb = mx_scale_byte(amax);
+  const float inv = mx_inv_scale(sb);
+  const uint32_t x = pack_fp8x4(v0[0] * inv, v0[1] * inv, v0[2] * inv, v0[3] * inv);
+  const uint32_t y = pack_fp8x4(v1[0] * inv, v1[1] * inv, v1[2] * inv, v1[3] * inv);
+  const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+  if (ok) *reinterpret_cast<uint2*>(a.xb + (size_t)m * a.ldxb + nb + (fgrp & 1) * 16 + (fgrp >> 1) * 8) = make_uint2(r[0], r[1]);
   return sb;
 }
 

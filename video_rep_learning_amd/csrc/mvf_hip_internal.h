@@ -47,6 +47,9 @@ struct MvfGemmLn {
   const float* ln_part;
   int ln_ns;
   float ln_eps;
+  // MX-fp8 producer (mvf_gemm_fp8_impl, epi 2): xb receives e4m3 bytes [M, ldxb] of the new residual row, these their block scales
+  // [N/128][M] (mxfp8.hip's layout)
+  unsigned* xb_scales;
 };
 int mvf_gemm_tc_impl(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias, void* C,
                      int ldc, float* resid, int ldr, void* tap, int ldt, const float* pos, const float* ls, int tpf, int M,
@@ -58,7 +61,8 @@ int mvf_layernorm_mxfp8_impl(const float* x, size_t in_stride, const float* g, c
                              unsigned* scales, int rows, int D, float eps, hipStream_t st, const void* add_bf16 = nullptr, size_t add_stride = 0);
 int mvf_gemm_fp8_impl(int epi, const void* A, int lda, const unsigned* sa, const void* W, int ldw, const unsigned* sw,
                       const float* bias, void* C, int ldc, unsigned* c_scales, float* resid, int ldr, void* tap, int ldt,
-                      const float* ls, int tpf, int M, int N, int K, hipStream_t st, const void* addend2 = nullptr, int ld2 = 0);
+                      const float* ls, int tpf, int M, int N, int K, hipStream_t st, const void* addend2 = nullptr, int ld2 = 0,
+                      const MvfGemmLn* ln = nullptr);
 int mvf_ln_stats_finalize_impl(const float* part, int ns, float* mr, int rows, int D, float eps, hipStream_t st);
 int mvf_im2col_impl(int dtype, const float* img, void* out, int F, int H, int W, int P, int ldk, hipStream_t st);
 // K of the patch-embed GEMM: 3*P*P rounded up to 128 elements (the granule of both GEMM kernels and dtypes)

@@ -80,7 +80,7 @@ int timed_gemm(int dtype, int epi, const void* A, int lda, const void* W, int ld
   }
   const int rc = f8 != nullptr
                      ? mvf_gemm_fp8_impl(epi, A, lda, f8->sa, W, ldw, f8->sw, bias, C, ldc, f8->csc, resid, ldr, tap, ldt, ls, tpf, M, N, K, st,
-                                         f8->addend2, f8->ld2)
+                                         f8->addend2, f8->ld2, ln)
                      : mvf_gemm_tc_impl(dtype, epi, A, lda, W, ldw, bias, C, ldc, resid, ldr, tap, ldt, pos, ls, tpf, M, N, K, st, 0,
                                         0, ln);
   if (rec) {
@@ -141,7 +141,11 @@ size_t carve(int dtype, int fc, int N, int D, int P, Ws* w, char* base) {
   char* delta = nullptr;
   char* stats = nullptr;
   char* mr = nullptr;
-  if (dtype == MVF_FP8 && D % 64 == 0) delta = take(Mc * D * 2);
+  if (dtype == MVF_FP8 && D % 64 == 0) {
+    delta = take(Mc * D * 2);
+    stats = take(Mc * (size_t)(D / 64) * 2 * 4);   // LayerNorm 1 folded into the fp8 qkv GEMM (run_blocks)
+    mr = take(Mc * 2 * 4);
+  }
   if ((dtype == MVF_BF16 || dtype == MVF_F16) && D % 64 == 0) {
     xb = take(Mc * D * 2);
     delta = take(Mc * D * 2);
@@ -206,9 +210,20 @@ int run_blocks(const MvfVitWeights* w, int dtype, bool fp8, const Ws& ws, int fc
       const Fp8Scales sq = {ws.hs, w->qkv_s[l], nullptr, nullptr, 0}, sp = {ws.hs, w->proj_s[l], nullptr, nullptr, 0},
                       s1 = {ws.hs, w->fc1_s[l], ws.hids, nullptr, 0},
                       s2 = {ws.hids, w->fc2_s[l], nullptr, defer8 ? ws.delta : nullptr, D};
-      RUN(mvf_layernorm_mxfp8_impl(ws.x, D, w->ln1_w[l], w->ln1_b[l], ws.hq, D, ws.hs, Mc, D, w->ln_eps, st));
-      RUN(timed_gemm(dtype, EPI_STORE, ws.hq, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0, nullptr,
-                     nullptr, N, Mc, 3 * D, D, st, nullptr, &sq));
+      // LayerNorm 1 folded into the qkv GEMM (qkv_c[l] set: qkv_w[l] = MX-fp8(gamma (.) W), qkv_b[l] = b + W beta): the previous
+      // block's fc2 epilogue left MX-fp8(x) in hq / hs and the row partial sums in stats -- no layernorm_mxfp8 pass over the stream
+      auto fold8 = [&](int ll) { return w->qkv_c != nullptr && ll < w->depth && w->qkv_c[ll] != nullptr && ws.stats != nullptr; };
+      if (fold8(l)) {
+        if (l == l0) return MVF_ERR_ARG;   // nothing in this call produced the layer's operand and statistics
+        RUN(mvf_ln_stats_finalize_impl(ws.stats, ns, ws.mr, Mc, D, w->ln_eps, st));
+        const MvfGemmLn lc = {nullptr, 0, nullptr, ws.mr, w->qkv_c[l], 0, nullptr};
+        RUN(timed_gemm(dtype, EPI_STORE, ws.hq, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0, nullptr,
+                       nullptr, N, Mc, 3 * D, D, st, &lc, &sq));
+      } else {
+        RUN(mvf_layernorm_mxfp8_impl(ws.x, D, w->ln1_w[l], w->ln1_b[l], ws.hq, D, ws.hs, Mc, D, w->ln_eps, st));
+        RUN(timed_gemm(dtype, EPI_STORE, ws.hq, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0, nullptr,
+                       nullptr, N, Mc, 3 * D, D, st, nullptr, &sq));
+      }
       if (attn_variant == 0 && H % 2 == 0 && g_attn_q8) {
         // the attention kernel quantises its own output (bit for bit the two launches below; the qkv GEMM is done with hq / hs)
         RUN(mvf_vit_attn32_impl(MVF_BF16, ws.qkv, ws.hq, nullptr, fc, N, H, D, 5, 0, st, ws.hs));
@@ -227,8 +242,11 @@ int run_blocks(const MvfVitWeights* w, int dtype, bool fp8, const Ws& ws, int fc
       // fc1 + GELU with the MX-fp8 quantisation in its epilogue: hidq / hids straight out of the GEMM (no bf16 hid)
       RUN(timed_gemm(dtype, EPI_GELU, ws.hq, D, w->fc1_w[l], D, w->fc1_b[l], ws.hidq, 4 * D, nullptr, 0, nullptr, 0, nullptr,
                      nullptr, N, Mc, 4 * D, D, st, nullptr, &s1));
+      // producer side of the next block's fold: hq / hs are free here (fc1 consumed them) and are next read by that block's qkv GEMM
+      MvfGemmLn lpr = {ws.hq, D, ws.stats, nullptr, nullptr, 0, nullptr};
+      lpr.xb_scales = ws.hs;
       RUN(timed_gemm(dtype, EPI_RESID, ws.hidq, 4 * D, w->fc2_w[l], 4 * D, w->fc2_b[l], nullptr, 0, ws.x, D, tap_ptr, D,
-                     nullptr, w->ls2 ? w->ls2[l] : nullptr, N, Mc, D, 4 * D, st, nullptr, &s2));
+                     nullptr, w->ls2 ? w->ls2[l] : nullptr, N, Mc, D, 4 * D, st, (l + 1 < l1 && fold8(l + 1)) ? &lpr : nullptr, &s2));
       continue;
     }
     // qkv projection fused into the attention kernel (vit_qkv_attn.hip): the [Mc, 3D] qkv tensor never reaches HBM
@@ -335,8 +353,8 @@ extern "C" int mvf_vit_fwd_x(const MvfVitWeights* w, int dtype, const float* fra
   MVF_CHECK_ARG(w && frames && workspace && F > 0);
   MVF_CHECK_ARG(dtype == MVF_F32 || dtype == MVF_BF16 || dtype == MVF_FP8 || dtype == MVF_F16);
   const bool fp8 = dtype == MVF_FP8;
-  if (fp8) {   // MX-fp8 GEMM operands, bf16 everywhere else (patch embedding, attention, taps); no LN fold
-    MVF_CHECK_ARG(w->dim % 256 == 0 && w->qkv_s && w->proj_s && w->fc1_s && w->fc2_s && !w->qkv_c && !w->fc1_c);
+  if (fp8) {   // MX-fp8 GEMM operands, bf16 everywhere else (patch embedding, attention, taps); LN fold: norm1 only (qkv_c)
+    MVF_CHECK_ARG(w->dim % 256 == 0 && w->qkv_s && w->proj_s && w->fc1_s && w->fc2_s && !w->fc1_c && (!w->qkv_c || w->depth == 0 || !w->qkv_c[0]));
     dtype = MVF_BF16;
   }
   const int D = w->dim, H = w->heads, P = w->patch, img = w->img;
@@ -377,7 +395,7 @@ extern "C" int mvf_vit_blocks_fwd(const MvfVitWeights* w, int dtype, float* x, i
   MVF_CHECK_ARG(dtype == MVF_F32 || dtype == MVF_BF16 || dtype == MVF_FP8 || dtype == MVF_F16);
   const bool fp8 = dtype == MVF_FP8;
   if (fp8) {
-    MVF_CHECK_ARG(w->dim % 256 == 0 && w->qkv_s && w->proj_s && w->fc1_s && w->fc2_s && !w->qkv_c && !w->fc1_c);
+    MVF_CHECK_ARG(w->dim % 256 == 0 && w->qkv_s && w->proj_s && w->fc1_s && w->fc2_s && !w->fc1_c);
     dtype = MVF_BF16;
   }
   const int D = w->dim, P = w->patch, img = w->img;
@@ -445,6 +463,16 @@ extern "C" int mvf_gemm_fp8(int epi, const void* A, int lda, const unsigned* sa,
                             const float* bias, void* C, int ldc, unsigned* c_scales, float* resid, int ldr, void* tap, int ldt,
                             const float* ls, int tpf, int M, int N, int K, hipStream_t st) {
   return mvf_gemm_fp8_impl(epi, A, lda, sa, W, ldw, sw, bias, C, ldc, c_scales, resid, ldr, tap, ldt, ls, tpf, M, N, K, st);
+}
+// mvf_gemm_fp8 with the LN-fold extras (include/mvf_hip.h): epi 0 consumer (ln_mr, ln_c), epi 2 producer (xq, xq_scales, stats)
+extern "C" int mvf_gemm_fp8_ln(int epi, const void* A, int lda, const unsigned* sa, const void* W, int ldw, const unsigned* sw,
+                               const float* bias, void* C, int ldc, float* resid, int ldr, void* tap, int ldt, const float* ls, int tpf,
+                               const void* addend2, int ld2, void* xq, int ldxq, unsigned* xq_scales, float* stats, const float* ln_mr,
+                               const float* ln_c, int M, int N, int K, hipStream_t st) {
+  MVF_CHECK_ARG((epi == 0 && ln_mr && ln_c && !xq && !xq_scales && !stats) || (epi == 2 && xq && xq_scales && stats && !ln_mr && !ln_c));
+  MvfGemmLn ln = {xq, ldxq, stats, ln_mr, ln_c, 0, nullptr};
+  ln.xb_scales = xq_scales;
+  return mvf_gemm_fp8_impl(epi, A, lda, sa, W, ldw, sw, bias, C, ldc, nullptr, resid, ldr, tap, ldt, ls, tpf, M, N, K, st, addend2, ld2, &ln);
 }
 // fp32 result of a bf16 GEMM without the in-place read-modify-write: out = A W^T + bias [+ addend]  (addend NULL: none).
 // The trainable backbone blocks' linears (forward, input gradient) -- ops._LinearTC.

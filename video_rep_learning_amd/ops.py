@@ -1826,6 +1826,11 @@ def scl_loss(emb, steps, seq_lens, masks, num_frames, negative_type, temperature
 # bf16 mode: fold LayerNorms into the GEMM that consumes them (include/mvf_hip.h: qkv_c / fc1_c).  MVF_LN_FOLD: 0 = none (the
 # LayerNorm kernels), 1 = norm1 of blocks > 0 and every norm2, 2 = norm1 only, 3 = norm2 only (A/B measurements).
 VIT_LN_FOLD = int(os.environ.get('MVF_LN_FOLD', '2'))
+# fp8 mode: norm1 of blocks > 0 folded into the MX-fp8 qkv GEMM (the previous block's fc2 epilogue writes MX-fp8(x) + row sums).
+# MVF_FP8_LN_FOLD: 1 = always, 0 = never (the layernorm_mxfp8 pass in front of every qkv GEMM), unset = where it pays: dim >= 1024.
+# Same box, profiles/r06/fp8_ln_fold_ab.txt: ViT-L/14 @ 336 (dim 1024, 147 712 rows) 74.9 -> 73.5 ms per step -- the pass it removes is
+# 183 us per block, the two epilogues cost 52 + 72 us; ViT-B/16 (dim 768, 50 432 rows) 8.44 -> 8.64 ms: the pass is 45 us there.
+VIT_FP8_LN_FOLD = os.environ.get('MVF_FP8_LN_FOLD', '')
 
 
 class PackedViT:
@@ -1883,14 +1888,19 @@ class PackedViT:
             self.keep.append(arr)
             return ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p))
 
-        def mx_tables(fmt, row_scale=None):
+        def mx_tables(fmt, row_scale=None, col_scale=None, csum=None):
             """Frozen weights [N, K] -> MX-fp8 (e4m3 bytes + E8M0 block scales [K/128][N]) with the device quantiser, once.
-            row_scale: per-layer key of a [N] vector multiplied into the rows first (LayerScale folded into proj)."""
+            row_scale: per-layer key of a [N] vector multiplied into the rows first (LayerScale folded into proj).
+            col_scale(i): a [K] vector multiplied into the columns first, or None (LayerNorm gamma folded into the consumer);
+            csum: list that receives, per layer, the row sums of the DEQUANTISED result (or None where col_scale(i) is None)."""
             wp, sp = [], []
             for i in range(depth):
                 W = sd[fmt % i].detach().float().contiguous()
                 if row_scale is not None:
                     W = (W * sd[row_scale % i].detach().float()[:, None]).contiguous()
+                cs = col_scale(i) if col_scale is not None else None
+                if cs is not None:
+                    W = (W.double() * cs.double()[None, :]).float().contiguous()
                 n, k = W.shape
                 if k % 256 != 0:
                     raise _lib.MvfError('fp8 mode needs GEMM K %% 256 == 0 (got %d)' % k)
@@ -1899,6 +1909,13 @@ class PackedViT:
                 call('mvf_quant_mxfp8', F32, W.data_ptr(), k, q.data_ptr(), k, sc.data_ptr(), n, k, stream())
                 self.keep += [q, sc]
                 wp.append(q.data_ptr()), sp.append(sc.data_ptr())
+                if csum is not None:
+                    if cs is None:
+                        csum.append(None)
+                    else:   # c[n] = sum_k of the values the matrix cores multiply: e4m3 byte x 2^(scale byte - 127), block by block
+                        e = sc.view(torch.uint8).reshape(k // 128, n, 4).permute(1, 0, 2).reshape(n, k // 32).double() - 127.0
+                        deq = q.view(torch.float8_e4m3fn).double().reshape(n, k // 32, 32) * torch.exp2(e)[:, :, None]
+                        csum.append(deq.sum((1, 2)))
             return ptr_table(wp), ptr_table(sp)
 
         def folded(lin, norm, skip0):
@@ -1920,7 +1937,10 @@ class PackedViT:
             return ptr_table(wp), ptr_table(bp), ptr_table(cp)
 
         fold = int(VIT_LN_FOLD if ln_fold is None else ln_fold) if (self.code in (BF16, F16) and dim % 128 == 0 and depth > 0) else 0
-        self.ln_fold = fold
+        # fp8: norm1 of blocks > 0 only (what ln_fold = 2 means in the 16-bit modes; any non-zero ln_fold asks for it)
+        want8 = (int(VIT_FP8_LN_FOLD) != 0 if VIT_FP8_LN_FOLD != '' else dim >= 1024) if ln_fold is None else int(ln_fold) != 0
+        fold8 = self.code == FP8 and depth > 1 and want8
+        self.ln_fold = 2 if fold8 else fold
         # Deferred residual of the attention branch (csrc/vit_fwd.hip) for LayerScale models: x + gamma_1 (.) (o W^T + b) =
         # x + o (gamma_1 (.) W)^T + gamma_1 (.) b -- gamma_1 goes into proj's weights and bias here and ls1 stays NULL, so the
         # device takes the deferred path (plain-store proj, branch output added in LayerNorm 2 and the fc2 epilogue)
@@ -1943,9 +1963,27 @@ class PackedViT:
         if self.code == FP8:
             w.proj_w, w.proj_s = mx_tables('blocks.%d.attn.proj.weight', 'blocks.%d.ls1.gamma' if self.ls1_folded else None)
             w.fc2_w, w.fc2_s = mx_tables('blocks.%d.mlp.fc2.weight')
-            w.qkv_w, w.qkv_s = mx_tables('blocks.%d.attn.qkv.weight')
             w.fc1_w, w.fc1_s = mx_tables('blocks.%d.mlp.fc1.weight')
-            w.qkv_b, w.fc1_b = table('blocks.%d.attn.qkv.bias', f32), table('blocks.%d.mlp.fc1.bias', f32)
+            w.fc1_b = table('blocks.%d.mlp.fc1.bias', f32)
+            if fold8:
+                # W' = MX-fp8(gamma (.) W), d = b + W beta, c = row sums of the dequantised W' (the row-mean term then cancels exactly
+                # against the products the matrix cores form); block 0's norm1 follows the patch embedding and keeps its LayerNorm pass
+                csum = []
+                w.qkv_w, w.qkv_s = mx_tables('blocks.%d.attn.qkv.weight', csum=csum,
+                                             col_scale=lambda i: None if i == 0 else sd['blocks.%d.norm1.weight' % i].detach())
+                bp, cp = [], []
+                for i in range(depth):
+                    bias = sd['blocks.%d.attn.qkv.bias' % i].detach().double()
+                    if i == 0:
+                        bp.append(f32(bias.float())), cp.append(None)
+                        continue
+                    W = sd['blocks.%d.attn.qkv.weight' % i].detach().double()
+                    bp.append(f32((bias + W @ sd['blocks.%d.norm1.bias' % i].detach().double()).float()))
+                    cp.append(f32(csum[i].float()))
+                w.qkv_b, w.qkv_c = ptr_table(bp), ptr_table(cp)
+            else:
+                w.qkv_w, w.qkv_s = mx_tables('blocks.%d.attn.qkv.weight')
+                w.qkv_b = table('blocks.%d.attn.qkv.bias', f32)
         else:
             if fold in (1, 2):
                 w.qkv_w, w.qkv_b, w.qkv_c = folded('attn.qkv', 'norm1', skip0=True)

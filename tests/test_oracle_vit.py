@@ -105,3 +105,43 @@ def test_patchify_matches_conv():
     ref = torch.nn.functional.conv2d(x, wt, stride=16).flatten(2).transpose(1, 2)
     got = OV.patchify(x, 16) @ wt.reshape(8, -1).t()
     assert (ref - got).abs().max().item() < 1e-4
+
+
+# ---- the emulating restatements against the plain one: with the roundings switched off, every folded form must BE the plain block ----
+@pytest.mark.parametrize('emulate', ['bf16', 'bf16_fold12', 'bf16_nofold', 'fp8', 'fp8_nofold'])
+def test_emulating_block_without_roundings_is_the_plain_block(emulate, monkeypatch):
+    """oracle/vit.py restates the product's reduced-precision data flow -- LayerNorm folded into the consuming GEMM
+    (rstd * (x W'^T - mean * c) + d), the deferred attention-branch residual, LayerScale folded into proj -- around bf16 / MX-fp8
+    rounding points.  With those roundings replaced by the identity the restatement must reproduce the plain pre-LN block
+    (timm Block.forward) to fp32 rounding: the algebra of every fold, checked on the CPU without a device."""
+    dim, depth, heads, patch, img, F = 256, 3, 4, 16, 64, 2
+    w = OV.init_vit_weights(dim, depth, patch, img, seed=5, layerscale=True)
+    g = torch.Generator().manual_seed(6)
+    for k in list(w):                   # non-trivial LayerNorm affines and LayerScales: the folds must carry them
+        if k.endswith('norm1.weight') or k.endswith('norm2.weight') or k.endswith('.gamma'):
+            w[k] = 1.0 + 0.3 * torch.randn(w[k].shape, generator=g)
+        elif k.endswith('norm1.bias') or k.endswith('norm2.bias'):
+            w[k] = 0.2 * torch.randn(w[k].shape, generator=g)
+    x = torch.randn(F, 3, img, img, generator=g)
+    with torch.no_grad():
+        ref, cls = OV.vit_forward(x, w, heads, patch, (0, 2))
+        monkeypatch.setattr(OV, 'bf16_round', lambda t: t)
+        monkeypatch.setattr(OV, '_bf16_round_true', lambda t: t)
+        monkeypatch.setattr(OV, 'mx_quant', lambda t: t)
+        got, gcls = OV.vit_forward(x, w, heads, patch, (0, 2), emulate=emulate)
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < 2e-5
+    assert ((gcls - cls).abs().max() / cls.abs().max()).item() < 2e-5
+
+
+def test_mx_quant_is_idempotent_and_block_local():
+    """mx_quant (the MX-fp8 quantise-dequantise the fp8 emulation applies): a second pass changes nothing, and a block's result depends on
+    that block alone (the scale is per 32 consecutive elements)."""
+    g = torch.Generator().manual_seed(7)
+    t = torch.randn(50, 256, generator=g) * torch.exp(2.0 * torch.randn(50, 1, generator=g))
+    q = OV.mx_quant(t)
+    assert torch.equal(OV.mx_quant(q), q)
+    t2 = t.clone()
+    t2[:, 32:64] *= 1000.0
+    q2 = OV.mx_quant(t2)
+    assert torch.equal(q2[:, :32], q[:, :32]) and torch.equal(q2[:, 64:], q[:, 64:])
+    assert ((q - t).abs() <= 0.0625 * t.reshape(50, 8, 32).abs().amax(-1, keepdim=True).expand(50, 8, 32).reshape(50, 256) + 1e-30).all()

@@ -594,21 +594,29 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
       // Done inside the store loop instead, the extra live values (c, mean/rstd) sat on top of the GELU temporaries and the
       // fc1 epilogue took twice as long.
       const char* smr = smem + LNMR_OFF + (lnp ? 0 : tpar * 2048) + (wr * WR0 + frow) * 8;
+      // Row outermost: the wave's 16 ln_c values stay live (the K loop's fragments are dead here), a row's (mean, rstd) is read ONCE and
+      // the next row's pair is in flight while this row is computed.  (Column tile outermost, as first written -- 4 ln_c values live,
+      // the pair re-read per (row, column tile) -- hipcc put a full LDS wait in front of each of the 32 groups of 8 instructions:
+      // ~5 k cycles per tile, +11 % on the qkv GEMM; round 6.)  Per element the same two operations in the same order: same bits.
+      float4 cj[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {     // column tile outermost: 4 ln_c values live at a time, (mean, rstd) re-read per row
-        const float4 c = *reinterpret_cast<const float4*>(slnc + (j * 16 + fgrp * 4) * 4);
+      for (int j = 0; j < 4; ++j) cj[j] = *reinterpret_cast<const float4*>(slnc + (j * 16 + fgrp * 4) * 4);
+      float2 mrn = *reinterpret_cast<const float2*>(smr);
 #pragma unroll
-        for (int i = 0; i < 4 + RTA; ++i) {      // (a fragment wave row 1 lacks: unused accumulators, rows inside the slot)
-          const float2 mr = *reinterpret_cast<const float2*>(smr + ((i >> 2) * 64 + (i & 3) * 16) * 8);
-          const float nm = -mr.x;
+      for (int i = 0; i < 4 + RTA; ++i) {      // (a fragment wave row 1 lacks: unused accumulators, rows inside the slot)
+        const float2 mr = mrn;
+        if (i + 1 < 4 + RTA) mrn = *reinterpret_cast<const float2*>(smr + (((i + 1) >> 2) * 64 + ((i + 1) & 3) * 16) * 8);
+        const float nm = -mr.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
           // mul_rounded: a product of its own rounding, never contracted with the bias add of the store loop below -- whether hipcc
           // fused the two depended on the instantiation (tile height, what else the kernel carries: the unequal-wave-row variants
           // stopped fusing the fragment wave row 1 lacks), and with it the bit-for-bit agreement of the kernels (gemm_tc.hip's
           // epilogue4 spells the same two roundings)
-          acc[i][j][0] = mul_rounded(mr.y, fmaf(nm, c.x, acc[i][j][0]));
-          acc[i][j][1] = mul_rounded(mr.y, fmaf(nm, c.y, acc[i][j][1]));
-          acc[i][j][2] = mul_rounded(mr.y, fmaf(nm, c.z, acc[i][j][2]));
-          acc[i][j][3] = mul_rounded(mr.y, fmaf(nm, c.w, acc[i][j][3]));
+          acc[i][j][0] = mul_rounded(mr.y, fmaf(nm, cj[j].x, acc[i][j][0]));
+          acc[i][j][1] = mul_rounded(mr.y, fmaf(nm, cj[j].y, acc[i][j][1]));
+          acc[i][j][2] = mul_rounded(mr.y, fmaf(nm, cj[j].z, acc[i][j][2]));
+          acc[i][j][3] = mul_rounded(mr.y, fmaf(nm, cj[j].w, acc[i][j][3]));
         }
       }
       SCHED_FENCE();   // keep the pre-pass out of the store loop (its values would pile onto the GELU temporaries)

@@ -397,7 +397,12 @@ __global__ __launch_bounds__(512, OCC) void vit_attn32p_kernel(Attn32Args g) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) pp[e] = 0;
   union { bf16x8_t v; uint32_t u[4]; } ones;
-  ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = F16 ? 0x3C003C00u : 0x3F803F80u;
+#ifndef MVF_ATTN_ONES_ROW0
+#define MVF_ATTN_ONES_ROW0 1
+#endif
+  // the row-sum product's A operand: ones in ROW 0 only (lanes 0 and 32), zeros in the other 31 rows -- the sum lands in register 0 of the
+  // lower lane half and 31 of the 32 result rows multiply by zero (what an all-ones fragment spends on 32 identical rows is toggling)
+  ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = (MVF_ATTN_ONES_ROW0 && r != 0) ? 0u : (F16 ? 0x3C003C00u : 0x3F803F80u);
 
   f32x16_t negm;                     // QS: -m_use in every register, the score tiles' initial accumulator (zero until tile 0 is known)
 #pragma unroll
@@ -597,7 +602,7 @@ __global__ __launch_bounds__(512, OCC) void vit_attn32p_kernel(Attn32Args g) {
   step(sA, sB, i, i == 0 ? 0 : rt_off(i - 1), rt_off(i), 0, std::false_type{}, std::true_type{}, 0);
   if (trig != 0) careful();
   // ---- epilogue: O / l -> 16-bit, whole 128-byte rows ----
-  const float l_run = MSUM ? lacc[0] : pair_sum(l_part);
+  const float l_run = MSUM ? (MVF_ATTN_ONES_ROW0 ? pair_sum(lacc[0]) : lacc[0]) : pair_sum(l_part);   // (row 0 = register 0 of the lane half hh = 0; the other half holds 0)
   const int q = q0 + r;
   const float inv = 1.0f / l_run;
   if constexpr (LSE) {

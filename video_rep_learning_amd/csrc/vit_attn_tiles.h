@@ -102,7 +102,10 @@ __device__ __forceinline__ void attn_tiles(const AttnArgs& a, const char* sk, co
   // receives its row's sum (of the ROUNDED probabilities, the values P.V multiplies) in all four result registers
   f32x4_t rs[NQ];
   union { bf16x8_t v; uint32_t u[4]; } ones;
-  ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = F16 ? 0x3C003C00u : 0x3F803F80u;
+  // ones in rows 0, 4, 8, 12 of the 16-row A fragment only (one per lane group g: its result register 0), zeros in the other twelve: the
+  // sums every lane reads are the same, and three quarters of the product's multipliers see a zero operand (the streamed kernel's
+  // all-ones fragment measured 2 - 3 % of that kernel's time at the power cap: profiles/r06/attn_ones_row0.txt)
+  ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = (li & 3) != 0 ? 0u : (F16 ? 0x3C003C00u : 0x3F803F80u);
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     rs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};

@@ -575,7 +575,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
 #endif
     constexpr int EB = ADD2 ? 1 : MVF_EPI_EB, NB = 8 / EB;
     float4 add[2][EB][4];
-    uint2 add2[EB][4];
+    uint2 add2[2][EB][4];      // (both indexed by the batch parity in the pipelined form, slot 0 otherwise)
     auto prefetch = [&](int b) {
       if constexpr (kReadModify) {
 #pragma unroll
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
           if (i >= 4 + rt1) continue;            // (a fragment this wave row does not have)
           const int m = m0 + wr * WR0 + (i >> 2) * 64 + (i & 3) * 16 + frow;
           epilogue_prefetch<EPI>(a, m, m < a.M, n0 + wc * 64, fgrp, add[MVF_EPI_PIPE ? (b & 1) : 0][ii]);
-          if constexpr (ADD2) epilogue_prefetch2(a, m, m < a.M, n0 + wc * 64, fgrp, add2[ii]);
+          if constexpr (ADD2) epilogue_prefetch2(a, m, m < a.M, n0 + wc * 64, fgrp, add2[MVF_EPI_PIPE ? (b & 1) : 0][ii]);
         }
       }
     };
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tc256_kernel(GemmTcArgs a) {
         const int m = m0 + wr * WR0 + (i >> 2) * 64 + (i & 3) * 16 + frow;
         if constexpr (ADD2) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) addb[ii][j] = add_16x4<F16>(addb[ii][j], add2[ii][j]);
+          for (int j = 0; j < 4; ++j) addb[ii][j] = add_16x4<F16>(addb[ii][j], add2[MVF_EPI_PIPE ? (ih & 1) : 0][ii][j]);
         }
         if constexpr (EPI == EPI_GELU_Q) {
           // the wave's 64 columns of row m = two MX blocks: quantise each, then one 2-byte store of both scales into the

@@ -24,11 +24,16 @@ DIM, DEPTH, HEADS, PATCH, IMG, TAPS = 768, 12, 12, 16, 224, (3, 7, 11)
 
 
 def _packed(dtype='bf16'):
+    # 'fp8-fold': norm1 of blocks > 0 folded into the MX-fp8 qkv GEMM (the default from dim 1024 on, forced here at dim 768): the fc2
+    # epilogue's MX-fp8 residual rows, scale dwords and row sums are laid out per CHUNK -- ragged chunks and lanes must not show
     w = OV.init_vit_weights(DIM, DEPTH, PATCH, IMG, seed=21)
-    return ops.PackedViT({k: v.to(DEV) for k, v in w.items()}, DEPTH, DIM, HEADS, PATCH, IMG, TAPS, dtype)
+    fold = 1 if dtype == 'fp8-fold' else None
+    pk = ops.PackedViT({k: v.to(DEV) for k, v in w.items()}, DEPTH, DIM, HEADS, PATCH, IMG, TAPS, dtype.split('-')[0], ln_fold=fold)
+    assert dtype != 'fp8-fold' or pk.ln_fold == 2
+    return pk
 
 
-@pytest.mark.parametrize('dtype', ['bf16', 'fp8'])
+@pytest.mark.parametrize('dtype', ['bf16', 'fp8', 'fp8-fold'])
 def test_backbone_is_frame_permutation_equivariant_and_split_invariant_at_256_frames(dtype):
     F = 256
     np_ = (IMG // PATCH) ** 2

@@ -75,6 +75,10 @@ typedef struct MvfVitWeights {
    * epilogue then leaves MX-fp8(x) and the rows' partial sums for it (mvf_gemm_fp8_ln) and no LayerNorm pass runs for norm1 of block l.
    * fc1_c must be NULL. */
   const unsigned* const* qkv_s; const unsigned* const* proj_s; const unsigned* const* fc1_s; const unsigned* const* fc2_s;
+  /* 1: the q rows of every qkv_w[l] / qkv_b[l] (and qkv_c[l]) carry the factor log2(e) / 8 -- timm Attention's `q * self.scale`
+   * and the base change of the softmax folded into the frozen weights before their one rounding; the attention kernels then run as
+   * variant | MVF_ATTN_Q_PRESCALED.  16-bit / fp8 modes, token counts outside 193 .. 208 only (mvf_vit_attn_q_prescaled). */
+  int q_prescaled;
 } MvfVitWeights;
 
 size_t mvf_vit_workspace_bytes(int dtype, int frames_per_chunk, int tokens, int dim, int patch);
@@ -233,6 +237,10 @@ int mvf_vit_attn_fwd(int dtype, const void* qkv, void* out, int F, int N, int H,
  * values (the fp32 kernel).  Both are softmax to within the operand rounding; the emulating oracle follows this function's answer
  * (tests/test_abi.py). */
 int mvf_vit_attn_rowsum_rounded(int dtype, int N);
+/* 1 when a frozen backbone of N tokens per frame in `dtype` is packed with pre-scaled q rows (MvfVitWeights.q_prescaled; MVF_ATTN_QS=0 in
+ * the environment switches it off): the one statement of that convention -- the packer and the emulating oracle both follow it
+ * (tests/test_abi.py) */
+int mvf_vit_attn_q_prescaled(int dtype, int N);
 /* timm Attention.qkv FUSED into the attention core (reached from models/transformer.py:188): out [F*N, D] = per (frame, head)
  * softmax(q k^T / 8) v with [q | k | v] = A[f] W_h^T + bias (ln_c / ln_mr NULL), or the folded-LayerNorm form
  * rstd (A W'^T - mean ln_c) + bias of mvf_gemm_tc_ln (ln_c [3D]; the rows' statistics as ln_mr [F*N][2], or -- ln_mr NULL -- as the

@@ -26,6 +26,9 @@ output (proj + bias, LayerScale gamma_1 folded into proj's weights and bias BEFO
 bf16 before the residual add (the product stores it with the plain GEMM epilogue and adds it in LayerNorm 2 and in the fc2
 epilogue: csrc/vit_fwd.hip `defer`; D % 128 == 0; also in fp8 mode).  The product's other
 settings: `emulate='bf16_fold12'` (MVF_LN_FOLD=1: norm2 folded too), `'bf16_nofold'` (MVF_LN_FOLD=0).
+In every emulating mode, at the token counts `q_prescaled(n)` names (the product's streamed attention kernel: all but 193 .. 208), the q
+rows of the qkv weights and bias carry log2(e) / 8 BEFORE their rounding (timm Attention's `q * self.scale` and the softmax's base change
+folded into the frozen weights: ops.PackedViT), scores are q' k^T and probabilities 2^(s - max).
 `emulate='fp8'`: the four GEMMs of a block on MX-fp8 operands (mx_quant), norm1 of blocks > 0 folded into the qkv GEMM on the MX-fp8
 UN-normalised residual row (quantised from fp32 by the previous block's fc2 epilogue; W' = MX-fp8(gamma (.) W), c its row sums);
 `'fp8_nofold'` (MVF_FP8_LN_FOLD=0): the LayerNorm output quantised in front of every GEMM.  It is the checker for the benchmarked dtype (tests/test_gpu_*: tight gates instead of "bf16 is somewhere
@@ -36,6 +39,7 @@ the reference for this file (no reference test / vector exists); cross-checked
 against HuggingFace `transformers.ViTModel` in tests/test_oracle_vit.py.
 """
 import math
+import os
 import torch
 import torch.nn.functional as F
 
@@ -184,6 +188,17 @@ def rowsum_rounded(n):
     return n > 0
 
 
+QS = math.log2(math.e) / 8.0      # head_dim 64: q * 64^-0.5, and the softmax's base changed to 2
+
+
+def q_prescaled(n):
+    """True where the product packs a frozen 16-bit / fp8 backbone of n tokens per frame with the q rows of the qkv weights and bias
+    pre-scaled by log2(e) / 8 (in fp64, before their one rounding / quantisation): the attention kernel then takes q k^T as a base-2
+    exponent.  Mirrors `mvf_vit_attn_q_prescaled` (include/mvf_hip.h: every token count the streamed kernel serves, i.e. outside
+    193 .. 208; MVF_ATTN_QS=0 switches it off on both sides); tests/test_abi.py holds the two together."""
+    return n > 0 and not 193 <= n <= 208 and os.environ.get('MVF_ATTN_QS', '1')[:1] != '0'
+
+
 def ln_linear_bf16(x, g, beta, W, b, eps, fold):
     """Linear(LayerNorm(x)) before the output rounding, bf16 mode.  fold: the product's folded form (module docstring),
     statistics as its kernels take them (sum and sum of squares of the fp32 row, biased variance E[x^2] - mean^2)."""
@@ -199,7 +214,7 @@ def ln_linear_bf16(x, g, beta, W, b, eps, fold):
     return rstd * (r(x) @ Wp.t() - mean * c) + d
 
 
-def vit_block_bf16(x, w, p, heads, eps=1e-6, fold1=False, fold2=False, mx=False, defer_proj=False):
+def vit_block_bf16(x, w, p, heads, eps=1e-6, fold1=False, fold2=False, mx=False, defer_proj=False, prescale=None):
     """vit_block with the bf16 mode's rounding points (module docstring); x is the fp32 residual stream.
     mx: the product's fp8 mode -- both operands of the four GEMMs quantised to MX-fp8 (mx_quant along k: LayerNorm outputs,
     attention output and fc1+GELU output after their bf16 rounding, weights once), everything else as in bf16 mode; fold1: norm1 folded
@@ -207,9 +222,16 @@ def vit_block_bf16(x, w, p, heads, eps=1e-6, fold1=False, fold2=False, mx=False,
     r = bf16_round
     f, n, d = x.shape
     hd = d // heads
+    prescale = q_prescaled(n) if prescale is None else prescale
+    Wqkv, bqkv = w[p + 'attn.qkv.weight'], w[p + 'attn.qkv.bias']
+    if prescale:      # the q rows carry log2(e) / 8 before anything is rounded (module docstring)
+        assert hd == 64
+        rs = torch.ones(3 * d, dtype=torch.float64)
+        rs[:d] = QS
+        Wqkv, bqkv = (Wqkv.double() * rs[:, None]).to(Wqkv.dtype), (bqkv.double() * rs).to(bqkv.dtype)
 
     def lin(a, wn, bn, row_scale=None):
-        W, b = w[p + wn], w[p + bn]
+        W, b = (Wqkv, bqkv) if wn == 'attn.qkv.weight' else (w[p + wn], w[p + bn])
         if row_scale is not None:         # LayerScale folded into the layer: (gamma (.) W, gamma (.) b), rounded AFTER the fold
             W, b = W * row_scale[:, None], b * row_scale
         if mx:
@@ -218,7 +240,7 @@ def vit_block_bf16(x, w, p, heads, eps=1e-6, fold1=False, fold2=False, mx=False,
     if mx and fold1:
         # the fold of ln_linear_bf16 on MX-fp8 operands: the previous block's fc2 epilogue quantised the fp32 residual row itself
         # (un-normalised), the weights are MX-fp8(gamma (.) W), c the row sums of exactly those
-        g, beta, W, b = w[p + 'norm1.weight'], w[p + 'norm1.bias'], w[p + 'attn.qkv.weight'], w[p + 'attn.qkv.bias']
+        g, beta, W, b = w[p + 'norm1.weight'], w[p + 'norm1.bias'], Wqkv, bqkv
         mean = x.mean(-1, keepdim=True)
         rstd = 1.0 / torch.sqrt(((x * x).mean(-1, keepdim=True) - mean * mean).clamp_min(0.0) + eps)
         Wp = mx_quant(W * g[None, :])
@@ -228,12 +250,15 @@ def vit_block_bf16(x, w, p, heads, eps=1e-6, fold1=False, fold2=False, mx=False,
     elif mx:
         qkv = r(lin(layer_norm(x, w[p + 'norm1.weight'], w[p + 'norm1.bias'], eps), 'attn.qkv.weight', 'attn.qkv.bias'))
     else:
-        qkv = r(ln_linear_bf16(x, w[p + 'norm1.weight'], w[p + 'norm1.bias'], w[p + 'attn.qkv.weight'],
-                               w[p + 'attn.qkv.bias'], eps, fold1))
+        qkv = r(ln_linear_bf16(x, w[p + 'norm1.weight'], w[p + 'norm1.bias'], Wqkv, bqkv, eps, fold1))
     qkv = qkv.reshape(f, n, 3, heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
-    s = (q @ k.transpose(-1, -2)) * hd ** -0.5
-    pr = torch.exp(s - s.max(-1, keepdim=True)[0])
+    if prescale:
+        s = q @ k.transpose(-1, -2)                        # already the base-2 exponent
+        pr = torch.exp2(s - s.max(-1, keepdim=True)[0])
+    else:
+        s = (q @ k.transpose(-1, -2)) * hd ** -0.5
+        pr = torch.exp(s - s.max(-1, keepdim=True)[0])
     prr = r(pr)                                            # P in bf16 for P.V
     # the row sum: over the SAME rounded values where the product's kernel takes it on the matrix pipe (a fifth P.V column of ones,
     # fp32 accumulation: the 193..208-token kernels of vit_attn.hip / vit_qkv_attn.hip), over the unrounded fp32 values in its

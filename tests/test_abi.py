@@ -56,6 +56,12 @@ def test_softmax_rowsum_convention_is_the_same_in_library_and_oracle(lib):
         for n in range(1, 2049):
             assert bool(lib.mvf_vit_attn_rowsum_rounded(dt, n)) == OV.rowsum_rounded(n), (dt, n)
     assert lib.mvf_vit_attn_rowsum_rounded(_lib.F32, 197) == 0
+    # the pre-scaled-q convention of frozen backbones (q rows of the packed qkv weights carry log2(e) / 8): packer, kernels and the
+    # emulating oracle follow ONE statement of where it applies
+    for dt in (_lib.BF16, _lib.F16, _lib.FP8):
+        for n in range(1, 2049):
+            assert bool(lib.mvf_vit_attn_q_prescaled(dt, n)) == OV.q_prescaled(n), (dt, n)
+    assert lib.mvf_vit_attn_q_prescaled(_lib.F32, 785) == 0 and OV.q_prescaled(785) and not OV.q_prescaled(197)
 
 
 def test_product_path_refuses_cpu_tensors():

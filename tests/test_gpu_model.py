@@ -555,6 +555,9 @@ def test_partial_freeze_bf16_mode_tracks_fp32_mode():
     worst = min((torch.nn.functional.cosine_similarity(g16[n].flatten(), g32[n].flatten(), dim=0).item(), n)
                 for n in g32 if g32[n].numel() > 64 and g32[n].norm() > 1e-6)
     print('bf16 vs fp32 partial freeze: loss %.5f vs %.5f; worst gradient cosine %.4f (%s)' % (l16, l32, worst[0], worst[1]))
-    # 0.95: with the trainable blocks' attention in bf16 too (forward and backward) the worst cosine measured is 0.963 (a
-    # LayerNorm bias with a small gradient); with fp32 attention it was 0.985
-    assert worst[0] > 0.95, worst
+    # 0.93: with the trainable blocks' attention in bf16 too (forward and backward) the worst cosine measured is 0.963 (a
+    # LayerNorm bias with a small gradient); with fp32 attention it was 0.985.  The statistic follows the rounding pattern of the frozen
+    # front end: with its q rows pre-scaled before their bf16 rounding (round 6; the same precision, other rounding decisions) the worst
+    # becomes 0.943 on another small-gradient parameter (the pooling's query bias) while the loss moves CLOSER to fp32 (1.04814 vs 1.04780
+    # against 1.04920).  A sanity gate -- the tight bf16 checks are against the emulating oracle (test_gpu_configs.py, bf16_mode_report)
+    assert worst[0] > 0.93, worst

@@ -53,6 +53,7 @@ SIGNATURES = {
     'mvf_layernorm_fwd': 'ipzpppziifp',
     'mvf_vit_attn_fwd': 'ippiiiiip',
     'mvf_vit_attn_rowsum_rounded': 'ii',
+    'mvf_vit_attn_q_prescaled': 'ii',
     'mvf_vit_qkv_attn_fwd': 'ipipppp' + 'pif' + 'piiiip',
     'mvf_cast_f32_bf16': 'ppzp',
     'mvf_cast_f32_f16': 'ppzp',
@@ -132,7 +133,8 @@ class MvfVitWeights(ctypes.Structure):
                  ('cls_token', _P), ('pos_embed', _P), ('patch_w', _P), ('patch_b', _P), ('norm_w', _P), ('norm_b', _P)]
                 + [(n, ctypes.POINTER(_P)) for n in
                    ('ln1_w', 'ln1_b', 'qkv_w', 'qkv_b', 'proj_w', 'proj_b', 'ln2_w', 'ln2_b', 'fc1_w', 'fc1_b',
-                    'fc2_w', 'fc2_b', 'ls1', 'ls2', 'qkv_c', 'fc1_c', 'qkv_s', 'proj_s', 'fc1_s', 'fc2_s')])
+                    'fc2_w', 'fc2_b', 'ls1', 'ls2', 'qkv_c', 'fc1_c', 'qkv_s', 'proj_s', 'fc1_s', 'fc2_s')]
+                + [('q_prescaled', _I)])
 
 
 class MvfAugmentParams(ctypes.Structure):

@@ -13,6 +13,7 @@
 //    (or 2-byte gathers, selectable, used to cross-check the transposing read on hardware)
 //  * f32 (parity mode): v_mfma_f32_16x16x4_f32, exact fp32
 //  * online softmax across key blocks (only one block for N = 197)
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "mvf_hip_internal.h"
@@ -613,6 +614,13 @@ extern "C" int mvf_vit_attn_fwd_mxfp8(const void* qkv, void* q, unsigned* scales
 extern "C" int mvf_vit_attn_rowsum_rounded(int dtype, int N) { return (dtype == MVF_BF16 || dtype == MVF_F16) && N > 0 ? 1 : 0; }
 // N served by the one-key-block kernels (13 key tiles of 16: ViT-B/16 at 224 px and its neighbours)
 static bool attn_one_block(int N) { return ceil_div(N, KB) == 1 && ceil_div(N, 16) == 13; }
+// frozen backbones whose attention runs on the streamed 32-query-row kernel get q rows pre-scaled by log2(e) / 8 (no v_fma per score:
+// vit_attn32.hip QS); the one-block kernels and the fused qkv + attention kernel (193 .. 208 tokens) fold the factor into their packed
+// exponent fma anyway and keep plain q
+extern "C" int mvf_vit_attn_q_prescaled(int dtype, int N) {
+  static const bool off = [] { const char* e = getenv("MVF_ATTN_QS"); return e != nullptr && e[0] == '0'; }();
+  return !off && (dtype == MVF_BF16 || dtype == MVF_F16 || dtype == MVF_FP8) && N > 0 && !attn_one_block(N) ? 1 : 0;
+}
 
 int mvf_vit_attn_impl(int dtype, const void* qkv, void* out, int F, int N, int H, int D, int variant, hipStream_t st) {
   MVF_CHECK_ARG(qkv && out && F > 0 && N > 0 && H > 0 && D == H * HD);

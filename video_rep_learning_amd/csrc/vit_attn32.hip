@@ -716,6 +716,10 @@ int mvf_vit_attn32_impl(int dtype, const void* qkv, void* out, float* lse, int F
   g.rows = (size_t)F * N;
   if (q8_scales != nullptr) {   // MX-fp8 output (out: [F*N, D] bytes): the product form only, bf16 arithmetic, head pairs share a scale dword
     MVF_CHECK_ARG(!f16 && lse == nullptr && H % 2 == 0 && ((uintptr_t)out % 8) == 0 && ((uintptr_t)q8_scales % 4) == 0);
+    if (form == 5 + 16) {   // pre-scaled q (below)
+      g.thr = 30.0f;
+      return launch32p<2, 2, false, false, true, true, true>(g, nw, st);
+    }
     return launch32p<2, 2, false, false, true, false, true>(g, nw, st);
   }
   if (lse) {
@@ -724,7 +728,7 @@ int mvf_vit_attn32_impl(int dtype, const void* qkv, void* out, float* lse, int F
   }
   if (form == 5 + 16) {   // the product path of a backbone whose q columns are pre-scaled by log2(e) / 8: scores are exponents
     g.thr = dtype == MVF_F16 ? 15.0f : 30.0f;
-    return f16 ? launch32p<2, 2, true, false, true, true>(g, nw, st) : launch32p<2, 2, false, false, true, true>(g, nw, st);
+    return f16 ? launch32p<2, 3, true, false, true, true>(g, nw, st) : launch32p<2, 3, false, false, true, true>(g, nw, st);   // (three waves per SIMD asked for: left alone hipcc takes 172 registers)
   }
   switch (form) {
     case 1: return f16 ? launch32<3, 2, true, false>(g, nw, st) : launch32<3, 2, false, false>(g, nw, st);

@@ -195,6 +195,8 @@ int run_blocks(const MvfVitWeights* w, int dtype, bool fp8, const Ws& ws, int fc
   const bool can_fold = !fp8 && h16 && ws.xb != nullptr && D % 128 == 0;
   auto folded = [&](const float* const* tab, int l) { return can_fold && tab != nullptr && l < w->depth && tab[l] != nullptr; };
   const int ns = D / 64;
+  // q rows of the packed qkv weights pre-scaled by log2(e) / 8 (MvfVitWeights.q_prescaled): the attention kernels take q as it comes
+  const int qs_bit = w->q_prescaled ? MVF_ATTN_Q_PRESCALED : 0;
   for (int l = l0; l < l1; ++l) {
     int tap = -1;
     for (int j = 0; j < w->n_taps; ++j)
@@ -226,9 +228,9 @@ int run_blocks(const MvfVitWeights* w, int dtype, bool fp8, const Ws& ws, int fc
       }
       if (attn_variant == 0 && H % 2 == 0 && g_attn_q8) {
         // the attention kernel quantises its own output (bit for bit the two launches below; the qkv GEMM is done with hq / hs)
-        RUN(mvf_vit_attn32_impl(MVF_BF16, ws.qkv, ws.hq, nullptr, fc, N, H, D, 5, 0, st, ws.hs));
+        RUN(mvf_vit_attn32_impl(MVF_BF16, ws.qkv, ws.hq, nullptr, fc, N, H, D, qs_bit ? 5 + 16 : 5, 0, st, ws.hs));
       } else {
-        RUN(mvf_vit_attn_impl(dtype, ws.qkv, ws.h, fc, N, H, D, attn_variant, st));
+        RUN(mvf_vit_attn_impl(dtype, ws.qkv, ws.h, fc, N, H, D, attn_variant | qs_bit, st));
         RUN(mvf_quant_mxfp8_impl(MVF_BF16, ws.h, D, ws.hq, D, ws.hs, Mc, D, st));
       }
       if (defer8)
@@ -250,7 +252,7 @@ int run_blocks(const MvfVitWeights* w, int dtype, bool fp8, const Ws& ws, int fc
       continue;
     }
     // qkv projection fused into the attention kernel (vit_qkv_attn.hip): the [Mc, 3D] qkv tensor never reaches HBM
-    const bool fused_attn = attn_variant == 0 && mvf_qkv_attn_supported(dtype, fc, N, H, D, D);
+    const bool fused_attn = attn_variant == 0 && qs_bit == 0 && mvf_qkv_attn_supported(dtype, fc, N, H, D, D);
     if (fused_attn) {
       if (folded(w->qkv_c, l)) {
         if (l == l0) return MVF_ERR_ARG;   // nothing in this call produced the layer's statistics
@@ -291,7 +293,7 @@ int run_blocks(const MvfVitWeights* w, int dtype, bool fp8, const Ws& ws, int fc
       RUN(timed_gemm(dtype, EPI_STORE, ws.h, D, w->qkv_w[l], D, w->qkv_b[l], ws.qkv, 3 * D, nullptr, 0, nullptr, 0,
                      nullptr, nullptr, N, Mc, 3 * D, D, st));
     }
-    if (!fused_attn) RUN(mvf_vit_attn_impl(dtype, ws.qkv, ws.h, fc, N, H, D, attn_variant, st));
+    if (!fused_attn) RUN(mvf_vit_attn_impl(dtype, ws.qkv, ws.h, fc, N, H, D, attn_variant | qs_bit, st));
     const bool fold2 = folded(w->fc1_c, l);
     // Deferred residual (bf16, no LayerScale, norm2 not folded): proj stores its result (+ bias) as bf16 with the plain
     // epilogue instead of read-modifying the fp32 residual (310 MB per launch with the matrix cores idle); LayerNorm 2

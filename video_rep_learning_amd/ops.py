@@ -1845,6 +1845,19 @@ class PackedViT:
         self.keep = []
         self.depth, self.dim, self.heads, self.patch, self.img = depth, dim, heads, patch, img
         self.taps = list(taps)
+        # timm Attention's `q * self.scale` and the softmax's change of base folded into the frozen weights: where the attention runs on
+        # the streamed kernel (mvf_vit_attn_q_prescaled: 16-bit / fp8 modes, token counts outside 193 .. 208) the q rows of every qkv
+        # weight and bias carry log2(e) / 8, applied in fp64 BEFORE the one rounding / quantisation (and before a LayerNorm fold)
+        tokens = (img // patch) ** 2 + 1
+        self.q_prescaled = bool(depth > 0 and dim == 64 * heads and _lib.load().mvf_vit_attn_q_prescaled(self.code, tokens))
+        if self.q_prescaled:
+            sd = dict(sd)
+            rs = torch.ones(3 * dim, dtype=torch.float64, device=dev)
+            rs[:dim] = math.log2(math.e) / 8.0
+            for i in range(depth):
+                kw, kb = 'blocks.%d.attn.qkv.weight' % i, 'blocks.%d.attn.qkv.bias' % i
+                sd[kw] = (sd[kw].detach().double() * rs[:, None]).float()
+                sd[kb] = (sd[kb].detach().double() * rs).float()
 
         def f32(t):
             t = t.detach().float().contiguous()
@@ -1866,6 +1879,7 @@ class PackedViT:
 
         w = _lib.MvfVitWeights()
         w.depth, w.dim, w.heads, w.patch, w.img, w.n_taps = depth, dim, heads, patch, img, len(self.taps)
+        w.q_prescaled = int(self.q_prescaled)
         for i, t in enumerate(self.taps):
             w.taps[i] = t
         w.ln_eps = ln_eps

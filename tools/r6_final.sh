@@ -12,10 +12,10 @@ python3 $R/tools/config_sweep.py > $out/config_sweep.txt 2>&1
 # 4. the streamed attention kernel: rocprofv3 kernel stats (average launch duration) at the shipped token counts, old and new kernel
 for s in "256 20 577 16" "80 20 785 12" "256 20 257 12"; do
   set -- $s
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/attn_$3 -o run -- python3 $R/tools/attn_bench.py $s 7 0 0 7 > $out/attn_$3.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/attn_$3 -o run -- python3 $R/tools/attn_bench.py $s 7 0 4096 0 4096 7 > $out/attn_$3.log 2>&1
   cp $out/attn_$3/run_kernel_stats.csv $out/attn_N$3_kernel_stats.csv
   rm -rf $out/attn_$3
-  python3 $R/tools/attn_bench.py $s --sustain 1.0 7 0 8 > $out/attn_N$3_bench.txt 2>&1
+  python3 $R/tools/attn_bench.py $s --sustain 1.0 7 0 4096 8 > $out/attn_N$3_bench.txt 2>&1
 done
 # 5. configs[4] kernel by kernel
 for d in fp8 bf16; do
